@@ -1,0 +1,270 @@
+"""Known-answer and cross-check tests of the oracle's four estimator kinds."""
+import numpy as np
+import pytest
+
+from lrr_amd import synth
+from oracle import binding as ob
+from tests import np_reference as ref
+
+
+def _corner_only(fs):
+    """all-CORNER projectors reduce the path to point-to-point ICP"""
+    n = fs.n
+    return synth.FeatureSet(fs.loc.copy(), np.tile(np.eye(3).ravel(), (n, 1)), fs.strength.copy(),
+                            np.zeros(n, dtype=np.uint8), fs.dirs.copy())
+
+
+def _noiseless_pair(n, seed, kind):
+    """moving = planted^-1(fixed), same points in a different order: the planted transform is
+    the exact fixed point of the iteration"""
+    pair = synth.make_pair(n, n, seed, kind=kind, noise=0.0, outlier_frac=0.0)
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(n)
+    fx = pair.fixed
+    mv = synth._pull_back(fx.subset(perm), pair.planted)
+    return fx, mv, pair.planted
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("kind,dof", [(ob.CDCL_FORWARD, 6), (ob.CDCL_FORWARD, 12), (ob.RRL_FORWARD, 12)])
+def test_forward_recovers_planted_transform(oracle_lib, kind, dof):
+    fx, mv, T = _noiseless_pair(3000, 11, "rigid" if dof == 6 else "affine")
+    if dof == 6:
+        fx, mv = _corner_only(fx), _corner_only(mv)
+    T0 = synth.perturbed(T, 5, rot_deg=0.2, trans_mm=0.3)
+    e = ob.OracleEstimator(kind, dof, mv, fx, T0.A, T0.t, T0.c, seed=3)
+    e.set_number_points(3000)
+    for it in range(25):
+        e.one_iteration(it)
+    A, t, c, cov = e.get_transform()
+    got = synth.Transform(A, t, c)
+    x = mv.loc[:200]
+    assert np.abs(got.map(x) - T.map(x)).max() < 1e-7
+    assert np.all(np.isfinite(cov))
+
+
+def test_forward_run_uses_1000_points_and_stops(oracle_lib):
+    # number_points_ stays min(1000, N) in the forward class (cdcl .txx:60-66), run() <= 30 its
+    fx, mv, T = _noiseless_pair(2500, 12, "affine")
+    T0 = synth.perturbed(T, 6, rot_deg=0.1, trans_mm=0.1)
+    e = ob.OracleEstimator(ob.CDCL_FORWARD, 12, mv, fx, T0.A, T0.t, T0.c, seed=4)
+    conv, its = e.run(30)
+    assert e.number_points() == 1000
+    assert e.matches()[0].shape[0] == 1000
+    assert conv and its < 30
+
+
+@pytest.mark.parametrize("normalize,strength", [(False, False), (True, False), (True, True)])
+def test_forward_estimate_LS_against_numpy(oracle_lib, normalize, strength):
+    pair = synth.make_pair(2000, 1800, 13, kind="affine")
+    T0 = synth.perturbed(pair.planted, 7)
+    e = ob.OracleEstimator(ob.CDCL_FORWARD, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=5)
+    e.set_number_points(1800)
+    if normalize:
+        e.normalize_matches()
+    e.weight_by_strength(strength)
+    e.inject_initial_scale(1.7)  # independent of the (unpinned) MUSE restatement
+    e.set_transform(T0.A, T0.t, T0.c)
+    e.set_number_points(1800)
+    e.find_closest_euclidean()
+    frm, to, w1 = e.matches()
+    assert np.all(w1 == 1.0)
+    # matches are exact nearest neighbours of the mapped points
+    y = T0.map(pair.moving.loc[frm])
+    d = ((pair.fixed.loc[None, :, :] - y[:200, None, :]) ** 2).sum(-1)
+    assert np.array_equal(to[:200], d.argmin(1))
+    e.estimate_LS(True)
+    AtA, Atb = e.normal_equations()
+    # numpy restatement, normalisation on the fly
+    p, q, P = pair.moving.loc[frm], pair.fixed.loc[to], pair.fixed.proj[to]
+    A, t, c = T0.A, T0.t, T0.c
+    if normalize:
+        cm, rm, cf, rf = ref.centres_radii(p, pair.fixed.loc, to)
+        A, t = ref.normalize_trans(A, t, c, rm, rf, cm, cf)
+        c = np.zeros(3)
+        p, q = (p - cm) / rm, (q - cf) / rf
+    r2 = ref.residual2(A, t, c, p, q, P)
+    sigma = 1.7
+    w = ref.weight_BT(r2 / sigma**2) / sigma**2
+    if strength:
+        g = ref.strength_gain(pair.moving.strength[frm], pair.fixed.strength[to], False)
+        nz = w != 0
+        w = np.where(nz, w * g, w) / ref.mad_scale(g[nz])
+    AtA_np, Atb_np = ref.normal_equations(12, p, c, q, P, w)
+    assert _rel(AtA, AtA_np) < 1e-11
+    assert _rel(Atb, Atb_np) < 1e-11
+    assert np.allclose(e.matches()[2], w, rtol=1e-12, atol=0)
+    # the solve, and the un-normalisation of the transform
+    theta = np.linalg.solve(AtA_np, Atb_np)
+    A2, t2 = theta[:9].reshape(3, 3), theta[9:]
+    if normalize:
+        A2 = rf / rm * A2
+        t2 = rf * t2 + cf
+        c2 = cm
+    else:
+        c2 = T0.c
+    Ao, to_, co, cov = e.get_transform()
+    assert _rel(Ao, A2) < 1e-8 and _rel(to_, t2) < 1e-8 and np.allclose(co, c2, atol=1e-12)
+    # clouds are restored after the in-place normalisation: second scale is the plain RMS
+    # of the (new) residuals because find_closest_euclidean resets every weight to 1
+    e.find_closest_euclidean()
+    e.estimate_LS(True)
+    assert e.last_scale() > 0
+
+
+def test_rigid_increment_matches_numpy(oracle_lib):
+    pair = synth.make_pair(1500, 1500, 14, kind="rigid")
+    T0 = synth.perturbed(pair.planted, 8)
+    e = ob.OracleEstimator(ob.CDCL_FORWARD, 6, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=6)
+    e.set_number_points(1500)
+    e.inject_initial_scale(2.0)
+    e.set_transform(T0.A, T0.t, T0.c)
+    e.set_number_points(1500)
+    e.one_iteration(0)
+    frm, to, w = e.matches()
+    AtA, Atb = e.normal_equations()
+    # premapped from_ = G(p); increment = identity; b = q - p'
+    p1 = T0.map(pair.moving.loc[frm])
+    q, P = pair.fixed.loc[to], pair.fixed.proj[to]
+    r2 = ref.residual2(np.eye(3), np.zeros(3), np.zeros(3), p1, q, P)
+    wn = ref.weight_BT(r2 / 4.0) / 4.0
+    AtA_np, Atb_np = ref.normal_equations(6, p1, np.zeros(3), q, P, wn, rigid_increment=True)
+    assert _rel(AtA, AtA_np) < 1e-11 and _rel(Atb, Atb_np) < 1e-11
+    theta = np.linalg.solve(AtA_np, Atb_np)
+    da, db, dg = theta[:3]
+    dR = np.array([[1, -dg, db], [dg, 1, -da], [-db, da, 1]])
+    U, _, Vt = np.linalg.svd(dR)
+    dR = U @ Vt
+    # recompose_increment (cdcl_trans_rigid3d.cxx:309-325): R <- R dR ; t <- dR t + dt
+    A, t, c, _ = e.get_transform()
+    assert _rel(A, T0.A @ dR) < 1e-10
+    assert _rel(t, dR @ T0.t + theta[3:]) < 1e-10
+    assert np.allclose(c, T0.c)
+
+
+def _sym(kind, dof, pair, T0, mi=None, fi=None, seed=9):
+    m_in = pair.moving if mi is None else pair.moving.subset(mi)
+    f_in = pair.fixed if fi is None else pair.fixed.subset(fi)
+    return ob.OracleEstimator(kind, dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                              moving_inside=m_in, fixed_inside=f_in, seed=seed)
+
+
+def test_rrl_symmetric_estimate_LS_against_numpy(oracle_lib):
+    pair = synth.make_pair(2500, 2400, 15, kind="affine")
+    T0 = synth.perturbed(pair.planted, 9)
+    e = _sym(ob.RRL_SYMMETRIC, 12, pair, T0)
+    e.inject_initial_scale(1.5, 1.6)
+    e.set_transform(T0.A, T0.t, T0.c)
+    e.set_number_points(10**6)
+    e.find_closest_euclidean()
+    ff, ft, _ = e.matches(0)
+    bf, bt, _ = e.matches(1)
+    Ti = T0.inverse()
+    Ab, tb, cb, _ = e.get_transform(1)
+    assert _rel(Ab, Ti.A) < 1e-12 and _rel(tb, Ti.t) < 1e-12
+    e.estimate_LS(True)
+    AtA, Atb = e.normal_equations()
+    # forward list: p in moving_inside(=moving), q in fixed; backward: p_b in fixed, q_b in moving
+    st = lambda a: a.astype(np.float32).astype(np.float64)
+    p, q, P = pair.moving.loc[ff], pair.fixed.loc[ft], pair.fixed.proj[ft]
+    pb, qb, Pb = pair.fixed.loc[bf], pair.moving.loc[bt], pair.moving.proj[bt]
+    wf = ref.weight_BT(ref.residual2(T0.A, T0.t, T0.c, p, q, P) / 1.5**2) / 1.5**2
+    wb = ref.weight_BT(ref.residual2(Ti.A, Ti.t, Ti.c, pb, qb, Pb) / 1.6**2) / 1.6**2
+    cm, rm, cf, rf = ref.centres_radii(p, pair.fixed.loc, ft)
+    A, t = ref.normalize_trans(T0.A, T0.t, T0.c, rm, rf, cm, cf)
+    pn, qn = (p - cm) / rm, (q - cf) / rf
+    pbn, qbn = (pb - cf) / rf, (qb - cm) / rm
+    for w, sp, sq in ((wf, pair.moving.strength[ff], pair.fixed.strength[ft]),
+                      (wb, pair.fixed.strength[bf], pair.moving.strength[bt])):
+        g = ref.strength_gain(st(sp), st(sq), True)
+        nz = w != 0
+        w[:] = np.where(nz, w * g, w) / ref.mad_scale(g[nz])
+    for w, qq in ((wf, qn), (wb, qbn)):
+        sw = 1.0 / (1.0 + 5.0 * (qq**2).sum(1))
+        w[:] = w * sw / ref.mad_scale(sw)
+    a1, b1 = ref.normal_equations(12, pn, np.zeros(3), qn, P, wf, skip=1e-4)
+    # backward term: J of the forward transform at q_b, projector of p_b, rhs p_b
+    a2, b2 = ref.normal_equations(12, qbn, np.zeros(3), pbn, pair.fixed.proj[bf], wb, skip=1e-4)
+    assert _rel(AtA, a1 + a2) < 1e-11 and _rel(Atb, b1 + b2) < 1e-11
+    assert np.allclose(e.matches(0)[2], wf, rtol=1e-11) and np.allclose(e.matches(1)[2], wb, rtol=1e-11)
+    theta = np.linalg.solve(a1 + a2, b1 + b2)
+    A2, t2 = rf / rm * theta[:9].reshape(3, 3), rf * theta[9:] + cf
+    Ao, to_, co, cov = e.get_transform(0)
+    assert _rel(Ao, A2) < 1e-8 and _rel(to_, t2) < 1e-8 and np.allclose(co, cm)
+    assert _rel(cov[:9, :9], (rf / rm) ** 2 * np.linalg.inv(a1 + a2)[:9, :9]) < 1e-7
+    # backward = inverse of the new forward (rrl sym .txx:910-912)
+    Ab, tb, cb, _ = e.get_transform(1)
+    Tn = synth.Transform(Ao, to_, co).inverse()
+    assert _rel(Ab, Tn.A) < 1e-10 and _rel(tb, Tn.t) < 1e-10 and np.allclose(cb, 0)
+
+
+@pytest.mark.parametrize("kind,dof", [(ob.RRL_SYMMETRIC, 12), (ob.CDCL_SYMMETRIC, 12), (ob.CDCL_SYMMETRIC, 6)])
+def test_symmetric_schedule_and_convergence(oracle_lib, kind, dof):
+    fx, mv, T = _noiseless_pair(5000, 16, "rigid" if dof == 6 else "affine")
+    if dof == 6:
+        # Reference defect, reproduced by the oracle: with normalisation on, the rigid increment
+        # is solved as I+[w]x in normalised coordinates, un-normalised to (rf/rm)(I+[w]x) with a
+        # translation that compensates the scale, and then orthogonalised by recompose_increment
+        # (cdcl_trans_rigid3d.cxx:284-325), which drops the scale but keeps the compensation: a
+        # spurious translation (1 - rf/rm) * centre per iteration.  With clouds ~270 mm from the
+        # origin that diverges; centred clouds keep it small enough to converge.
+        fx.loc -= 150.0
+        mv.loc -= 150.0
+        T = synth.Transform(T.A, T.t - 150.0, T.c - 150.0)
+    pair = synth.VolumePair(fx, mv, T, 300.0)
+    T0 = synth.perturbed(T, 10, rot_deg=0.2, trans_mm=0.3)
+    e = _sym(kind, dof, pair, T0)
+    seen = []
+    conv = False
+    for it in range(70):  # the caller's loop: rrl/itkLocationRegistration.cxx:2418
+        conv = e.one_iteration(it)
+        seen.append(e.matches(0)[0].shape[0])
+        if conv:
+            break
+    # coarse-to-fine: 1000 -> 2000 -> 4000 -> all (number_matches_ *= 2)
+    assert seen[0] == 1000 and seen[-1] == 5000
+    assert sorted(set(seen)) == [1000, 2000, 4000, 5000]
+    assert e.finest_level()
+    A, t, c, _ = e.get_transform(0)
+    x = mv.loc[:200]
+    tol = 1e-6 if dof == 12 else 0.5  # rigid + normalisation: see the defect note above
+    assert np.abs(synth.Transform(A, t, c).map(x) - T.map(x)).max() < tol
+    if kind == ob.RRL_SYMMETRIC:
+        assert conv
+
+
+def test_set_features_resets_schedule(oracle_lib):
+    pair = synth.make_pair(20000, 20000, 17, kind="affine")
+    T0 = synth.perturbed(pair.planted, 11)
+    rois = synth.query_rois(pair, 2, 17, half=70.0, min_features=1000)
+    assert len(rois) == 2
+    (_, _, mi, fi), (_, _, mi2, fi2) = rois
+    e = _sym(ob.RRL_SYMMETRIC, 12, pair, T0, mi, fi)
+    for it in range(6):
+        e.one_iteration(it)
+    assert e.number_points(0) > 1000 or e.finest_level()
+    e.set_features(pair.moving.subset(mi2), pair.fixed.subset(fi2))
+    e.set_transform(T0.A, T0.t, T0.c)
+    assert e.number_points(0) == min(1000, mi2.size) and not e.finest_level()
+    assert e.matches(0)[0].shape[0] == 0
+    assert e.weighted_error(0) == 0.0  # no matches yet -> 0 (rrl .txx:249-275)
+    e.one_iteration(0)
+    assert e.matches(0)[0].shape[0] == min(1000, mi2.size)
+
+
+def test_diagnostics_smoke(oracle_lib):
+    pair = synth.make_pair(3000, 3000, 18, kind="affine", noise=0.1, outlier_frac=0.0)
+    e = _sym(ob.RRL_SYMMETRIC, 12, pair, pair.planted)
+    for it in range(3):
+        e.one_iteration(it)
+    sa, ta = e.sheet_angles(0), e.tube_angles(0)
+    assert 0 <= sa < 0.2 and 0 <= ta < 0.2  # correctly aligned surfaces: small angle differences
+    cj, cb = e.compute_transfer_error_covariance()
+    assert np.allclose(cj, cj.T, atol=1e-12) and np.all(np.linalg.eigvalsh(cj) > 0)
+    e.estimate_LS_backward(False)
+    _, _, _, covb = e.get_transform(1)
+    assert np.all(np.isfinite(covb)) and np.abs(covb).max() > 0
+    assert not e.oscillated()

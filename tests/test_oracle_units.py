@@ -1,0 +1,86 @@
+"""Known-answer tests that pin the CPU oracle's building blocks (the reference has no
+tests or golden vectors for this path: SURVEY.md §4, §8c -> parity unpinned)."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+
+
+def test_weight_BT_table(oracle_lib):
+    # cdcl/cdcl_utils.h:142-152: (1 - u/16)^2 for u <= 16 else 0
+    for u, want in [(0.0, 1.0), (4.0, 0.5625), (8.0, 0.25), (16.0, 0.0), (16.0001, 0.0), (100.0, 0.0)]:
+        assert ob.weight_BT(u) == pytest.approx(want, abs=1e-15)
+
+
+def test_mad_scale_formula(oracle_lib):
+    rng = np.random.default_rng(0)
+    for n in (2, 3, 10, 11, 1000, 1001):
+        v = rng.normal(size=n)
+        a = np.sort(np.abs(v))
+        want = 1.4826 * (1 + 5.0 / (n - 1)) * a[(n - 1) // 2 + 1]
+        assert ob.mad_scale(v) == want
+    assert ob.mad_scale(np.array([3.0])) == 0.0
+
+
+def test_muse_recovers_gaussian_sigma(oracle_lib):
+    rng = np.random.default_rng(1)
+    for sigma in (0.3, 2.0):
+        r = np.abs(rng.normal(scale=sigma, size=20000))
+        assert ob.muse_scale(r) == pytest.approx(sigma, rel=0.03)
+        # 30 % gross outliers: bounded upward bias.  The k-th inlier sits at quantile k/(0.7 n)
+        # of the inlier distribution but is priced at k/n, so the smallest fraction (0.25) gives
+        # sigma * Phi^-1((1+.25/.7)/2) / Phi^-1((1+.25)/2) = 1.455 sigma at best.
+        r2 = r.copy()
+        r2[:6000] = rng.uniform(5 * sigma, 50 * sigma, size=6000)
+        assert 1.3 * sigma < ob.muse_scale(r2) < 1.7 * sigma
+    # scale equivariance
+    r = np.abs(rng.normal(size=5000))
+    assert ob.muse_scale(3.0 * r) == pytest.approx(3.0 * ob.muse_scale(r), rel=1e-12)
+
+
+def test_nn_brute_equals_kdtree_with_ties(oracle_lib):
+    rng = np.random.default_rng(2)
+    f = rng.uniform(0, 50, size=(4000, 3))
+    f[100:200] = f[0:100]            # exact duplicates -> distance ties, lowest index must win
+    f[300:400] = np.round(f[300:400])  # lattice points -> more ties
+    q = np.concatenate([rng.uniform(-10, 60, size=(3000, 3)), f[150:250], np.round(rng.uniform(0, 50, size=(500, 3)))])
+    a = ob.nn(f, q, ob.NN_BRUTE)
+    b = ob.nn(f, q, ob.NN_KDTREE)
+    assert np.array_equal(a, b)
+    d = ((f[:, None, :] - q[None, :50, :]) ** 2).sum(-1)
+    assert np.array_equal(a[:50], d.argmin(0))
+    # a query that IS a duplicated fixed point returns the lower index
+    assert np.all(a[3000:3050] < 100)
+
+
+def test_nn_empty_and_single(oracle_lib):
+    f = np.array([[1.0, 2.0, 3.0]])
+    q = np.zeros((4, 3))
+    assert np.array_equal(ob.nn(f, q, ob.NN_BRUTE), np.zeros(4, dtype=np.int64))
+    assert np.array_equal(ob.nn(f, q, ob.NN_KDTREE), np.zeros(4, dtype=np.int64))
+    assert ob.nn(f, np.zeros((0, 3))).shape == (0,)
+    assert np.array_equal(ob.nn(np.zeros((0, 3)), q, ob.NN_KDTREE), -np.ones(4, dtype=np.int64))
+
+
+def test_shuffle_is_a_seeded_permutation(oracle_lib):
+    a, s1 = ob.shuffle(1000, 42)
+    b, s2 = ob.shuffle(1000, 42)
+    c, _ = ob.shuffle(1000, 43)
+    assert np.array_equal(a, b) and s1 == s2
+    assert not np.array_equal(a, c)
+    assert np.array_equal(np.sort(a), np.arange(1000))
+
+
+def test_sym_pinv_and_svd3(oracle_lib):
+    rng = np.random.default_rng(3)
+    for n in (6, 12):
+        B = rng.normal(size=(n + 5, n))
+        M = B.T @ B
+        assert np.allclose(ob.sym_pinv(M), np.linalg.inv(M), rtol=1e-9, atol=1e-12)
+    for _ in range(20):
+        M = rng.normal(size=(3, 3))
+        U, s, V = ob.svd3(M)
+        assert np.allclose(U @ np.diag(s) @ V.T, M, atol=1e-13)
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-13)
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-13)
+        assert np.allclose(np.sort(s), np.sort(np.linalg.svd(M, compute_uv=False)), atol=1e-13)
