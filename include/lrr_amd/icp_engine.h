@@ -1,0 +1,740 @@
+// icp_engine.h — host side of the MI355X robust-ICP estimators.
+//
+// Two class templates carry the logic of the reference's four estimator classes:
+//   icp_direction<dof, Feature, RRL>  <-> cdcl_estimation_ICP_matching_all (RRL = false,
+//        cdcl/cdcl_estimation_ICP_matching_all.{h,txx}) and rrl_estimation_ICP_matching_all
+//        (RRL = true, rrl/rrl_estimation_ICP_matching_all.{h,txx})
+//   icp_symmetric<dof, Feature, RRL>  <-> cdcl_/rrl_estimation_symmetric_ICP_matching_all
+// Same method names, argument meaning and state machine (number_points_ schedule,
+// scale_estimated_, oscillation counters); every per-match loop of the reference is one call
+// into the C-ABI of include/lrr_icp.h.  The host keeps only O(dof^2) arithmetic: transform
+// bookkeeping, the dof x dof solve, convergence logic.
+//
+// What differs from the reference by design:
+//   * feature objects are never mutated: cdcl_normalize_matches() computes the centres/radii
+//     and the kernels normalise on the fly (the reference rewrites location_ in place and
+//     restores it, cdcl .txx:1159-1286);
+//   * std::random_shuffle(rand()) is a seeded keyed permutation evaluated on the device;
+//   * matches_ lives in HBM and is materialised as cdcl_match objects only on demand
+//     (callbacks, sheet/tube angles);
+//   * failures of the device layer throw std::runtime_error (the reference prints and goes on).
+#ifndef LRR_AMD_ICP_ENGINE_H_
+#define LRR_AMD_ICP_ENGINE_H_
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lrr_amd/cdcl_types.h"
+#include "lrr_amd/linalg.h"
+#include "lrr_icp.h"
+
+// ---- abstract interface (cdcl/cdcl_estimation_abs.h:20-65) -----------------------------------
+template <unsigned int dim, unsigned int dof, class feature_typeT = cdcl_feature<dim> >
+class cdcl_estimation_abs : public vbl_ref_count {
+ public:
+  typedef vbl_smart_ptr<cdcl_estimation_abs> sptr;
+  typedef feature_typeT feature_type;
+  typedef typename feature_type::sptr feature_sptr_type;
+  typedef cdcl_match<dim, feature_type> match_type;
+  typedef cdcl_trans<dim, dof> trans_type;
+  typedef typename match_type::sptr match_sptr_type;
+  typedef typename trans_type::sptr trans_sptr_type;
+  typedef void (*display_callback_type)(void *caller, vcl_vector<feature_sptr_type> const &moving_,
+                                        vcl_vector<feature_sptr_type> const &fixed_,
+                                        vcl_vector<match_sptr_type> const &matches_,
+                                        trans_sptr_type const &transform, unsigned int iteration);
+  cdcl_estimation_abs() {}
+  virtual void initialize() = 0;
+  virtual bool run(void *caller = 0, display_callback_type display_points = 0) = 0;
+};
+
+namespace lrr_amd {
+
+// One device context per host thread, created on first use on the device selected by
+// set_device() or the LRR_ICP_DEVICE environment variable (default 0).
+class device {
+ public:
+  static void set_device(int index) { slot().want = index; }
+  static lrr_icp_ctx *ctx() {
+    state &s = slot();
+    if (!s.ctx) {
+      int dev = s.want;
+      if (dev < 0) {
+        const char *e = std::getenv("LRR_ICP_DEVICE");
+        dev = e ? std::atoi(e) : 0;
+      }
+      if (lrr_icp_create(dev, &s.ctx) != LRR_ICP_OK || !s.ctx)
+        throw std::runtime_error("lrr_amd: cannot create a HIP context on device " + std::to_string(dev) +
+                                 " (no usable MI355X / HIP runtime): the ICP estimators have no CPU path");
+    }
+    return s.ctx;
+  }
+  static void release() {
+    state &s = slot();
+    if (s.ctx) lrr_icp_destroy(s.ctx);
+    s.ctx = nullptr;
+  }
+
+ private:
+  struct state { lrr_icp_ctx *ctx = nullptr; int want = -1; };
+  static state &slot() { static thread_local state s; return s; }
+};
+
+inline void check(int rc, const char *what) {
+  if (rc != LRR_ICP_OK) throw std::runtime_error(std::string("lrr_amd: ") + what + " failed: " + lrr_icp_last_error(device::ctx()));
+}
+
+template <class F> struct feature_traits;
+template <unsigned d> struct feature_traits<cdcl_feature_with_shape<d> > { static const bool float_strength = false; };
+template <unsigned d> struct feature_traits<cdcl_feature_ICP<d> > { static const bool float_strength = true; };
+
+// a feature vector resident on the device
+template <class FeatureT>
+class device_cloud {
+ public:
+  device_cloud() : h_(nullptr) {}
+  ~device_cloud() { reset(); }
+  device_cloud(const device_cloud &) = delete;
+  device_cloud &operator=(const device_cloud &) = delete;
+  void reset() { if (h_) lrr_icp_cloud_destroy(h_); h_ = nullptr; }
+  void upload(const std::vector<typename FeatureT::sptr> &f) {
+    reset();
+    const size_t n = f.size();
+    std::vector<double> loc(3 * n + 3), proj(9 * n + 9), st(n + 1);
+    for (size_t i = 0; i < n; ++i) {
+      for (int d = 0; d < 3; ++d) loc[3 * i + d] = f[i]->location_[d];
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) proj[9 * i + 3 * r + c] = f[i]->error_projector_(r, c);
+      st[i] = (double)f[i]->strength_;
+    }
+    check(lrr_icp_cloud_create(device::ctx(), (int64_t)n, loc.data(), proj.data(), st.data(),
+                               feature_traits<FeatureT>::float_strength ? 1 : 0, &h_), "cloud upload");
+  }
+  lrr_icp_cloud *handle() const { return h_; }
+
+ private:
+  lrr_icp_cloud *h_;
+};
+
+template <unsigned dof, class FeatureT, bool RRL> class icp_symmetric;
+
+// =============================================================================================
+// forward estimator
+// =============================================================================================
+template <unsigned dof, class FeatureT, bool RRL>
+class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
+ public:
+  static const unsigned dim = 3;
+  typedef cdcl_estimation_abs<3, dof, FeatureT> superclass_type;
+  typedef FeatureT feature_type;
+  typedef typename superclass_type::feature_sptr_type feature_sptr_type;
+  typedef typename superclass_type::match_type match_type;
+  typedef typename superclass_type::match_sptr_type match_sptr_type;
+  typedef typename superclass_type::trans_sptr_type trans_sptr_type;
+  typedef typename superclass_type::display_callback_type display_callback_type;
+  typedef vnl_vector_fixed<double, 3> vec3;
+  friend class icp_symmetric<dof, FeatureT, RRL>;
+
+  // (cdcl .txx:73-91; rrl .txx:89-113)
+  icp_direction(vcl_vector<feature_sptr_type> const &moving, vcl_vector<feature_sptr_type> const &fixed,
+                trans_sptr_type const &trans)
+      : trans_(trans), res_(0), number_points_(1000), normalize_matches_(false), weight_by_strength_(false),
+        scale_estimated_(false) {
+    moving_.push_back(moving);
+    fixed_.push_back(fixed);
+    init_state();
+    this->build_kd_trees();
+    upload_moving();
+    if (number_points_ > moving_[res_].size()) number_points_ = (unsigned)moving_[res_].size();
+  }
+  virtual ~icp_direction() { if (dir_) lrr_icp_dir_destroy(dir_); }
+
+  // ---- reference public interface (cdcl/cdcl_estimation_ICP_matching_all.h:73-135)
+  virtual bool run(void *caller = 0, display_callback_type display_points = 0) {
+    this->initialize();
+    bool converged = false;
+    unsigned int max_iterations = 30, iteration = 0;
+    while (!converged && iteration < max_iterations) {
+      converged = this->one_iteration(caller, display_points, iteration);
+      ++iteration;
+    }
+    iterations_run_ = iteration;
+    return converged;
+  }
+  virtual void initialize() {}
+
+  // (cdcl .txx:434-509; rrl .txx:427-462)
+  virtual bool one_iteration(void *caller, display_callback_type display_points, unsigned int iteration) {
+    this->find_closest_euclidean();
+    if (caller && display_points) display_points(caller, moving_[res_], fixed_[res_], this->matches(), trans_, iteration);
+    double RMS_before = this->RMS_error();
+    trans_sptr_type global_transform;
+    const bool rigid = is_rigid();
+    if (rigid) global_transform = begin_rigid_increment();
+    this->estimate_LS(true);
+    if (rigid) end_rigid_increment(global_transform);
+    // NB rigid: from_ are still the pre-mapped copies, so they are mapped twice here, as in
+    // the reference (cdcl .txx:499 against :477)
+    double RMS_after = this->RMS_error();
+    return std::fabs(RMS_before - RMS_after) < 1e-4;
+  }
+
+  // (cdcl .txx:139-153)
+  void set_transform(trans_sptr_type const &trans) {
+    trans_ = trans;
+    scale_estimated_ = false;
+    number_points_ = 1000;
+    if (number_points_ > moving_[res_].size()) number_points_ = (unsigned)moving_[res_].size();
+  }
+  trans_sptr_type get_transform() { return trans_; }
+  void normalize_matches() { normalize_matches_ = true; }
+  // (cdcl .h:96)
+  void set_moving_data(vcl_vector<vcl_vector<feature_sptr_type> > const &moving) {
+    moving_ = moving;
+    upload_moving();
+    invalidate_matches();
+  }
+
+  // (cdcl .txx:196-230; the rrl class never increments `count` and returns the raw sum, rrl .txx:211-241)
+  double RMS_error() {
+    double s2 = 0, swr = 0, sw = 0;
+    errors(s2, swr, sw);
+    if (RRL) return s2;
+    int64_t count = lrr_icp_dir_num_matches(dir_);
+    return count != 0 ? std::sqrt(s2 / double(count)) : s2;
+  }
+  // (cdcl .txx:236-268)
+  double weighted_error() {
+    double s2 = 0, swr = 0, sw = 0;
+    errors(s2, swr, sw);
+    return sw != 0 ? swr / sw : swr;
+  }
+  // (cdcl .txx:388-404)
+  void compute_transfer_error_covariance() {
+    const vcl_vector<match_sptr_type> &m = this->matches();
+    vnl_matrix_fixed<double, 3, 3> covarJ(0.0);
+    vnl_matrix_fixed<double, dof, dof> covar = trans_->get_covariance();
+    vnl_matrix_fixed<double, 3, dof> J;
+    for (size_t i = 0; i < m.size(); ++i) {
+      trans_->jacobian_wrt_par_thread(m[i]->from_->location_, J);
+      covarJ += J * covar * J.transpose();
+    }
+    covarJ *= (1.0 / double(m.size()));
+    trans_->set_covarianceJ(covarJ);
+  }
+  double sheet_angles() { return angles(false); }
+  double tube_angles() { return angles(true); }
+  void weight_by_strength(bool flag) { weight_by_strength_ = flag; }
+  // (cdcl .txx:826-862; rrl .txx:722-752)
+  void weight_by_strength() {
+    double gs = 0;
+    check(lrr_icp_weight_by_strength(dir_, nullptr, &gs), "weight_by_strength");
+    matches_dirty_ = true;
+  }
+  // (cdcl .txx:973-1004; rrl .txx:756-778)
+  void weight_spatially() {
+    double ss = 0;
+    check(lrr_icp_weight_spatially(dir_, &norm_, nullptr, nullptr, &ss), "weight_spatially");
+    matches_dirty_ = true;
+  }
+  // (cdcl .txx:113-135): the search structure of the fixed set (here: upload + uniform grid)
+  void build_kd_trees() {
+    fixed_cloud_.upload(fixed_[res_]);
+    rebuild_dir();
+  }
+
+  // ---- protected in the reference, reachable by the friend symmetric classes -----------------
+  // (cdcl .txx:541-654; rrl .txx:494-571)
+  void find_closest_euclidean() {
+    lrr_icp_xform xf = xform_of(trans_);
+    uint32_t keys[4];
+    lrr_icp_perm_keys(&rng_, keys);
+    const int64_t *order = explicit_order_.empty() ? nullptr : explicit_order_.data();
+    check(lrr_icp_match(dir_, &xf, keys, order, (int64_t)number_points_, nn_method_), "find_closest_euclidean");
+    explicit_order_.clear();
+    norm_ = identity_norm();
+    matches_dirty_ = true;
+    premapped_ = false;
+    premap_G_ = trans_sptr_type();
+  }
+  // (cdcl .txx:660-822; rrl .txx:577-718)
+  double estimate_scale_and_assign_weight() {
+    lrr_icp_xform xf = xform_of(trans_);
+    double S = 0, W = 0;
+    check(lrr_icp_residual_pass(dir_, &xf, &norm_, &S, &W), "residual pass");
+    double scale;
+    if (!scale_estimated_) {
+      if (injected_scale_ > 0.0) scale = injected_scale_;
+      else check(lrr_icp_muse_scale(dir_, &scale), "MUSE scale");
+      scale_estimated_ = true;
+    } else {
+      scale = std::sqrt(S / W);
+    }
+    check(lrr_icp_assign_weights(dir_, scale), "assign weights");
+    last_scale_ = scale;
+    matches_dirty_ = true;
+    return scale;
+  }
+  // (cdcl .txx:1009-1093; rrl .txx:783-859)
+  void estimate_LS(bool estimate_parameters = false) {
+    vec3 cm(0.0), cf(0.0);
+    double rm = 0.0, rf = 0.0;
+    if (normalize_matches_) {
+      this->cdcl_normalize_matches(cm, rm, cf, rf);
+      trans_->normalize(rm, rf, cm, cf);
+    }
+    this->estimate_scale_and_assign_weight();
+    if (weight_by_strength_) this->weight_by_strength();
+    double AtA[dof * dof], Atb[dof];
+    accumulate(trans_, (!RRL && is_rigid()) ? LRR_ICP_ACC_RIGID_INCREMENT : 0, AtA, Atb);
+    solve_and_set(trans_, AtA, Atb, estimate_parameters);
+    if (normalize_matches_) {
+      trans_->unnormalize(rm, rf, cm, cf);
+      this->cdcl_unnormalize_matches(cm, rm, cf, rf);
+    }
+  }
+  // (cdcl .txx:1159-1240): statistics only; the kernels normalise on the fly from now on
+  void cdcl_normalize_matches(vec3 &center_moving, double &avg_radius_moving, vec3 &center_fixed, double &avg_radius_fixed) {
+    lrr_icp_norm nm;
+    check(lrr_icp_normalize_stats(dir_, &nm), "normalize statistics");
+    for (int d = 0; d < 3; ++d) { center_moving[d] = nm.cm[d]; center_fixed[d] = nm.cf[d]; }
+    avg_radius_moving = nm.rm;
+    avg_radius_fixed = nm.rf;
+    norm_ = nm;
+  }
+  // (cdcl sym .txx:869-908; rrl sym .txx:1093-1129)
+  void cdcl_normalize_matches_known(vec3 const &center_moving, double avg_radius_moving, vec3 const &center_fixed, double avg_radius_fixed) {
+    for (int d = 0; d < 3; ++d) { norm_.cm[d] = center_moving[d]; norm_.cf[d] = center_fixed[d]; }
+    norm_.rm = avg_radius_moving;
+    norm_.rf = avg_radius_fixed;
+  }
+  // (cdcl .txx:1245-1286)
+  void cdcl_unnormalize_matches(vec3 const &, double, vec3 const &, double) { norm_ = identity_norm(); }
+  // (cdcl .txx:94-108)
+  bool set_number_points(unsigned int number_points) {
+    if (number_points >= moving_[res_].size()) {
+      number_points_ = (unsigned)moving_[res_].size();
+      return true;
+    }
+    number_points_ = number_points;
+    return false;
+  }
+  // matches_ of the reference, materialised from the device on demand
+  vcl_vector<match_sptr_type> const &matches() {
+    if (matches_dirty_) {
+      int64_t n = lrr_icp_dir_num_matches(dir_);
+      std::vector<int64_t> fi((size_t)n + 1), ti((size_t)n + 1);
+      std::vector<double> w((size_t)n + 1);
+      check(lrr_icp_get_matches(dir_, fi.data(), ti.data(), w.data()), "get matches");
+      matches_.clear();
+      matches_.reserve((size_t)n);
+      for (int64_t i = 0; i < n; ++i) {
+        match_sptr_type m = new match_type;
+        feature_sptr_type p = moving_[res_][(size_t)fi[(size_t)i]];
+        if (premapped_) {  // new feature at G(p) (cdcl .txx:473-479)
+          feature_sptr_type c = new feature_type(*p);
+          c->location_ = premap_G_->map_loc(p->location_);
+          p = c;
+        }
+        m->from_ = p;
+        m->to_.push_back(fixed_[res_][(size_t)ti[(size_t)i]]);
+        m->w_.push_back(w[(size_t)i]);
+        matches_.push_back(m);
+      }
+      matches_dirty_ = false;
+    }
+    return matches_;
+  }
+
+  // ---- hooks that do not exist in the reference (tests, benchmarks) --------------------------
+  void set_subset_seed(uint64_t seed) { rng_ = seed; }
+  void inject_initial_scale(double s) { injected_scale_ = s; }
+  void set_subset_order(std::vector<int64_t> const &order) { explicit_order_ = order; }
+  void set_nn_method(int method) { nn_method_ = method; }
+  double last_scale() const { return last_scale_; }
+  unsigned number_points() const { return number_points_; }
+  unsigned iterations_run() const { return iterations_run_; }
+  lrr_icp_dir *device_dir() const { return dir_; }
+  void last_normal_equations(double *AtA, double *Atb) const {
+    for (unsigned i = 0; i < dof * dof; ++i) AtA[i] = last_AtA_[i];
+    for (unsigned i = 0; i < dof; ++i) Atb[i] = last_Atb_[i];
+  }
+
+ protected:
+  static lrr_icp_norm identity_norm() {
+    lrr_icp_norm n;
+    for (int d = 0; d < 3; ++d) n.cm[d] = n.cf[d] = 0.0;
+    n.rm = n.rf = 1.0;
+    return n;
+  }
+  static lrr_icp_xform xform_of(trans_sptr_type const &T) {
+    lrr_icp_xform x;
+    vnl_matrix_fixed<double, 3, 3> &A = T->get_A();
+    vnl_vector_fixed<double, 3> &t = T->get_translation();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) x.A[3 * r + c] = A(r, c); x.t[r] = t[r]; x.c[r] = T->center_moving_[r]; }
+    return x;
+  }
+  bool is_rigid() const { return !RRL && dof == 6 && trans_->is_type(cdcl_trans_rigid3d::type_id()); }
+  void init_state() {
+    dir_ = nullptr;
+    rng_ = 1;
+    injected_scale_ = -1.0;
+    last_scale_ = 0.0;
+    nn_method_ = LRR_ICP_NN_AUTO;
+    norm_ = identity_norm();
+    matches_dirty_ = true;
+    premapped_ = false;
+    iterations_run_ = 0;
+    for (unsigned i = 0; i < dof * dof; ++i) last_AtA_[i] = 0.0;
+    for (unsigned i = 0; i < dof; ++i) last_Atb_[i] = 0.0;
+  }
+  void upload_moving() {
+    moving_cloud_.upload(moving_[res_]);
+    rebuild_dir();
+  }
+  void rebuild_dir() {
+    if (!moving_cloud_.handle() || !fixed_cloud_.handle()) return;
+    if (dir_) lrr_icp_dir_destroy(dir_);
+    dir_ = nullptr;
+    check(lrr_icp_dir_create(device::ctx(), moving_cloud_.handle(), fixed_cloud_.handle(), &dir_), "dir create");
+    invalidate_matches();
+  }
+  void invalidate_matches() {
+    matches_.clear();
+    matches_dirty_ = true;
+    premapped_ = false;
+    norm_ = identity_norm();
+  }
+  void errors(double &s2, double &swr, double &sw) {
+    lrr_icp_xform xf = xform_of(trans_);
+    check(lrr_icp_errors(dir_, &xf, &s2, &swr, &sw), "error metrics");
+  }
+  void accumulate(trans_sptr_type const &jac_trans, int flags, double *AtA, double *Atb) {
+    double c[3] = {jac_trans->center_moving_[0], jac_trans->center_moving_[1], jac_trans->center_moving_[2]};
+    check(lrr_icp_accumulate(dir_, (int)dof, c, &norm_, flags, AtA, Atb), "normal equations");
+  }
+  // C = svd(AtA).inverse(); covariance = C; theta = C Atb (cdcl .txx:1073-1083)
+  void solve_and_set(trans_sptr_type const &T, const double *AtA, const double *Atb, bool estimate_parameters) {
+    for (unsigned i = 0; i < dof * dof; ++i) last_AtA_[i] = AtA[i];
+    for (unsigned i = 0; i < dof; ++i) last_Atb_[i] = Atb[i];
+    vnl_matrix_fixed<double, dof, dof> invAA;
+    linalg::sym_inverse((int)dof, AtA, invAA.data_block());
+    T->set_covariance(invAA);
+    if (estimate_parameters) {
+      vnl_vector<double> p(dof, 0.0);
+      for (unsigned i = 0; i < dof; ++i) {
+        double s = 0.0;
+        for (unsigned k = 0; k < dof; ++k) s += invAA(i, k) * Atb[k];
+        p[i] = s;
+      }
+      T->set_parameterization(p);
+    }
+  }
+  // rigid increment bracket (cdcl .txx:455-484 and :490-496)
+  trans_sptr_type begin_rigid_increment() {
+    trans_sptr_type global_transform = trans_;
+    trans_ = trans_->create_new();
+    trans_->set_covariance(global_transform->get_covariance());
+    lrr_icp_xform G = xform_of(global_transform);
+    check(lrr_icp_premap(dir_, &G), "rigid pre-map");
+    premapped_ = true;
+    premap_G_ = global_transform->clone();
+    matches_dirty_ = true;
+    trans_->set_parameterization(vnl_vector<double>(6, 0.0));
+    return global_transform;
+  }
+  void end_rigid_increment(trans_sptr_type const &global_transform) {
+    global_transform->recompose_increment(trans_);
+    global_transform->set_covariance(trans_->get_covariance());
+    trans_ = global_transform;
+  }
+  // sheet_angles / tube_angles.  cdcl_feature_ICP: mapped directions_ (rrl .txx:281-375).
+  double angles(bool tube) {
+    const vcl_vector<match_sptr_type> &m = this->matches();
+    const double pi = 3.14159265358979323846;
+    double avg = 0.0, sum_weight = 0.0;
+    for (size_t i = 0; i < m.size(); ++i) {
+      feature_type *p = m[i]->from_.as_pointer(), *q = m[i]->to_[0].as_pointer();
+      if (tube ? (p->shape_ != feature_type::TUBE || q->shape_ != feature_type::TUBE)
+               : (p->shape_ != feature_type::SHEET || q->shape_ != feature_type::SHEET)) continue;
+      vec3 dp, dq;
+      if (tube) {
+        if (p->directions_.size() < 2 || q->directions_.size() < 2) continue;
+        dp = cross(p->directions_[0], p->directions_[1]);
+        dq = cross(q->directions_[0], q->directions_[1]);
+      } else {
+        if (p->directions_.empty() || q->directions_.empty()) continue;
+        dp = p->directions_[0];
+        dq = q->directions_[0];
+      }
+      vec3 y = trans_->map_loc(p->location_), y2 = trans_->map_loc(p->location_ + dp);
+      vec3 d = y2 - y;
+      d /= d.magnitude();
+      double a = std::acos(dot_product(d, dq));
+      if (a > pi / 2) a = pi - a;
+      double w = m[i]->w_[0];
+      avg += w * a;
+      sum_weight += w;
+    }
+    return avg / sum_weight;
+  }
+  static vec3 cross(vec3 const &a, vec3 const &b) {
+    return vec3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+  }
+
+  vcl_vector<vcl_vector<feature_sptr_type> > moving_, fixed_;
+  vcl_vector<match_sptr_type> matches_;
+  trans_sptr_type trans_;
+  unsigned int res_;
+  unsigned int number_points_;
+  bool normalize_matches_, weight_by_strength_, scale_estimated_;
+
+  device_cloud<FeatureT> moving_cloud_, fixed_cloud_;
+  lrr_icp_dir *dir_;
+  lrr_icp_norm norm_;
+  uint64_t rng_;
+  double injected_scale_, last_scale_;
+  int nn_method_;
+  bool matches_dirty_, premapped_;
+  trans_sptr_type premap_G_;
+  std::vector<int64_t> explicit_order_;
+  unsigned iterations_run_;
+  double last_AtA_[dof * dof], last_Atb_[dof];
+};
+
+// =============================================================================================
+// symmetric estimator
+// =============================================================================================
+template <unsigned dof, class FeatureT, bool RRL>
+class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
+ public:
+  static const unsigned dim = 3;
+  typedef icp_direction<dof, FeatureT, RRL> estimation_type;
+  typedef cdcl_estimation_abs<3, dof, FeatureT> superclass_type;
+  typedef FeatureT feature_type;
+  typedef typename superclass_type::feature_sptr_type feature_sptr_type;
+  typedef typename superclass_type::match_sptr_type match_sptr_type;
+  typedef typename superclass_type::trans_sptr_type trans_sptr_type;
+  typedef typename superclass_type::display_callback_type display_callback_type;
+  typedef vnl_vector_fixed<double, 3> location_type;
+
+  // (rrl sym .txx:198-220; cdcl sym .txx:144-164)
+  icp_symmetric(vcl_vector<feature_sptr_type> const &moving, vcl_vector<feature_sptr_type> const &fixed,
+                trans_sptr_type const &trans, trans_sptr_type const &trans_inverse,
+                vcl_vector<feature_sptr_type> const &moving_inside, vcl_vector<feature_sptr_type> const &fixed_inside)
+      : normalize_matches_(true), oscillation_count_(0), error_difference_(0.0), weighted_error_(0.0),
+        number_matches_(1000), finest_level_(false) {
+    forward_ = new estimation_type(moving_inside, fixed, trans);
+    backward_ = new estimation_type(fixed_inside, moving, trans_inverse);
+    forward_->weight_by_strength(true);
+    forward_->normalize_matches();
+    backward_->weight_by_strength(true);
+    backward_->normalize_matches();
+    set_subset_seed(1);
+  }
+  // region form (rrl sym .txx:135-192): ROI copies cut out of the full sets
+  icp_symmetric(vcl_vector<feature_sptr_type> const &moving, vcl_vector<feature_sptr_type> const &fixed,
+                trans_sptr_type const &trans, trans_sptr_type const &trans_inverse, location_type const &moving_x0,
+                location_type const &moving_x1, location_type const &fixed_x0, location_type const &fixed_x1)
+      : normalize_matches_(true), oscillation_count_(0), error_difference_(0.0), weighted_error_(0.0),
+        number_matches_(1000), finest_level_(false) {
+    vcl_vector<feature_sptr_type> fixed_inside = inside(fixed, fixed_x0, fixed_x1);
+    vcl_vector<feature_sptr_type> moving_inside = inside(moving, moving_x0, moving_x1);
+    forward_ = new estimation_type(moving_inside, fixed, trans);
+    backward_ = new estimation_type(fixed_inside, moving, trans_inverse);
+    forward_->weight_by_strength(true);
+    forward_->normalize_matches();
+    backward_->weight_by_strength(true);
+    backward_->normalize_matches();
+    set_subset_seed(1);
+  }
+
+  // (rrl sym .txx:224-264)
+  bool set_regions(vcl_vector<feature_sptr_type> const &moving, vcl_vector<feature_sptr_type> const &fixed,
+                   location_type const &moving_x0, location_type const &moving_x1, location_type const &fixed_x0,
+                   location_type const &fixed_x1) {
+    vcl_vector<feature_sptr_type> fixed_inside = inside(fixed, fixed_x0, fixed_x1);
+    vcl_vector<feature_sptr_type> moving_inside = inside(moving, moving_x0, moving_x1);
+    this->set_features(moving_inside, fixed_inside);
+    return !(moving_inside.size() < 1000 || fixed_inside.size() < 1000);
+  }
+  // (rrl sym .txx:268-289)
+  void set_features(vcl_vector<feature_sptr_type> const &moving_inside, vcl_vector<feature_sptr_type> const &fixed_inside) {
+    vcl_vector<vcl_vector<feature_sptr_type> > mm(1, moving_inside), ff(1, fixed_inside);
+    forward_->set_moving_data(mm);
+    backward_->set_moving_data(ff);
+    reset_schedule();
+  }
+  // the exact device search needs no precomputed Voronoi volume (rrl sym .txx:293-299)
+  template <class VoronoiPointer> void set_voronoi_maps(VoronoiPointer const &, VoronoiPointer const &) {}
+  // (rrl sym .txx:303-315)
+  void set_transform(trans_sptr_type const &trans) {
+    forward_->set_transform(trans);
+    backward_->set_transform(trans->inverse());
+    reset_schedule();
+  }
+  virtual void initialize() { forward_->initialize(); backward_->initialize(); }
+  virtual bool run(void * = 0, display_callback_type = 0) { return false; }  // stub in the reference (rrl sym .h)
+  void find_closest_euclidean() { forward_->find_closest_euclidean(); backward_->find_closest_euclidean(); }
+
+  // (rrl sym .txx:341-438; cdcl sym .txx:268-363)
+  virtual bool one_iteration(void *caller, display_callback_type display_points, unsigned int iteration) {
+    double weighted_error_before = forward_->weighted_error();
+    this->find_closest_euclidean();
+    this->estimate_LS(true);
+    if (caller && display_points)
+      display_points(caller, forward_->moving_[forward_->res_], forward_->fixed_[forward_->res_], forward_->matches(), forward_->trans_, iteration);
+    double weighted_error_after = forward_->weighted_error();
+    double curr_error_difference = weighted_error_after - weighted_error_before;
+    double diff = (weighted_error_after - weighted_error_before) / weighted_error_after;
+    bool converged = std::fabs(diff) < 1e-4;
+    weighted_error_ = weighted_error_after;
+    if (!RRL || iteration > 0) {  // the rrl class guards the oscillation logic with iteration > 0 (:387)
+      if (!finest_level_ && (oscillation_count_ > 1 || (std::fabs(diff) < 0.01))) converged = true;
+      else if (!converged) {
+        if (weighted_error_after > 1.5) {
+          if (curr_error_difference * error_difference_ < 0.0) ++oscillation_count_;
+          else if (oscillation_count_ > 0) --oscillation_count_;
+          if (oscillated()) converged = true;
+        } else {
+          if (curr_error_difference > 0.0) ++oscillation_count_;
+          if (oscillation_count_ > 3) converged = true;
+        }
+      }
+    }
+    error_difference_ = curr_error_difference;
+    if (converged && !finest_level_) {
+      converged = false;
+      number_matches_ *= 2;
+      bool forward_at_max = forward_->set_number_points(number_matches_);
+      bool backward_at_max = backward_->set_number_points(number_matches_);
+      finest_level_ = forward_at_max && backward_at_max;
+      oscillation_count_ = 0;
+      error_difference_ = 0.0;
+    }
+    return converged && finest_level_;
+  }
+
+  // (rrl sym .txx:699-918; cdcl sym .txx:398-701)
+  void estimate_LS(bool estimate_parameters) {
+    estimation_type &F = *forward_, &B = *backward_;
+    trans_sptr_type forward_global, backward_global;
+    const bool rigid = !RRL && F.is_rigid();
+    if (rigid) {
+      forward_global = F.begin_rigid_increment();
+      if (B.is_rigid()) backward_global = B.begin_rigid_increment();
+    }
+    F.estimate_scale_and_assign_weight();  // un-normalised coordinates
+    B.estimate_scale_and_assign_weight();
+    location_type cm(0.0), cf(0.0);
+    double rm = 0.0, rf = 0.0;
+    if (normalize_matches_) {
+      F.cdcl_normalize_matches(cm, rm, cf, rf);
+      F.trans_->normalize(rm, rf, cm, cf);
+      B.cdcl_normalize_matches_known(cf, rf, cm, rm);  // flipped centres and radii
+      B.trans_->normalize(rf, rm, cf, cm);
+    }
+    double AtA[dof * dof], Atb[dof], AtA2[dof * dof], Atb2[dof];
+    if (RRL) {
+      if (F.weight_by_strength_) F.weight_by_strength();
+      if (B.weight_by_strength_) B.weight_by_strength();
+      F.weight_spatially();
+      B.weight_spatially();
+      F.accumulate(F.trans_, LRR_ICP_ACC_PREMUL_SKIP, AtA, Atb);
+      // backward term: Jacobian of the FORWARD transform at the backward to_, projector and
+      // right-hand side from the backward from_ (rrl sym .txx:557-646)
+      B.accumulate(F.trans_, LRR_ICP_ACC_PREMUL_SKIP | LRR_ICP_ACC_REVERSED, AtA2, Atb2);
+    } else {
+      // add_constraints (cdcl sym .txx:367-393, 541-546): the role-reversed clones of the backward
+      // matches are weighted together with the forward list, then dropped again
+      double gs = 0, ss = 0;
+      check(lrr_icp_clone_weights(B.dir_), "clone weights");
+      if (F.weight_by_strength_) check(lrr_icp_weight_by_strength(F.dir_, B.dir_, &gs), "merged weight_by_strength");
+      check(lrr_icp_weight_spatially(F.dir_, &F.norm_, B.dir_, &B.norm_, &ss), "merged weight_spatially");
+      F.matches_dirty_ = true;
+      const int rg = rigid ? LRR_ICP_ACC_RIGID_INCREMENT : 0;
+      F.accumulate(F.trans_, rg, AtA, Atb);
+      B.accumulate(F.trans_, rg | LRR_ICP_ACC_REVERSED | LRR_ICP_ACC_CLONE_W, AtA2, Atb2);
+    }
+    for (unsigned i = 0; i < dof * dof; ++i) AtA[i] += AtA2[i];
+    for (unsigned i = 0; i < dof; ++i) Atb[i] += Atb2[i];
+    F.solve_and_set(F.trans_, AtA, Atb, estimate_parameters);
+    if (normalize_matches_) {
+      F.trans_->unnormalize(rm, rf, cm, cf);
+      F.cdcl_unnormalize_matches(cm, rm, cf, rf);
+      B.trans_->unnormalize(rf, rm, cf, cm);
+      B.cdcl_unnormalize_matches(cf, rf, cm, rm);
+    }
+    if (rigid) F.end_rigid_increment(forward_global);
+    if (estimate_parameters) B.trans_ = F.trans_->inverse();
+  }
+  // swap forward_/backward_, estimate_LS, swap back (rrl sym .txx:921-934).  The cdcl class's own
+  // variant (cdcl sym .txx:704-863) is not provided.
+  void estimate_LS_backward(bool estimate_parameters) {
+    if (!RRL) throw std::runtime_error("lrr_amd: estimate_LS_backward is implemented for the rrl class only");
+    vbl_smart_ptr<estimation_type> f = forward_, b = backward_;
+    forward_ = b;
+    backward_ = f;
+    this->estimate_LS(estimate_parameters);
+    forward_ = f;
+    backward_ = b;
+  }
+
+  trans_sptr_type get_transform() { return forward_->get_transform(); }
+  trans_sptr_type get_transform_backward() { return backward_->get_transform(); }
+  void weight_by_strength(bool flag) { forward_->weight_by_strength(flag); backward_->weight_by_strength(flag); }
+  virtual void normalize_matches() { forward_->normalize_matches(); backward_->normalize_matches(); normalize_matches_ = true; }
+  double RMS_error() { return forward_->RMS_error(); }
+  bool oscillated() { return oscillation_count_ > 10; }
+  double weighted_error() { return forward_->weighted_error(); }
+  void compute_transfer_error_covariance() { forward_->compute_transfer_error_covariance(); backward_->compute_transfer_error_covariance(); }
+  double sheet_angles() { return forward_->sheet_angles(); }
+  double tube_angles() { return forward_->tube_angles(); }
+  double weighted_error_backward() { return backward_->weighted_error(); }
+  double sheet_angles_backward() { return backward_->sheet_angles(); }
+  double tube_angles_backward() { return backward_->tube_angles(); }
+
+  // ---- hooks that do not exist in the reference ----------------------------------------------
+  void set_subset_seed(uint64_t seed) { forward_->set_subset_seed(seed); backward_->set_subset_seed(seed ^ 0xD1B54A32D192ED03ULL); }
+  void inject_initial_scale(double fwd, double bwd) { forward_->inject_initial_scale(fwd); backward_->inject_initial_scale(bwd); }
+  void set_number_points(unsigned n) {
+    bool a = forward_->set_number_points(n), b = backward_->set_number_points(n);
+    number_matches_ = n;
+    finest_level_ = a && b;
+  }
+  void set_nn_method(int m) { forward_->set_nn_method(m); backward_->set_nn_method(m); }
+  bool finest_level() const { return finest_level_; }
+  estimation_type &forward() { return *forward_; }
+  estimation_type &backward() { return *backward_; }
+
+ protected:
+  static vcl_vector<feature_sptr_type> inside(vcl_vector<feature_sptr_type> const &all, location_type const &x0, location_type const &x1) {
+    vcl_vector<feature_sptr_type> out;
+    for (size_t i = 0; i < all.size(); ++i) {
+      location_type const &p = all[i]->location_;
+      bool in = true;
+      for (unsigned d = 0; d < 3; ++d) if (x0[d] > p[d] || p[d] > x1[d]) in = false;
+      if (in) out.push_back(new feature_type(*(all[i])));
+    }
+    return out;
+  }
+  void reset_schedule() {
+    oscillation_count_ = 0;
+    error_difference_ = 0.0;
+    number_matches_ = 1000;
+    finest_level_ = false;
+  }
+
+  vbl_smart_ptr<estimation_type> forward_, backward_;
+  bool normalize_matches_;
+  unsigned int oscillation_count_;
+  double error_difference_, weighted_error_;
+  unsigned int number_matches_;
+  bool finest_level_;
+};
+
+}  // namespace lrr_amd
+#endif

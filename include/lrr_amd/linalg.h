@@ -1,0 +1,117 @@
+// linalg.h — the two small dense factorizations the ICP host code needs, standing in for
+// vnl_svd<double> (absent): inverse of the symmetric dof x dof normal matrix
+// (cdcl/cdcl_estimation_ICP_matching_all.txx:1073-1074) and the 3x3 SVD behind
+// cdcl_trans::inverse() / recompose_increment() (cdcl/cdcl_trans_rigid3d.cxx:115, 318).
+#ifndef LRR_AMD_LINALG_H_
+#define LRR_AMD_LINALG_H_
+
+#include <cmath>
+#include <cstring>
+
+namespace lrr_amd {
+namespace linalg {
+
+// inverse of a symmetric n x n matrix (n <= 12) through a cyclic-Jacobi eigen-decomposition;
+// zero eigenvalues are left out, which is what vnl_svd::inverse() does with zero singular values
+inline void sym_inverse(int n, const double *M, double *out) {
+  double A[144], V[144];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      A[i * n + j] = 0.5 * (M[i * n + j] + M[j * n + i]);
+      V[i * n + j] = i == j ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0, dg = 0.0;
+    for (int i = 0; i < n; ++i) {
+      dg += A[i * n + i] * A[i * n + i];
+      for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+    }
+    if (off == 0.0 || off <= 1e-60 * dg) break;
+    for (int p = 0; p + 1 < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        double th = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+        double t = (th >= 0.0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+        double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          double x = A[k * n + p], y = A[k * n + q];
+          A[k * n + p] = c * x - s * y;
+          A[k * n + q] = s * x + c * y;
+        }
+        for (int k = 0; k < n; ++k) {
+          double x = A[p * n + k], y = A[q * n + k];
+          A[p * n + k] = c * x - s * y;
+          A[q * n + k] = s * x + c * y;
+        }
+        for (int k = 0; k < n; ++k) {
+          double x = V[k * n + p], y = V[k * n + q];
+          V[k * n + p] = c * x - s * y;
+          V[k * n + q] = s * x + c * y;
+        }
+      }
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < n; ++k) {
+        double lam = A[k * n + k];
+        if (lam != 0.0) s += V[i * n + k] * V[j * n + k] / lam;
+      }
+      out[i * n + j] = s;
+    }
+}
+
+// one-sided Jacobi SVD of a 3x3 (row-major): M = U diag(s) V^T
+inline void svd3(const double *M, double *U, double *s, double *V) {
+  double W[9];
+  std::memcpy(W, M, sizeof W);
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double a = 0, b = 0, g = 0;
+        for (int k = 0; k < 3; ++k) {
+          a += W[k * 3 + p] * W[k * 3 + p];
+          b += W[k * 3 + q] * W[k * 3 + q];
+          g += W[k * 3 + p] * W[k * 3 + q];
+        }
+        if (g == 0.0 || std::fabs(g) <= 1e-17 * std::sqrt(a * b)) continue;
+        rotated = true;
+        double z = (b - a) / (2.0 * g);
+        double t = (z >= 0.0 ? 1.0 : -1.0) / (std::fabs(z) + std::sqrt(1.0 + z * z));
+        double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+        for (int k = 0; k < 3; ++k) {
+          double x = W[k * 3 + p], y = W[k * 3 + q];
+          W[k * 3 + p] = c * x - sn * y;
+          W[k * 3 + q] = sn * x + c * y;
+          x = V[k * 3 + p]; y = V[k * 3 + q];
+          V[k * 3 + p] = c * x - sn * y;
+          V[k * 3 + q] = sn * x + c * y;
+        }
+      }
+    if (!rotated) break;
+  }
+  for (int j = 0; j < 3; ++j) {
+    double nrm = std::sqrt(W[j] * W[j] + W[3 + j] * W[3 + j] + W[6 + j] * W[6 + j]);
+    s[j] = nrm;
+    for (int k = 0; k < 3; ++k) U[k * 3 + j] = nrm > 0.0 ? W[k * 3 + j] / nrm : 0.0;
+  }
+}
+
+inline void inverse3(const double *M, double *out) {
+  double U[9], s[3], V[9];
+  svd3(M, U, s, V);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0.0;
+      for (int k = 0; k < 3; ++k)
+        if (s[k] != 0.0) a += V[i * 3 + k] * U[j * 3 + k] / s[k];
+      out[i * 3 + j] = a;
+    }
+}
+
+}  // namespace linalg
+}  // namespace lrr_amd
+#endif

@@ -1,0 +1,147 @@
+/*
+ * lrr_icp.h — C-ABI of the MI355X (gfx950) robust-ICP hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its seam is the C++
+ * class family cdcl_estimation_ICP_matching_all / rrl_estimation_symmetric_ICP_matching_all.
+ * The host-side classes in include/lrr_amd/ keep those names and methods and call ONLY the
+ * functions below; every function names the reference loop it replaces (paths relative to the
+ * msofka/LRR repo root).  Plain pointers and sizes, no C++ / torch types, no exceptions: every
+ * function returns 0 on success or a negative code and records a message readable through
+ * lrr_icp_last_error().  One context per host thread; all work of a context is issued on its
+ * own HIP stream.
+ *
+ * Coordinates: "xf" is x -> A (x - c) + t (cdcl_trans_rigid3d.cxx:171-174,
+ * cdcl_trans_affine.txx:112-115).  "norm" carries the normalisation of
+ * cdcl_normalize_matches (cdcl/cdcl_estimation_ICP_matching_all.txx:1159-1240): the reference
+ * rewrites the shared feature objects in place and restores them afterwards; the device clouds
+ * are never mutated, kernels apply (x - centre) / radius on the fly.
+ */
+#ifndef LRR_ICP_H_
+#define LRR_ICP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRR_ICP_OK 0
+#define LRR_ICP_ERR_ARG (-1)
+#define LRR_ICP_ERR_HIP (-2)
+#define LRR_ICP_ERR_STATE (-3)
+
+typedef struct lrr_icp_ctx lrr_icp_ctx;
+typedef struct lrr_icp_cloud lrr_icp_cloud; /* a feature vector resident in HBM + its search grid */
+typedef struct lrr_icp_dir lrr_icp_dir;     /* device state of one (forward) estimation object: matches_, w_ */
+
+typedef struct { double A[9]; double t[3]; double c[3]; } lrr_icp_xform;
+/* from-side points are normalised by (cm, rm), to-side points by (cf, rf); identity = {0,1,0,1} */
+typedef struct { double cm[3]; double rm; double cf[3]; double rf; } lrr_icp_norm;
+
+/* nearest-neighbour methods: both exact, ties -> lowest index */
+enum { LRR_ICP_NN_AUTO = 0, LRR_ICP_NN_BRUTE = 1, LRR_ICP_NN_GRID = 2 };
+
+/* accumulate flags */
+enum {
+  LRR_ICP_ACC_RIGID_INCREMENT = 1, /* b = q - p   (cdcl .txx:1051-1054)                            */
+  LRR_ICP_ACC_REVERSED = 2,        /* role-reversed term: J at to_, projector of from_, b = from_
+                                      (rrl sym .txx:546-655; cdcl sym add_constraints .txx:367-393)  */
+  LRR_ICP_ACC_PREMUL_SKIP = 4,     /* rrl: projector pre-multiplied by w, skip w < 1e-4
+                                      (rrl sym .txx:463-468)                                         */
+  LRR_ICP_ACC_CLONE_W = 8          /* use the clone weights written by the *_merged weighting calls   */
+};
+
+/* ---- context ---------------------------------------------------------------------------- */
+int  lrr_icp_create(int device, lrr_icp_ctx **out);
+void lrr_icp_destroy(lrr_icp_ctx *ctx);
+const char *lrr_icp_last_error(const lrr_icp_ctx *ctx);
+int  lrr_icp_synchronize(lrr_icp_ctx *ctx);
+/* HIP-event stopwatch on the context's stream (bench.py's kernel timing) */
+int  lrr_icp_timer_start(lrr_icp_ctx *ctx);
+int  lrr_icp_timer_stop(lrr_icp_ctx *ctx, double *elapsed_ms);
+/* accumulated device time of the matching kernels since the last reset (HIP events around
+ * every K1 launch when profiling is enabled) */
+int  lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_t *launches, int reset);
+
+/* ---- feature clouds ---------------------------------------------------------------------
+ * Replaces the vcl_vector<feature_sptr> the estimators hold plus build_kd_trees()
+ * (cdcl/cdcl_estimation_ICP_matching_all.txx:113-135) / set_voronoi_maps()
+ * (rrl/rrl_estimation_symmetric_ICP_matching_all.txx:293-299): uploads location_,
+ * error_projector_ (must be symmetric; 9 doubles row-major) and strength_ once and builds the
+ * uniform search grid.  float_strength != 0 rounds strengths to float and makes the strength
+ * product a float multiply (cdcl_feature_ICP.h:83). */
+int  lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const double *proj,
+                          const double *strength, int float_strength, lrr_icp_cloud **out);
+void lrr_icp_cloud_destroy(lrr_icp_cloud *cloud);
+int64_t lrr_icp_cloud_size(const lrr_icp_cloud *cloud);
+
+/* ---- one estimation direction ------------------------------------------------------------ */
+int  lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to, lrr_icp_dir **out);
+void lrr_icp_dir_destroy(lrr_icp_dir *dir);
+/* set_moving_data (cdcl/cdcl_estimation_ICP_matching_all.h:96): new from-cloud, matches cleared */
+int  lrr_icp_dir_set_from(lrr_icp_dir *dir, lrr_icp_cloud *from);
+int64_t lrr_icp_dir_num_matches(const lrr_icp_dir *dir);
+
+/* keys of the seeded subset permutation (stand-in for std::random_shuffle, cdcl .txx:557):
+ * advances *state and fills 4 round keys; perm(i) is evaluated inside the match kernel. */
+void lrr_icp_perm_keys(uint64_t *state, uint32_t keys[4]);
+int64_t lrr_icp_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]);
+
+/* K1 — find_closest_euclidean (cdcl .txx:541-654; rrl .txx:494-571): for i < n_points:
+ * p = from[perm(i)], y = xf(p), q = argmin_j |y - to_j| (exact, ties -> lowest j), w = 1.
+ * order: optional explicit host permutation (n_points indices into the from-cloud); when NULL the
+ * keyed permutation is used. */
+int  lrr_icp_match(lrr_icp_dir *dir, const lrr_icp_xform *xf, const uint32_t keys[4],
+                   const int64_t *order, int64_t n_points, int method);
+
+/* rigid pre-map (cdcl .txx:455-484; cdcl sym .txx:400-456): every match's from_ becomes a new
+ * feature located at G(p) */
+int  lrr_icp_premap(lrr_icp_dir *dir, const lrr_icp_xform *G);
+
+/* K2 pass 1 — estimate_scale_and_assign_weight, first loop (cdcl .txx:677-708; rrl .txx:594-617):
+ * r2_i = max(0, e^T P_q e), e = xf(p~) - q~; stashes r2; returns S = sum w_prev r2, W = sum w_prev */
+int  lrr_icp_residual_pass(lrr_icp_dir *dir, const lrr_icp_xform *xf, const lrr_icp_norm *norm,
+                           double *S, double *W);
+/* rrel_muset_obj(0,false).scale on sqrt(r2) (call sites cdcl .txx:721-725; rrl .txx:630-634) */
+int  lrr_icp_muse_scale(lrr_icp_dir *dir, double *sigma);
+/* K2 pass 2 (cdcl .txx:744-765; rrl .txx:652-671): w_i = BT(r2_i / sigma^2) / sigma^2 */
+int  lrr_icp_assign_weights(lrr_icp_dir *dir, double sigma);
+
+/* K5 — cdcl_normalize_matches statistics (cdcl .txx:1159-1213; rrl .txx:864-916): centroid and
+ * mean radius of from_ over matches and of the DISTINCT matched to_ */
+int  lrr_icp_normalize_stats(lrr_icp_dir *dir, lrr_icp_norm *out);
+
+/* add_constraints (cdcl sym .txx:367-393): the role-reversed clones of this direction's matches
+ * start with a copy of its weights; the merged weighting calls below then work on the copy. */
+int  lrr_icp_clone_weights(lrr_icp_dir *dir);
+/* weight_by_strength() (cdcl .txx:826-862; rrl .txx:722-752).  b may be NULL.  With b != NULL the
+ * two lists are weighted as ONE merged list (cdcl sym .txx:541-544): a's own weights and b's
+ * clone weights. */
+int  lrr_icp_weight_by_strength(lrr_icp_dir *a, lrr_icp_dir *b_merged, double *grad_scale);
+/* weight_spatially() (cdcl .txx:973-1004; rrl .txx:756-778); to-locations normalised by norm.cf/rf.
+ * Merged form as above: b's clones are role-reversed, their to_ is b's from_ (normalised by
+ * norm_b.cm/rm). */
+int  lrr_icp_weight_spatially(lrr_icp_dir *a, const lrr_icp_norm *norm_a, lrr_icp_dir *b_merged,
+                              const lrr_icp_norm *norm_b, double *spatial_scale);
+
+/* K3 — normal equations (cdcl .txx:1039-1069; rrl sym .txx:441-655): AtA (dof x dof row-major,
+ * both triangles filled) and Atb of this list; jac_centre is trans_->center_moving_ of the
+ * transform whose Jacobian is used. */
+int  lrr_icp_accumulate(lrr_icp_dir *dir, int dof, const double jac_centre[3],
+                        const lrr_icp_norm *norm, int flags, double *AtA, double *Atb);
+
+/* K4 — RMS_error / weighted_error in one pass (cdcl .txx:196-268; rrl .txx:211-276):
+ * sum_r2 = sum r2_i, sum_wr = sum sqrt(r2_i) w_i, sum_w = sum w_i */
+int  lrr_icp_errors(lrr_icp_dir *dir, const lrr_icp_xform *xf, double *sum_r2, double *sum_wr,
+                    double *sum_w);
+
+/* matches_ on demand (callbacks, sheet/tube angles): from/to indices into the clouds, weights */
+int  lrr_icp_get_matches(lrr_icp_dir *dir, int64_t *from_idx, int64_t *to_idx, double *w);
+
+/* stand-alone exact nearest neighbour of host query points (tests, diagnostics) */
+int  lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int method, int64_t *idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

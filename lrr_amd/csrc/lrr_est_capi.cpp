@@ -1,0 +1,336 @@
+// lrr_est_capi.cpp — flat C view of the C++ drop-in estimator classes (include/lrr_amd/*.h).
+//
+// The product interface is the C++ class family; this file only exists so that Python
+// (tests/, bench.py, the multi-GPU driver) can drive those classes through ctypes: it builds
+// cdcl_feature_* objects from flat arrays, instantiates the four classes at <3,6> and <3,12>
+// and forwards the reference's method names one to one.  No arithmetic of the hot path lives
+// here.
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "lrr_amd/cdcl_estimation_ICP_matching_all.h"
+#include "lrr_amd/cdcl_estimation_symmetric_ICP_matching_all.h"
+#include "lrr_amd/rrl_estimation_ICP_matching_all.h"
+#include "lrr_amd/rrl_estimation_symmetric_ICP_matching_all.h"
+
+extern "C" {
+typedef struct {
+  int64_t n;
+  const double *loc;       // n x 3
+  const double *proj;      // n x 9
+  const double *strength;  // n
+  const uint8_t *shape;    // n (may be NULL)
+  const double *dirs;      // n x 6 (may be NULL)
+} lrr_est_features;
+}
+
+namespace {
+
+typedef vnl_vector_fixed<double, 3> vec3;
+typedef vnl_matrix_fixed<double, 3, 3> mat3;
+
+thread_local std::string g_error;
+
+template <class F>
+std::vector<typename F::sptr> make_features(const lrr_est_features *f);
+
+template <class F>
+void fill_common(F *p, const lrr_est_features *f, int64_t i) {
+  for (int d = 0; d < 3; ++d) p->location_[d] = f->loc[3 * i + d];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) p->error_projector_(r, c) = f->proj[9 * i + 3 * r + c];
+  p->shape_ = (typename F::shape_type)(f->shape ? f->shape[i] : 0);
+  if (f->dirs) {
+    p->directions_.push_back(vec3(f->dirs[6 * i], f->dirs[6 * i + 1], f->dirs[6 * i + 2]));
+    p->directions_.push_back(vec3(f->dirs[6 * i + 3], f->dirs[6 * i + 4], f->dirs[6 * i + 5]));
+  }
+}
+
+template <>
+std::vector<cdcl_feature_with_shape<3>::sptr> make_features<cdcl_feature_with_shape<3> >(const lrr_est_features *f) {
+  std::vector<cdcl_feature_with_shape<3>::sptr> out;
+  if (!f) return out;
+  out.reserve((size_t)f->n);
+  for (int64_t i = 0; i < f->n; ++i) {
+    cdcl_feature_with_shape<3> *p = new cdcl_feature_with_shape<3>;
+    fill_common(p, f, i);
+    p->strength_ = f->strength ? f->strength[i] : 0.0;
+    out.push_back(p);
+  }
+  return out;
+}
+
+template <>
+std::vector<cdcl_feature_ICP<3>::sptr> make_features<cdcl_feature_ICP<3> >(const lrr_est_features *f) {
+  std::vector<cdcl_feature_ICP<3>::sptr> out;
+  if (!f) return out;
+  out.reserve((size_t)f->n);
+  for (int64_t i = 0; i < f->n; ++i) {
+    cdcl_feature_ICP<3> *p = new cdcl_feature_ICP<3>;
+    fill_common(p, f, i);
+    p->strength_ = (float)(f->strength ? f->strength[i] : 0.0);
+    out.push_back(p);
+  }
+  return out;
+}
+
+template <unsigned dof> struct trans_factory;
+template <> struct trans_factory<6> {
+  static cdcl_trans<3, 6>::sptr make(const double *A, const double *t, const double *c) {
+    mat3 R; vec3 tt, cc;
+    for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) R(r, k) = A[3 * r + k]; tt[r] = t[r]; cc[r] = c[r]; }
+    return new cdcl_trans_rigid3d(R, tt, cc);
+  }
+};
+template <> struct trans_factory<12> {
+  static cdcl_trans<3, 12>::sptr make(const double *A, const double *t, const double *c) {
+    mat3 M; vec3 tt, cc;
+    for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) M(r, k) = A[3 * r + k]; tt[r] = t[r]; cc[r] = c[r]; }
+    return new cdcl_trans_affine<3, 12>(M, tt, cc);
+  }
+};
+
+template <unsigned dof>
+void read_trans(typename cdcl_trans<3, dof>::sptr const &T, double *A, double *t, double *c, double *covar) {
+  if (A) for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) A[3 * r + k] = T->get_A()(r, k);
+  if (t) for (int r = 0; r < 3; ++r) t[r] = T->get_translation()[r];
+  if (c) for (int r = 0; r < 3; ++r) c[r] = T->center_moving_[r];
+  if (covar) for (unsigned r = 0; r < dof; ++r) for (unsigned k = 0; k < dof; ++k) covar[r * dof + k] = T->get_covariance()(r, k);
+}
+
+struct est_base {
+  int dof = 0;
+  virtual ~est_base() {}
+  virtual void set_transform(const double *A, const double *t, const double *c) = 0;
+  virtual void set_features(const lrr_est_features *mi, const lrr_est_features *fi) = 0;
+  virtual void weight_by_strength(bool) = 0;
+  virtual void normalize_matches() = 0;
+  virtual void set_number_points(int64_t n) = 0;
+  virtual void inject_initial_scale(double f, double b) = 0;
+  virtual void set_subset_order(int dir, const int64_t *order, int64_t n) = 0;
+  virtual void set_nn_method(int m) = 0;
+  virtual void find_closest_euclidean() = 0;
+  virtual bool one_iteration(unsigned it) = 0;
+  virtual bool run(unsigned max_it, unsigned *done) = 0;
+  virtual void estimate_LS(bool) = 0;
+  virtual void estimate_LS_backward(bool) = 0;
+  virtual void get_transform(int dir, double *A, double *t, double *c, double *covar) = 0;
+  virtual double RMS_error() = 0;
+  virtual double weighted_error(int dir) = 0;
+  virtual double sheet_angles(int dir) = 0;
+  virtual double tube_angles(int dir) = 0;
+  virtual void transfer_error_covariance(double *cf, double *cb) = 0;
+  virtual bool oscillated() = 0;
+  virtual bool finest_level() = 0;
+  virtual int64_t num_matches(int dir) = 0;
+  virtual void get_matches(int dir, int64_t *f, int64_t *t, double *w) = 0;
+  virtual int64_t number_points(int dir) = 0;
+  virtual double last_scale(int dir) = 0;
+  virtual void normal_equations(double *AtA, double *Atb) = 0;
+};
+
+template <class Dir>
+void dir_matches(Dir &d, int64_t *f, int64_t *t, double *w) {
+  if (lrr_icp_get_matches(d.device_dir(), f, t, w) != LRR_ICP_OK) throw std::runtime_error("get_matches failed");
+}
+
+template <unsigned DOF, class F, class Est>
+struct fwd_impl : est_base {
+  vbl_smart_ptr<Est> e;
+  fwd_impl(const lrr_est_features *m, const lrr_est_features *f, const double *A, const double *t, const double *c, uint64_t seed, int nn) {
+    this->dof = DOF;
+    e = new Est(make_features<F>(m), make_features<F>(f), trans_factory<DOF>::make(A, t, c));
+    e->set_subset_seed(seed);
+    e->set_nn_method(nn);
+  }
+  void set_transform(const double *A, const double *t, const double *c) override { e->set_transform(trans_factory<DOF>::make(A, t, c)); }
+  void set_features(const lrr_est_features *mi, const lrr_est_features *) override {
+    std::vector<std::vector<typename F::sptr> > mm(1, make_features<F>(mi));
+    e->set_moving_data(mm);
+  }
+  void weight_by_strength(bool b) override { e->weight_by_strength(b); }
+  void normalize_matches() override { e->normalize_matches(); }
+  void set_number_points(int64_t n) override { e->set_number_points((unsigned)n); }
+  void inject_initial_scale(double f, double) override { e->inject_initial_scale(f); }
+  void set_subset_order(int, const int64_t *order, int64_t n) override { e->set_subset_order(std::vector<int64_t>(order, order + n)); }
+  void set_nn_method(int m) override { e->set_nn_method(m); }
+  void find_closest_euclidean() override { e->find_closest_euclidean(); }
+  bool one_iteration(unsigned it) override { return e->one_iteration(0, 0, it); }
+  bool run(unsigned max_it, unsigned *done) override {
+    // run() of the reference hard-codes 30 iterations (cdcl .txx:419)
+    bool conv = false;
+    unsigned it = 0;
+    e->initialize();
+    while (!conv && it < max_it) { conv = e->one_iteration(0, 0, it); ++it; }
+    if (done) *done = it;
+    return conv;
+  }
+  void estimate_LS(bool b) override { e->estimate_LS(b); }
+  void estimate_LS_backward(bool) override {}
+  void get_transform(int, double *A, double *t, double *c, double *covar) override { read_trans<DOF>(e->get_transform(), A, t, c, covar); }
+  double RMS_error() override { return e->RMS_error(); }
+  double weighted_error(int) override { return e->weighted_error(); }
+  double sheet_angles(int) override { return e->sheet_angles(); }
+  double tube_angles(int) override { return e->tube_angles(); }
+  void transfer_error_covariance(double *cf, double *) override {
+    e->compute_transfer_error_covariance();
+    if (cf) for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) cf[3 * r + k] = e->get_transform()->get_covarianceJ()(r, k);
+  }
+  bool oscillated() override { return false; }
+  bool finest_level() override { return false; }
+  int64_t num_matches(int) override { return lrr_icp_dir_num_matches(e->device_dir()); }
+  void get_matches(int, int64_t *f, int64_t *t, double *w) override { dir_matches(*e, f, t, w); }
+  int64_t number_points(int) override { return e->number_points(); }
+  double last_scale(int) override { return e->last_scale(); }
+  void normal_equations(double *AtA, double *Atb) override { e->last_normal_equations(AtA, Atb); }
+};
+
+template <unsigned DOF, class F, class Est>
+struct sym_impl : est_base {
+  vbl_smart_ptr<Est> e;
+  sym_impl(const lrr_est_features *m, const lrr_est_features *f, const lrr_est_features *mi, const lrr_est_features *fi,
+           const double *A, const double *t, const double *c, uint64_t seed, int nn) {
+    this->dof = DOF;
+    typename cdcl_trans<3, DOF>::sptr T = trans_factory<DOF>::make(A, t, c);
+    e = new Est(make_features<F>(m), make_features<F>(f), T, T->inverse(), make_features<F>(mi), make_features<F>(fi));
+    e->set_subset_seed(seed);
+    e->set_nn_method(nn);
+  }
+  typename Est::estimation_type &d(int dir) { return dir ? e->backward() : e->forward(); }
+  void set_transform(const double *A, const double *t, const double *c) override { e->set_transform(trans_factory<DOF>::make(A, t, c)); }
+  void set_features(const lrr_est_features *mi, const lrr_est_features *fi) override { e->set_features(make_features<F>(mi), make_features<F>(fi)); }
+  void weight_by_strength(bool b) override { e->weight_by_strength(b); }
+  void normalize_matches() override { e->normalize_matches(); }
+  void set_number_points(int64_t n) override { e->set_number_points((unsigned)n); }
+  void inject_initial_scale(double f, double b) override { e->inject_initial_scale(f, b); }
+  void set_subset_order(int dir, const int64_t *order, int64_t n) override { d(dir).set_subset_order(std::vector<int64_t>(order, order + n)); }
+  void set_nn_method(int m) override { e->set_nn_method(m); }
+  void find_closest_euclidean() override { e->find_closest_euclidean(); }
+  bool one_iteration(unsigned it) override { return e->one_iteration(0, 0, it); }
+  bool run(unsigned max_it, unsigned *done) override {
+    // the caller's loop (rrl/itkLocationRegistration.cxx:2418): the class's own run() is a stub
+    bool conv = false;
+    unsigned it = 0;
+    while (!conv && it < max_it) { conv = e->one_iteration(0, 0, it); ++it; }
+    if (done) *done = it;
+    return conv;
+  }
+  void estimate_LS(bool b) override { e->estimate_LS(b); }
+  void estimate_LS_backward(bool b) override { e->estimate_LS_backward(b); }
+  void get_transform(int dir, double *A, double *t, double *c, double *covar) override {
+    read_trans<DOF>(dir ? e->get_transform_backward() : e->get_transform(), A, t, c, covar);
+  }
+  double RMS_error() override { return e->RMS_error(); }
+  double weighted_error(int dir) override { return dir ? e->weighted_error_backward() : e->weighted_error(); }
+  double sheet_angles(int dir) override { return dir ? e->sheet_angles_backward() : e->sheet_angles(); }
+  double tube_angles(int dir) override { return dir ? e->tube_angles_backward() : e->tube_angles(); }
+  void transfer_error_covariance(double *cf, double *cb) override {
+    e->compute_transfer_error_covariance();
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) {
+      if (cf) cf[3 * r + k] = e->get_transform()->get_covarianceJ()(r, k);
+      if (cb) cb[3 * r + k] = e->get_transform_backward()->get_covarianceJ()(r, k);
+    }
+  }
+  bool oscillated() override { return e->oscillated(); }
+  bool finest_level() override { return e->finest_level(); }
+  int64_t num_matches(int dir) override { return lrr_icp_dir_num_matches(d(dir).device_dir()); }
+  void get_matches(int dir, int64_t *f, int64_t *t, double *w) override { dir_matches(d(dir), f, t, w); }
+  int64_t number_points(int dir) override { return d(dir).number_points(); }
+  double last_scale(int dir) override { return d(dir).last_scale(); }
+  void normal_equations(double *AtA, double *Atb) override { e->forward().last_normal_equations(AtA, Atb); }
+};
+
+template <class Fn>
+int guard(Fn fn) {
+  try {
+    fn();
+    return 0;
+  } catch (const std::exception &ex) {
+    g_error = ex.what();
+    return -1;
+  } catch (...) {
+    g_error = "unknown exception";
+    return -1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+typedef struct lrr_est lrr_est;
+
+const char *lrr_est_last_error() { return g_error.c_str(); }
+
+int lrr_est_set_device(int device) {
+  return guard([&] { lrr_amd::device::set_device(device); (void)lrr_amd::device::ctx(); });
+}
+
+// context of the calling thread (for the timing helpers of lrr_icp.h)
+lrr_icp_ctx *lrr_est_context() {
+  lrr_icp_ctx *c = nullptr;
+  guard([&] { c = lrr_amd::device::ctx(); });
+  return c;
+}
+
+// kind: 0 cdcl forward, 1 rrl forward, 2 cdcl symmetric, 3 rrl symmetric; dof 6 or 12
+lrr_est *lrr_est_create(int kind, int dof, const lrr_est_features *moving, const lrr_est_features *fixed,
+                        const lrr_est_features *moving_inside, const lrr_est_features *fixed_inside, const double *A,
+                        const double *t, const double *c, uint64_t seed, int nn_method) {
+  est_base *out = nullptr;
+  typedef cdcl_feature_with_shape<3> FS;
+  typedef cdcl_feature_ICP<3> FI;
+  int rc = guard([&] {
+    if (!moving || !fixed || !A || !t || !c) throw std::runtime_error("lrr_est_create: null argument");
+    if (kind >= 2 && (!moving_inside || !fixed_inside)) throw std::runtime_error("lrr_est_create: symmetric kinds need the inside sets");
+    if (dof == 6) {
+      if (kind == 0) out = new fwd_impl<6, FS, cdcl_estimation_ICP_matching_all<3, 6> >(moving, fixed, A, t, c, seed, nn_method);
+      else if (kind == 1) out = new fwd_impl<6, FI, rrl_estimation_ICP_matching_all<3, 6> >(moving, fixed, A, t, c, seed, nn_method);
+      else if (kind == 2) out = new sym_impl<6, FS, cdcl_estimation_symmetric_ICP_matching_all<3, 6> >(moving, fixed, moving_inside, fixed_inside, A, t, c, seed, nn_method);
+      else if (kind == 3) out = new sym_impl<6, FI, rrl_estimation_symmetric_ICP_matching_all<3, 6> >(moving, fixed, moving_inside, fixed_inside, A, t, c, seed, nn_method);
+    } else if (dof == 12) {
+      if (kind == 0) out = new fwd_impl<12, FS, cdcl_estimation_ICP_matching_all<3, 12> >(moving, fixed, A, t, c, seed, nn_method);
+      else if (kind == 1) out = new fwd_impl<12, FI, rrl_estimation_ICP_matching_all<3, 12> >(moving, fixed, A, t, c, seed, nn_method);
+      else if (kind == 2) out = new sym_impl<12, FS, cdcl_estimation_symmetric_ICP_matching_all<3, 12> >(moving, fixed, moving_inside, fixed_inside, A, t, c, seed, nn_method);
+      else if (kind == 3) out = new sym_impl<12, FI, rrl_estimation_symmetric_ICP_matching_all<3, 12> >(moving, fixed, moving_inside, fixed_inside, A, t, c, seed, nn_method);
+    }
+    if (!out) throw std::runtime_error("lrr_est_create: unsupported kind/dof");
+  });
+  if (rc) return nullptr;
+  return reinterpret_cast<lrr_est *>(out);
+}
+
+#define E(e) (reinterpret_cast<est_base *>(e))
+
+void lrr_est_destroy(lrr_est *e) { delete E(e); }
+int lrr_est_set_transform(lrr_est *e, const double *A, const double *t, const double *c) { return guard([&] { E(e)->set_transform(A, t, c); }); }
+int lrr_est_set_features(lrr_est *e, const lrr_est_features *mi, const lrr_est_features *fi) { return guard([&] { E(e)->set_features(mi, fi); }); }
+int lrr_est_weight_by_strength(lrr_est *e, int flag) { return guard([&] { E(e)->weight_by_strength(flag != 0); }); }
+int lrr_est_normalize_matches(lrr_est *e) { return guard([&] { E(e)->normalize_matches(); }); }
+int lrr_est_set_number_points(lrr_est *e, int64_t n) { return guard([&] { E(e)->set_number_points(n); }); }
+int lrr_est_inject_initial_scale(lrr_est *e, double f, double b) { return guard([&] { E(e)->inject_initial_scale(f, b); }); }
+int lrr_est_set_subset_order(lrr_est *e, int dir, const int64_t *order, int64_t n) { return guard([&] { E(e)->set_subset_order(dir, order, n); }); }
+int lrr_est_set_nn_method(lrr_est *e, int m) { return guard([&] { E(e)->set_nn_method(m); }); }
+int lrr_est_find_closest_euclidean(lrr_est *e) { return guard([&] { E(e)->find_closest_euclidean(); }); }
+int lrr_est_one_iteration(lrr_est *e, unsigned it, int *converged) { return guard([&] { bool c = E(e)->one_iteration(it); if (converged) *converged = c ? 1 : 0; }); }
+int lrr_est_run(lrr_est *e, unsigned max_it, unsigned *done, int *converged) { return guard([&] { bool c = E(e)->run(max_it, done); if (converged) *converged = c ? 1 : 0; }); }
+int lrr_est_estimate_LS(lrr_est *e, int p) { return guard([&] { E(e)->estimate_LS(p != 0); }); }
+int lrr_est_estimate_LS_backward(lrr_est *e, int p) { return guard([&] { E(e)->estimate_LS_backward(p != 0); }); }
+int lrr_est_get_transform(lrr_est *e, int dir, double *A, double *t, double *c, double *covar) { return guard([&] { E(e)->get_transform(dir, A, t, c, covar); }); }
+int lrr_est_RMS_error(lrr_est *e, double *out) { return guard([&] { *out = E(e)->RMS_error(); }); }
+int lrr_est_weighted_error(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->weighted_error(dir); }); }
+int lrr_est_sheet_angles(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->sheet_angles(dir); }); }
+int lrr_est_tube_angles(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->tube_angles(dir); }); }
+int lrr_est_compute_transfer_error_covariance(lrr_est *e, double *cf, double *cb) { return guard([&] { E(e)->transfer_error_covariance(cf, cb); }); }
+int lrr_est_oscillated(lrr_est *e) { return E(e)->oscillated() ? 1 : 0; }
+int lrr_est_finest_level(lrr_est *e) { return E(e)->finest_level() ? 1 : 0; }
+int64_t lrr_est_num_matches(lrr_est *e, int dir) { int64_t n = 0; guard([&] { n = E(e)->num_matches(dir); }); return n; }
+int lrr_est_get_matches(lrr_est *e, int dir, int64_t *f, int64_t *t, double *w) { return guard([&] { E(e)->get_matches(dir, f, t, w); }); }
+int64_t lrr_est_get_number_points(lrr_est *e, int dir) { int64_t n = 0; guard([&] { n = E(e)->number_points(dir); }); return n; }
+int lrr_est_last_scale(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->last_scale(dir); }); }
+int lrr_est_last_normal_equations(lrr_est *e, double *AtA, double *Atb) { return guard([&] { E(e)->normal_equations(AtA, Atb); }); }
+
+}  // extern "C"

@@ -1,0 +1,1534 @@
+// lrr_icp.hip — hand-written HIP kernels (gfx950 / CDNA4) + the C-ABI of include/lrr_icp.h.
+//
+// The per-iteration hot path of LRR's robust ICP:
+//   K1  map moving features + exact nearest fixed feature      (k_match_grid / k_match_brute)
+//   K2  projected residuals, robust scale, Beaton-Tukey weights (k_residual, k_select, k_assign)
+//   K5  normalisation statistics                                (k_from_sum, k_to_sum, ...)
+//   K3  weighted normal equations J^T P J, J^T P b              (k_accumulate)
+//   K4  error metrics                                           (k_errors)
+// Everything is fp64: the reference is double throughout (cdcl/cdcl_feature.h:21) and "match
+// sets exactly" is a parity requirement.  This is distance search + small reductions: no MFMA.
+// The file is compiled with -ffp-contract=off so that per-pair quantities are bit-identical to
+// the CPU restatement used as checker; the only fused operations are the explicit fma() calls
+// of dist2().  Reductions are two-stage with a fixed block->partial->final order, so results
+// are run-to-run deterministic (no floating-point atomics anywhere).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lrr_icp.h"
+
+// ---------------------------------------------------------------------------------------------
+// host-side objects
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kBlock = 256;          // 4 wavefronts of 64
+constexpr int kMaxBlocks = 1024;     // reduction grids: 4 blocks / CU on 256 CUs
+constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 for dof 12)
+constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
+constexpr int kRingMax = 6;          // grid search rings before the brute-force fallback
+constexpr int kSelThreads = 1024;
+constexpr int kMaxSelJobs = 32;
+constexpr int kProfEvents = 4096;
+
+struct SelJob {
+  const double *k0; int n0;
+  const double *k1; int n1;
+  long long k;     // 0-based rank
+  double *out;     // out[0] = k-th smallest, out[1] = sum of keys < it, out[2] = their count
+};
+
+}  // namespace
+
+struct lrr_icp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double *d_partials = nullptr;  // kMaxBlocks * kMaxRed
+  double *d_final = nullptr;     // kMaxRed + select outputs
+  double *h_pinned = nullptr;    // results staging
+  SelJob *d_jobs = nullptr;
+  SelJob *h_jobs = nullptr;
+  // brute-force partial argmin scratch
+  double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;
+  int *d_overflow = nullptr; size_t overflow_cap = 0; int *d_overflow_count = nullptr;
+  int *d_order = nullptr; size_t order_cap = 0;
+  // match-kernel profile (event pairs resolved lazily)
+  bool prof = false;
+  std::vector<hipEvent_t> pe;
+  int pe_used = 0;
+  double match_ms = 0.0;
+  int64_t match_launches = 0;
+};
+
+struct lrr_icp_cloud {
+  lrr_icp_ctx *ctx = nullptr;
+  int64_t n = 0;
+  int float_strength = 0;
+  double *rec = nullptr;                       // n x 10, original order (gather target)
+  double *gx = nullptr, *gy = nullptr, *gz = nullptr;  // sorted by grid cell
+  int *gidx = nullptr;                         // original index of sorted point
+  int *cell_start = nullptr;                   // ncell + 1
+  double lo[3] = {0, 0, 0}, h = 1.0, inv_h = 1.0, tol = 0.0;
+  int dim[3] = {1, 1, 1};
+};
+
+struct lrr_icp_dir {
+  lrr_icp_ctx *ctx = nullptr;
+  lrr_icp_cloud *from = nullptr, *to = nullptr;
+  int64_t cap = 0, n = 0;
+  int *m_from = nullptr, *m_to = nullptr;
+  double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
+  double *from_loc = nullptr;  // 3 per match: pre-mapped copies
+  int from_is_copy = 0;
+  unsigned *flag = nullptr; int64_t flag_cap = 0;
+};
+
+namespace {
+
+int fail(lrr_icp_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                    \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail((ctx), LRR_ICP_ERR_HIP,                                                    \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device helpers — canonical operation order shared with the CPU checker
+// ---------------------------------------------------------------------------------------------
+struct XfD { double A[9], t[3], c[3]; };
+struct NormD { double cm[3], rm, cf[3], rf; };
+struct Keys { unsigned k[4]; };
+
+struct GridView {
+  const double *gx, *gy, *gz;
+  const int *gidx, *cell_start;
+  double lox, loy, loz, h, inv_h, tol;
+  int dx, dy, dz, n;
+};
+
+__device__ __forceinline__ void map_loc(const XfD &T, double x0, double x1, double x2, double &y0,
+                                        double &y1, double &y2) {
+  // R (x - c) + t   (cdcl_trans_rigid3d.cxx:171-174, cdcl_trans_affine.txx:112-115)
+  double d0 = x0 - T.c[0], d1 = x1 - T.c[1], d2 = x2 - T.c[2];
+  y0 = ((T.A[0] * d0 + T.A[1] * d1) + T.A[2] * d2) + T.t[0];
+  y1 = ((T.A[3] * d0 + T.A[4] * d1) + T.A[5] * d2) + T.t[1];
+  y2 = ((T.A[6] * d0 + T.A[7] * d1) + T.A[8] * d2) + T.t[2];
+}
+
+__device__ __forceinline__ double dist2(double qx, double qy, double qz, double px, double py,
+                                        double pz) {
+  double dx = qx - px, dy = qy - py, dz = qz - pz;
+  return fma(dz, dz, fma(dy, dy, dx * dx));
+}
+
+// e^T P e clamped at 0 (cdcl .txx:214-220): v = e^T P, then v . e; P symmetric, 6 unique
+__device__ __forceinline__ double proj_residual2(double y0, double y1, double y2, double q0,
+                                                 double q1, double q2, double pxx, double pxy,
+                                                 double pxz, double pyy, double pyz, double pzz) {
+  double e0 = y0 - q0, e1 = y1 - q1, e2 = y2 - q2;
+  double v0 = (e0 * pxx + e1 * pxy) + e2 * pxz;
+  double v1 = (e0 * pxy + e1 * pyy) + e2 * pyz;
+  double v2 = (e0 * pxz + e1 * pyz) + e2 * pzz;
+  double r2 = (v0 * e0 + v1 * e1) + v2 * e2;
+  return r2 < 0.0 ? 0.0 : r2;
+}
+
+__device__ __forceinline__ unsigned fmix32(unsigned h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+// keyed permutation of [0, n): 4-round Feistel over 2^(2*half) >= n, cycle-walked
+__device__ __forceinline__ int subset_perm(int i, int n, int half, const Keys &keys) {
+  unsigned mask = (1u << half) - 1u;
+  unsigned long long x = (unsigned)i;
+  do {
+    unsigned L = (unsigned)(x >> half), R = (unsigned)(x & mask);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      unsigned F = fmix32(R ^ keys.k[r]) & mask;
+      unsigned nL = R;
+      R = L ^ F;
+      L = nL;
+    }
+    x = ((unsigned long long)L << half) | R;
+  } while (x >= (unsigned long long)n);
+  return (int)x;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Block-wide sum of K per-thread values; result for value k lands in partials[blockIdx.x*K + k].
+// Fixed order: lanes by shuffle tree, then the 4 waves in index order.
+template <int K>
+__device__ __forceinline__ void block_reduce_store(double (&v)[K], double *partials) {
+  __shared__ double red[kBlock / 64][K];
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double s = wave_sum(v[k]);
+    if (lane == 0) red[wv][k] = s;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += kBlock) {
+    double s = red[0][k];
+#pragma unroll
+    for (int w2 = 1; w2 < kBlock / 64; ++w2) s += red[w2][k];
+    partials[(size_t)blockIdx.x * K + k] = s;
+  }
+}
+
+__global__ void k_reduce_partials(const double *partials, int nblocks, int K, double *out) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * K + k];
+  out[k] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: exact nearest neighbour
+// ---------------------------------------------------------------------------------------------
+struct QuerySrc {
+  const double *rec;   // query records
+  int stride;          // doubles per record (10 for a cloud, 3 for raw points)
+  const int *order;    // explicit permutation or nullptr
+  int use_keys;        // keyed permutation when order == nullptr
+  int nsrc;            // size of the source set (domain of the permutation)
+  int half;
+  Keys keys;
+};
+
+__device__ __forceinline__ int query_index(const QuerySrc &q, int i) {
+  if (q.order) return q.order[i];
+  if (q.use_keys) return subset_perm(i, q.nsrc, q.half, q.keys);
+  return i;
+}
+
+__device__ __forceinline__ void scan_range(const GridView &g, int s, int e, double yx, double yy,
+                                           double yz, double &bd, int &bi) {
+  for (int j = s; j < e; ++j) {
+    double d = dist2(yx, yy, yz, g.gx[j], g.gy[j], g.gz[j]);
+    int oi = g.gidx[j];
+    if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+  }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// One thread per query: ring search over the uniform grid.  After ring r every unvisited point
+// lies beyond one of the interior faces of the (2r+1)^3 block, so the search stops as soon as
+// the best squared distance is strictly below (distance to the nearest such face - tol)^2.
+// Queries that are not settled after kRingMax rings go to the brute-force fallback list.
+__global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, XfD xf, int n,
+                                                       int *m_from, int *m_to, int *overflow,
+                                                       int *overflow_count) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int p = query_index(qs, i);
+  const double *pr = qs.rec + (size_t)p * qs.stride;
+  double yx, yy, yz;
+  map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
+  if (m_from) m_from[i] = p;
+  int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
+  int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
+  int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
+  double bd = INFINITY;
+  int bi = 0x7fffffff;
+  bool done = false;
+  for (int r = 0; r <= kRingMax && !done; ++r) {
+    int x0 = max(cx - r, 0), x1 = min(cx + r, g.dx - 1);
+    int y0 = max(cy - r, 0), y1 = min(cy + r, g.dy - 1);
+    int z0 = max(cz - r, 0), z1 = min(cz + r, g.dz - 1);
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        int row = (z * g.dy + y) * g.dx;
+        bool shell = (z - cz == r) || (cz - z == r) || (y - cy == r) || (cy - y == r);
+        if (shell) {
+          scan_range(g, g.cell_start[row + x0], g.cell_start[row + x1 + 1], yx, yy, yz, bd, bi);
+        } else {
+          if (cx - r >= 0) scan_range(g, g.cell_start[row + cx - r], g.cell_start[row + cx - r + 1], yx, yy, yz, bd, bi);
+          if (cx + r <= g.dx - 1) scan_range(g, g.cell_start[row + cx + r], g.cell_start[row + cx + r + 1], yx, yy, yz, bd, bi);
+        }
+      }
+    double lb = INFINITY;
+    if (cx - r > 0) lb = fmin(lb, yx - (g.lox + (cx - r) * g.h));
+    if (cx + r < g.dx - 1) lb = fmin(lb, (g.lox + (cx + r + 1) * g.h) - yx);
+    if (cy - r > 0) lb = fmin(lb, yy - (g.loy + (cy - r) * g.h));
+    if (cy + r < g.dy - 1) lb = fmin(lb, (g.loy + (cy + r + 1) * g.h) - yy);
+    if (cz - r > 0) lb = fmin(lb, yz - (g.loz + (cz - r) * g.h));
+    if (cz + r < g.dz - 1) lb = fmin(lb, (g.loz + (cz + r + 1) * g.h) - yz);
+    if (lb == INFINITY) done = true;  // the block covers the whole grid
+    else {
+      lb -= g.tol;
+      if (lb > 0.0 && bd < lb * lb) done = true;
+    }
+  }
+  if (done) m_to[i] = (bi == 0x7fffffff) ? 0 : bi;  // only reachable with non-finite input
+  else {
+    m_to[i] = -1;
+    int slot = atomicAdd(overflow_count, 1);
+    overflow[slot] = i;
+  }
+}
+
+// brute-force fallback for the (rare) queries the ring search did not settle: one block each
+__global__ __launch_bounds__(kBlock) void k_match_overflow(GridView g, QuerySrc qs, XfD xf,
+                                                           const int *overflow,
+                                                           const int *overflow_count, int *m_to) {
+  __shared__ double sd[kBlock];
+  __shared__ int si[kBlock];
+  int cnt = *overflow_count;
+  for (int o = blockIdx.x; o < cnt; o += gridDim.x) {
+    int i = overflow[o];
+    int p = query_index(qs, i);
+    const double *pr = qs.rec + (size_t)p * qs.stride;
+    double yx, yy, yz;
+    map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
+    double bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < g.n; j += kBlock) {
+      double d = dist2(yx, yy, yz, g.gx[j], g.gy[j], g.gz[j]);
+      int oi = g.gidx[j];
+      if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+    }
+    sd[threadIdx.x] = bd; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        double d2 = sd[threadIdx.x + s]; int i2 = si[threadIdx.x + s];
+        if (d2 < sd[threadIdx.x] || (d2 == sd[threadIdx.x] && i2 < si[threadIdx.x])) { sd[threadIdx.x] = d2; si[threadIdx.x] = i2; }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) m_to[i] = (si[0] == 0x7fffffff) ? 0 : si[0];
+    __syncthreads();
+  }
+}
+
+// All-vs-all matcher: each block owns kBlock*Q queries (Q per thread, in registers) and streams
+// one chunk of the target cloud through LDS in tiles; every lane reads the same LDS address
+// (broadcast, conflict-free).  blockIdx.y splits the target cloud so that small query counts
+// still fill the chip; partial (d2, idx) pairs are merged lexicographically by k_brute_merge.
+constexpr int kBruteQ = 2;
+constexpr int kBruteTile = 1024;
+
+__global__ __launch_bounds__(kBlock) void k_match_brute(GridView g, QuerySrc qs, XfD xf, int n,
+                                                        int chunk, int *m_from, double *pd,
+                                                        int *pi) {
+  __shared__ double sx[kBruteTile], sy[kBruteTile], sz[kBruteTile];
+  __shared__ int sidx[kBruteTile];
+  double yx[kBruteQ], yy[kBruteQ], yz[kBruteQ], bd[kBruteQ];
+  int bi[kBruteQ], qi[kBruteQ];
+#pragma unroll
+  for (int q = 0; q < kBruteQ; ++q) {
+    int i = (blockIdx.x * kBruteQ + q) * kBlock + threadIdx.x;
+    qi[q] = i;
+    bd[q] = INFINITY; bi[q] = 0x7fffffff;
+    yx[q] = yy[q] = yz[q] = 0.0;
+    if (i < n) {
+      int p = query_index(qs, i);
+      const double *pr = qs.rec + (size_t)p * qs.stride;
+      map_loc(xf, pr[0], pr[1], pr[2], yx[q], yy[q], yz[q]);
+      if (m_from && blockIdx.y == 0) m_from[i] = p;
+    }
+  }
+  int begin = blockIdx.y * chunk, end = min(begin + chunk, g.n);
+  for (int base = begin; base < end; base += kBruteTile) {
+    int tn = min(kBruteTile, end - base);
+    __syncthreads();
+    for (int j = threadIdx.x; j < tn; j += kBlock) {
+      sx[j] = g.gx[base + j]; sy[j] = g.gy[base + j]; sz[j] = g.gz[base + j];
+      sidx[j] = g.gidx[base + j];
+    }
+    __syncthreads();
+    for (int j = 0; j < tn; ++j) {
+      double px = sx[j], py = sy[j], pz = sz[j];
+      int oi = sidx[j];
+#pragma unroll
+      for (int q = 0; q < kBruteQ; ++q) {
+        double d = dist2(yx[q], yy[q], yz[q], px, py, pz);
+        if (d < bd[q] || (d == bd[q] && oi < bi[q])) { bd[q] = d; bi[q] = oi; }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kBruteQ; ++q)
+    if (qi[q] < n) {
+      pd[(size_t)blockIdx.y * n + qi[q]] = bd[q];
+      pi[(size_t)blockIdx.y * n + qi[q]] = bi[q];
+    }
+}
+
+__global__ void k_brute_merge(const double *pd, const int *pi, int n, int S, int *m_to) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double bd = pd[i];
+  int bi = pi[i];
+  for (int s = 1; s < S; ++s) {
+    double d = pd[(size_t)s * n + i];
+    int oi = pi[(size_t)s * n + i];
+    if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+  }
+  m_to[i] = (bi == 0x7fffffff) ? 0 : bi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-match passes
+// ---------------------------------------------------------------------------------------------
+struct PairSrc {
+  const double *from_rec, *to_rec;
+  const int *m_from, *m_to;
+  const double *from_loc;  // pre-mapped copies or nullptr
+};
+
+__device__ __forceinline__ void load_from(const PairSrc &ps, int i, double &p0, double &p1, double &p2) {
+  if (ps.from_loc) {
+    p0 = ps.from_loc[3 * (size_t)i]; p1 = ps.from_loc[3 * (size_t)i + 1]; p2 = ps.from_loc[3 * (size_t)i + 2];
+  } else {
+    const double *r = ps.from_rec + (size_t)ps.m_from[i] * kRecStride;
+    p0 = r[0]; p1 = r[1]; p2 = r[2];
+  }
+}
+
+// rigid pre-map (cdcl .txx:467-482)
+__global__ void k_premap(PairSrc ps, XfD G, int n, double *out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double p0, p1, p2, y0, y1, y2;
+  load_from(ps, i, p0, p1, p2);
+  map_loc(G, p0, p1, p2, y0, y1, y2);
+  out[3 * (size_t)i] = y0; out[3 * (size_t)i + 1] = y1; out[3 * (size_t)i + 2] = y2;
+}
+
+__device__ __forceinline__ double pair_residual2(const PairSrc &ps, int i, const XfD &xf, const NormD &nm) {
+  double p0, p1, p2;
+  load_from(ps, i, p0, p1, p2);
+  p0 = (p0 - nm.cm[0]) / nm.rm; p1 = (p1 - nm.cm[1]) / nm.rm; p2 = (p2 - nm.cm[2]) / nm.rm;
+  const double *q = ps.to_rec + (size_t)ps.m_to[i] * kRecStride;
+  double q0 = (q[0] - nm.cf[0]) / nm.rf, q1 = (q[1] - nm.cf[1]) / nm.rf, q2 = (q[2] - nm.cf[2]) / nm.rf;
+  double y0, y1, y2;
+  map_loc(xf, p0, p1, p2, y0, y1, y2);
+  return proj_residual2(y0, y1, y2, q0, q1, q2, q[3], q[4], q[5], q[6], q[7], q[8]);
+}
+
+// K2 pass 1 (cdcl .txx:677-708; rrl .txx:594-617)
+__global__ __launch_bounds__(kBlock) void k_residual(PairSrc ps, XfD xf, NormD nm, int n,
+                                                     const double *w_prev, double *r2_out,
+                                                     double *dist_out, double *partials) {
+  double acc[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    double r2 = pair_residual2(ps, i, xf, nm);
+    double wp = w_prev[i];
+    acc[0] += wp * r2;
+    acc[1] += wp;
+    r2_out[i] = r2;
+    dist_out[i] = sqrt(r2);
+  }
+  block_reduce_store<2>(acc, partials);
+}
+
+// K2 pass 2 (cdcl .txx:744-765, weight_BT cdcl_utils.h:142-152)
+__global__ void k_assign(const double *r2, double scale, int n, double *w) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double scale2 = scale * scale;
+  double u = r2[i] / scale2;
+  double bt = 0.0;
+  if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
+  w[i] = bt / scale2;
+}
+
+// K4 (cdcl .txx:196-268)
+__global__ __launch_bounds__(kBlock) void k_errors(PairSrc ps, XfD xf, NormD nm, int n,
+                                                   const double *w, double *partials) {
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    double r2 = pair_residual2(ps, i, xf, nm);
+    double wi = w[i];
+    acc[0] += r2;
+    acc[1] += sqrt(r2) * wi;
+    acc[2] += wi;
+  }
+  block_reduce_store<3>(acc, partials);
+}
+
+// K5 statistics (cdcl .txx:1175-1213)
+__global__ __launch_bounds__(kBlock) void k_from_sum(PairSrc ps, int n, double *partials) {
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    double p0, p1, p2;
+    load_from(ps, i, p0, p1, p2);
+    acc[0] += p0; acc[1] += p1; acc[2] += p2;
+  }
+  block_reduce_store<3>(acc, partials);
+}
+
+__global__ void k_mark(const int *m_to, int n, unsigned *flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[m_to[i]] = 1u;  // benign race: every writer stores 1
+}
+
+__global__ __launch_bounds__(kBlock) void k_to_sum(const double *to_rec, const unsigned *flag, int nt,
+                                                   double *partials) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
+    if (flag[j]) {
+      const double *q = to_rec + (size_t)j * kRecStride;
+      acc[0] += q[0]; acc[1] += q[1]; acc[2] += q[2]; acc[3] += 1.0;
+    }
+  }
+  block_reduce_store<4>(acc, partials);
+}
+
+__global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, int n, const double *to_rec,
+                                                  const unsigned *flag, int nt, double cm0, double cm1,
+                                                  double cm2, double cf0, double cf1, double cf2,
+                                                  double *partials) {
+  double acc[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    double p0, p1, p2;
+    load_from(ps, i, p0, p1, p2);
+    p0 -= cm0; p1 -= cm1; p2 -= cm2;
+    acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
+  }
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
+    if (flag[j]) {
+      const double *q = to_rec + (size_t)j * kRecStride;
+      double q0 = q[0] - cf0, q1 = q[1] - cf1, q2 = q[2] - cf2;
+      acc[1] += sqrt((q0 * q0 + q1 * q1) + q2 * q2);
+    }
+  }
+  block_reduce_store<2>(acc, partials);
+}
+
+// weight_by_strength, first loop (cdcl .txx:832-851; rrl .txx:728-743).  reversed: the list is a
+// role-reversed clone list (the product is symmetric, only the weight buffer differs).
+__global__ __launch_bounds__(kBlock) void k_strength(PairSrc ps, int n, int float_product, double *w,
+                                                     double *key, double *partials) {
+  double acc[1] = {0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    double wi = w[i];
+    double k = INFINITY;
+    if (wi != 0) {
+      double sp = ps.from_rec[(size_t)ps.m_from[i] * kRecStride + 9];
+      double sq = ps.to_rec[(size_t)ps.m_to[i] * kRecStride + 9];
+      double g = float_product ? (double)((float)sp * (float)sq) : sp * sq;
+      if (g > 90000.0) g = 90000.0;
+      w[i] = wi * g;
+      k = g;
+      acc[0] += 1.0;
+    }
+    key[i] = k;
+  }
+  block_reduce_store<1>(acc, partials);
+}
+
+// weight_spatially, first loop (cdcl .txx:977-990; rrl .txx:760-770).  use_from: the to_ of a
+// role-reversed clone is this direction's from_.
+__global__ void k_spatial(PairSrc ps, NormD nm, int n, int use_from, double *w, double *key) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double q0, q1, q2;
+  if (use_from) {
+    load_from(ps, i, q0, q1, q2);
+    q0 = (q0 - nm.cm[0]) / nm.rm; q1 = (q1 - nm.cm[1]) / nm.rm; q2 = (q2 - nm.cm[2]) / nm.rm;
+  } else {
+    const double *q = ps.to_rec + (size_t)ps.m_to[i] * kRecStride;
+    q0 = (q[0] - nm.cf[0]) / nm.rf; q1 = (q[1] - nm.cf[1]) / nm.rf; q2 = (q[2] - nm.cf[2]) / nm.rf;
+  }
+  double d = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
+  double sw = 1.0 / (1.0 + 5.0 * d * d);
+  w[i] *= sw;
+  key[i] = sw;
+}
+
+__global__ void k_scale_w(double *w, int n, double f) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) w[i] *= f;
+}
+
+// K3 — normal equations.  Upper triangle + rhs per thread in registers, grid-stride over the
+// matches, fixed-order block reduction.  Per-pair products follow the reference's operation
+// order (generic: (J^T P) J w, cdcl .txx:1061-1062; PREMUL: (J^T (P w)) J, rrl sym .txx:468-536)
+// so that only the ORDER of the sum differs from the CPU path.
+template <int DOF> struct Tri { static constexpr int N = DOF * (DOF + 1) / 2; };
+
+template <int DOF, bool PREMUL>
+__global__ __launch_bounds__(kBlock) void k_accumulate(PairSrc ps, NormD nm, int n, const double *w,
+                                                       double c0, double c1, double c2,
+                                                       int rigid_increment, int reversed,
+                                                       double *partials) {
+  constexpr int NT = Tri<DOF>::N;
+  double acc[NT + DOF];
+#pragma unroll
+  for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    double wi = w[i];
+    if (PREMUL && wi < 1e-4) continue;
+    double p0, p1, p2;
+    load_from(ps, i, p0, p1, p2);
+    p0 = (p0 - nm.cm[0]) / nm.rm; p1 = (p1 - nm.cm[1]) / nm.rm; p2 = (p2 - nm.cm[2]) / nm.rm;
+    const double *qr = ps.to_rec + (size_t)ps.m_to[i] * kRecStride;
+    double q0 = (qr[0] - nm.cf[0]) / nm.rf, q1 = (qr[1] - nm.cf[1]) / nm.rf, q2 = (qr[2] - nm.cf[2]) / nm.rf;
+    double P[6];
+    double jx, jy, jz, b0, b1, b2;
+    if (!reversed) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) P[k] = qr[3 + k];
+      jx = p0; jy = p1; jz = p2;
+      b0 = q0; b1 = q1; b2 = q2;
+    } else {
+      const double *pr = ps.from_rec + (size_t)ps.m_from[i] * kRecStride;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) P[k] = pr[3 + k];
+      jx = q0; jy = q1; jz = q2;
+      b0 = p0; b1 = p1; b2 = p2;
+    }
+    if (rigid_increment) { b0 = b0 - jx; b1 = b1 - jy; b2 = b2 - jz; }
+    if (PREMUL) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) P[k] = P[k] * wi;
+    }
+    // symmetric projector as a full 3x3
+    const double Pm[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
+    double l0 = jx - c0, l1 = jy - c1, l2 = jz - c2;
+    if (DOF == 12) {
+      // affine Jacobian: J[d][3d+k] = l_k, J[d][9+d] = 1 (cdcl_trans_affine.txx:141-161);
+      // one non-zero per column, so (J^T P)[a][c] = lt[k_a] * P[d_a][c] exactly
+      const double lt[4] = {l0, l1, l2, 1.0};
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 12; ++a) {
+        const int da = a < 9 ? a / 3 : a - 9, ka = a < 9 ? a % 3 : 3;
+        double Ma0 = lt[ka] * Pm[da][0], Ma1 = lt[ka] * Pm[da][1], Ma2 = lt[ka] * Pm[da][2];
+        const double Ma[3] = {Ma0, Ma1, Ma2};
+#pragma unroll
+        for (int b = a; b < 12; ++b) {
+          const int db = b < 9 ? b / 3 : b - 9, kb = b < 9 ? b % 3 : 3;
+          double v = Ma[db] * lt[kb];
+          acc[t++] += PREMUL ? v : v * wi;
+        }
+        double r = (Ma0 * b0 + Ma1 * b1) + Ma2 * b2;
+        acc[NT + a] += PREMUL ? r : r * wi;
+      }
+    } else {
+      // rigid small-angle Jacobian [-[l]x , I] (cdcl_trans_rigid3d.cxx:197-225)
+      const double J[3][6] = {{0.0, l2, -l1, 1.0, 0.0, 0.0}, {-l2, 0.0, l0, 0.0, 1.0, 0.0}, {l1, -l0, 0.0, 0.0, 0.0, 1.0}};
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double Ma[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Ma[c] = (J[0][a] * Pm[0][c] + J[1][a] * Pm[1][c]) + J[2][a] * Pm[2][c];
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+          double v = (Ma[0] * J[0][b] + Ma[1] * J[1][b]) + Ma[2] * J[2][b];
+          acc[t++] += PREMUL ? v : v * wi;
+        }
+        double r = (Ma[0] * b0 + Ma[1] * b1) + Ma[2] * b2;
+        acc[NT + a] += PREMUL ? r : r * wi;
+      }
+    }
+  }
+  block_reduce_store<NT + DOF>(acc, partials);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact order statistics: one 1024-thread block per job, 6-pass MSB radix select on the
+// (non-negative) double bit patterns with an LDS histogram; optional sum/count of smaller keys
+// (needed by the trimmed MUSE scale).  Stands in for std::nth_element / std::sort.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long job_key(const SelJob &j, int i) {
+  double v = i < j.n0 ? j.k0[i] : j.k1[i - j.n0];
+  return (unsigned long long)__double_as_longlong(fabs(v));
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
+  __shared__ int hist[2048];
+  __shared__ int wave_tot[kSelThreads / 64];
+  __shared__ int sel_bin, sel_before;
+  __shared__ double red_s[kSelThreads / 64];
+  __shared__ double red_c[kSelThreads / 64];
+  SelJob job = jobs[blockIdx.x];
+  int n = job.n0 + job.n1;
+  if (n <= 0 || job.k < 0 || job.k >= n) {
+    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; }
+    return;
+  }
+  unsigned long long prefix = 0, mask = 0;
+  long long k = job.k;
+  const int shifts[6] = {53, 42, 31, 20, 9, 0};
+  const int widths[6] = {11, 11, 11, 11, 11, 9};
+  for (int pass = 0; pass < 6; ++pass) {
+    int shift = shifts[pass], bins = 1 << widths[pass];
+    for (int b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kSelThreads) {
+      unsigned long long key = job_key(job, i);
+      if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & (unsigned long long)(bins - 1))], 1);
+    }
+    __syncthreads();
+    // each thread owns 2 bins; block-wide exclusive scan of the pair sums
+    int h0 = hist[2 * threadIdx.x], h1 = hist[2 * threadIdx.x + 1];
+    int s = h0 + h1, incl = s;
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
+    int excl = before + incl - s;
+    if (s > 0 && k >= excl && k < excl + s) {
+      if (k < excl + h0) { sel_bin = 2 * threadIdx.x; sel_before = excl; }
+      else { sel_bin = 2 * threadIdx.x + 1; sel_before = excl + h0; }
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)sel_bin << shift;
+    mask |= (unsigned long long)(bins - 1) << shift;
+    k -= sel_before;
+    __syncthreads();
+  }
+  double value = __longlong_as_double((long long)prefix);
+  double sum = 0.0, cnt = 0.0;
+  for (int i = threadIdx.x; i < n; i += kSelThreads) {
+    unsigned long long key = job_key(job, i);
+    if (key < prefix) { sum += __longlong_as_double((long long)key); cnt += 1.0; }
+  }
+  sum = wave_sum(sum); cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) { red_s[threadIdx.x >> 6] = sum; red_c[threadIdx.x >> 6] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s2 = 0.0, c2 = 0.0;
+    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) { s2 += red_s[w2]; c2 += red_c[w2]; }
+    job.out[0] = value; job.out[1] = s2; job.out[2] = c2;
+  }
+}
+
+__global__ void k_copy_w(const double *src, double *dst, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+__global__ void k_fill(double *dst, int n, double v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
+__global__ void k_widen_idx(const int *src, int n, long long *dst) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------------
+inline int grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  return (int)std::min<int64_t>(b, kMaxBlocks);
+}
+inline int blocks_for(int64_t n) { return (int)std::max<int64_t>(1, (n + kBlock - 1) / kBlock); }
+
+XfD to_dev(const lrr_icp_xform *x) {
+  XfD d;
+  std::memcpy(d.A, x->A, sizeof d.A);
+  std::memcpy(d.t, x->t, sizeof d.t);
+  std::memcpy(d.c, x->c, sizeof d.c);
+  return d;
+}
+NormD to_dev(const lrr_icp_norm *m) {
+  NormD d;
+  if (m) {
+    std::memcpy(d.cm, m->cm, sizeof d.cm); d.rm = m->rm;
+    std::memcpy(d.cf, m->cf, sizeof d.cf); d.rf = m->rf;
+  } else {
+    d.cm[0] = d.cm[1] = d.cm[2] = 0.0; d.rm = 1.0;
+    d.cf[0] = d.cf[1] = d.cf[2] = 0.0; d.rf = 1.0;
+  }
+  return d;
+}
+XfD identity_xf() {
+  XfD d;
+  std::memset(&d, 0, sizeof d);
+  d.A[0] = d.A[4] = d.A[8] = 1.0;
+  return d;
+}
+
+GridView view_of(const lrr_icp_cloud *c) {
+  GridView g;
+  g.gx = c->gx; g.gy = c->gy; g.gz = c->gz; g.gidx = c->gidx; g.cell_start = c->cell_start;
+  g.lox = c->lo[0]; g.loy = c->lo[1]; g.loz = c->lo[2];
+  g.h = c->h; g.inv_h = c->inv_h; g.tol = c->tol;
+  g.dx = c->dim[0]; g.dy = c->dim[1]; g.dz = c->dim[2];
+  g.n = (int)c->n;
+  return g;
+}
+
+PairSrc pairs_of(const lrr_icp_dir *d) {
+  PairSrc ps;
+  ps.from_rec = d->from->rec; ps.to_rec = d->to->rec;
+  ps.m_from = d->m_from; ps.m_to = d->m_to;
+  ps.from_loc = d->from_is_copy ? d->from_loc : nullptr;
+  return ps;
+}
+
+// finish a block-partials reduction: final sum on device, copy K doubles to host, synchronise
+int finish_reduce(lrr_icp_ctx *ctx, int nblocks, int K, double *host_out) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_partials, nblocks, K, ctx->d_final);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_final, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(host_out, ctx->h_pinned, sizeof(double) * K);
+  return LRR_ICP_OK;
+}
+
+// run up to kMaxSelJobs selection jobs; results (3 doubles per job) land in host_out
+int run_select(lrr_icp_ctx *ctx, std::vector<SelJob> &jobs, double *host_out) {
+  int nj = (int)jobs.size();
+  if (nj == 0) return LRR_ICP_OK;
+  if (nj > kMaxSelJobs) return fail(ctx, LRR_ICP_ERR_ARG, "too many selection jobs");
+  double *d_out = ctx->d_final + kMaxRed;
+  for (int j = 0; j < nj; ++j) { jobs[j].out = d_out + 3 * j; ctx->h_jobs[j] = jobs[j]; }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, ctx->h_jobs, sizeof(SelJob) * nj, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_select, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, d_out, sizeof(double) * 3 * nj, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(host_out, ctx->h_pinned, sizeof(double) * 3 * nj);
+  return LRR_ICP_OK;
+}
+
+// rrel_util_median_abs_dev_scale, dof = 1 (cdcl .txx:520-536): k-th of m values, 0 if m <= 1
+inline long long mad_rank(long long m) { return (m - 1) / 2 + 1; }
+inline double mad_from_kth(long long m, double kth) { return 1.4826 * (1 + 5.0 / (double)(m - 1)) * kth; }
+
+int ensure_dir_capacity(lrr_icp_dir *d, int64_t n) {
+  lrr_icp_ctx *ctx = d->ctx;
+  if (n <= d->cap) return LRR_ICP_OK;
+  int64_t cap = std::max<int64_t>(n, 1024);
+  void *ptrs[] = {d->m_from, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  d->cap = 0;
+  HIPCHK(ctx, hipMalloc(&d->m_from, sizeof(int) * cap));
+  HIPCHK(ctx, hipMalloc(&d->m_to, sizeof(int) * cap));
+  HIPCHK(ctx, hipMalloc(&d->w, sizeof(double) * cap));
+  HIPCHK(ctx, hipMalloc(&d->wc, sizeof(double) * cap));
+  HIPCHK(ctx, hipMalloc(&d->r2, sizeof(double) * cap));
+  HIPCHK(ctx, hipMalloc(&d->key_g, sizeof(double) * cap));
+  HIPCHK(ctx, hipMalloc(&d->key_s, sizeof(double) * cap));
+  HIPCHK(ctx, hipMalloc(&d->from_loc, sizeof(double) * 3 * cap));
+  d->cap = cap;
+  return LRR_ICP_OK;
+}
+
+int perm_half(int64_t n) {
+  int half = 1;
+  while ((1LL << (2 * half)) < n) ++half;
+  return half;
+}
+
+unsigned host_fmix32(unsigned h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+// launch the exact NN search of n queries against `to`; results in m_to (and m_from when given)
+int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const QuerySrc &qs, const XfD &xf, int n,
+                 int method, int *m_from, int *m_to) {
+  if (n <= 0) return LRR_ICP_OK;
+  if (to->n <= 0) {
+    HIPCHK(ctx, hipMemsetAsync(m_to, 0xff, sizeof(int) * n, ctx->stream));
+    return LRR_ICP_OK;
+  }
+  GridView g = view_of(to);
+  bool prof = ctx->prof && ctx->pe_used + 2 <= (int)ctx->pe.size();
+  if (prof) HIPCHK(ctx, hipEventRecord(ctx->pe[ctx->pe_used], ctx->stream));
+  if (method == LRR_ICP_NN_BRUTE) {
+    int bx = (n + kBlock * kBruteQ - 1) / (kBlock * kBruteQ);
+    int S = std::max(1, std::min(64, 1024 / bx));
+    int max_chunks = (int)((to->n + kBruteTile - 1) / kBruteTile);
+    S = std::min(S, std::max(1, max_chunks));
+    int chunk = (int)((to->n + S - 1) / S);
+    chunk = ((chunk + kBruteTile - 1) / kBruteTile) * kBruteTile;
+    S = (int)((to->n + chunk - 1) / chunk);
+    size_t need = (size_t)S * (size_t)n;
+    if (need > ctx->brute_cap) {
+      if (ctx->d_bd) (void)hipFree(ctx->d_bd);
+      if (ctx->d_bi) (void)hipFree(ctx->d_bi);
+      ctx->brute_cap = 0;
+      HIPCHK(ctx, hipMalloc(&ctx->d_bd, sizeof(double) * need));
+      HIPCHK(ctx, hipMalloc(&ctx->d_bi, sizeof(int) * need));
+      ctx->brute_cap = need;
+    }
+    hipLaunchKernelGGL(k_match_brute, dim3(bx, S), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, chunk, m_from, ctx->d_bd, ctx->d_bi);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_bd, ctx->d_bi, n, S, m_to);
+    HIPCHK(ctx, hipGetLastError());
+  } else {
+    if ((size_t)n > ctx->overflow_cap) {
+      if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+      ctx->overflow_cap = 0;
+      HIPCHK(ctx, hipMalloc(&ctx->d_overflow, sizeof(int) * (size_t)n));
+      ctx->overflow_cap = (size_t)n;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow_count, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_match_grid, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, m_from, m_to, ctx->d_overflow, ctx->d_overflow_count);
+    HIPCHK(ctx, hipGetLastError());
+    // exits immediately when the overflow list is empty; every block reaches its loop bound
+    hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, ctx->stream, g, qs, xf, ctx->d_overflow, ctx->d_overflow_count, m_to);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  if (prof) {
+    HIPCHK(ctx, hipEventRecord(ctx->pe[ctx->pe_used + 1], ctx->stream));
+    ctx->pe_used += 2;
+  }
+  ctx->match_launches += 1;
+  return LRR_ICP_OK;
+}
+
+int resolve_profile(lrr_icp_ctx *ctx) {
+  if (ctx->pe_used == 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i + 1 < ctx->pe_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->pe[i], ctx->pe[i + 1]));
+    ctx->match_ms += ms;
+  }
+  ctx->pe_used = 0;
+  return LRR_ICP_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+int lrr_icp_create(int device, lrr_icp_ctx **out) {
+  if (!out) return LRR_ICP_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return LRR_ICP_ERR_HIP;
+  lrr_icp_ctx *ctx = new (std::nothrow) lrr_icp_ctx;
+  if (!ctx) return LRR_ICP_ERR_HIP;
+  ctx->device = device;
+  auto bail = [&](hipError_t e) { fprintf(stderr, "lrr_icp_create: %s\n", hipGetErrorString(e)); lrr_icp_destroy(ctx); return LRR_ICP_ERR_HIP; };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e);
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e);
+  if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_partials, sizeof(double) * kMaxBlocks * kMaxRed)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_final, sizeof(double) * (kMaxRed + 3 * kMaxSelJobs))) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 3 * kMaxSelJobs))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_overflow_count, sizeof(int))) != hipSuccess) return bail(e);
+  *out = ctx;
+  return LRR_ICP_OK;
+}
+
+void lrr_icp_destroy(lrr_icp_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (hipEvent_t ev : ctx->pe) (void)hipEventDestroy(ev);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+  if (ctx->d_final) (void)hipFree(ctx->d_final);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->d_jobs) (void)hipFree(ctx->d_jobs);
+  if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
+  if (ctx->d_bd) (void)hipFree(ctx->d_bd);
+  if (ctx->d_bi) (void)hipFree(ctx->d_bi);
+  if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+  if (ctx->d_overflow_count) (void)hipFree(ctx->d_overflow_count);
+  if (ctx->d_order) (void)hipFree(ctx->d_order);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *lrr_icp_last_error(const lrr_icp_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int lrr_icp_synchronize(lrr_icp_ctx *ctx) {
+  if (!ctx) return LRR_ICP_ERR_ARG;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_timer_start(lrr_icp_ctx *ctx) {
+  if (!ctx) return LRR_ICP_ERR_ARG;
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_timer_stop(lrr_icp_ctx *ctx, double *elapsed_ms) {
+  if (!ctx || !elapsed_ms) return LRR_ICP_ERR_ARG;
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *elapsed_ms = ms;
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_t *launches, int reset) {
+  if (!ctx) return LRR_ICP_ERR_ARG;
+  int rc = resolve_profile(ctx);
+  if (rc) return rc;
+  if (total_ms) *total_ms = ctx->match_ms;
+  if (launches) *launches = ctx->match_launches;
+  if (reset) { ctx->match_ms = 0.0; ctx->match_launches = 0; }
+  if (enable && ctx->pe.empty()) {
+    ctx->pe.resize(kProfEvents);
+    for (auto &ev : ctx->pe) HIPCHK(ctx, hipEventCreate(&ev));
+  }
+  ctx->prof = enable != 0;
+  return LRR_ICP_OK;
+}
+
+// ---- clouds ----------------------------------------------------------------------------------
+int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const double *proj,
+                         const double *strength, int float_strength, lrr_icp_cloud **out) {
+  if (!ctx || !out || n < 0 || n > 0x3fffffff || (n > 0 && (!loc || !proj))) return fail(ctx, LRR_ICP_ERR_ARG, "cloud_create: bad argument");
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // records; the error projector must be symmetric (nn^T, I - tt^T, I: features/itkFeatureImageFilter.txx:1053-1072)
+  std::vector<double> rec((size_t)std::max<int64_t>(n, 1) * kRecStride);
+  for (int64_t i = 0; i < n; ++i) {
+    const double *P = proj + 9 * i;
+    if (P[1] != P[3] || P[2] != P[6] || P[5] != P[7]) return fail(ctx, LRR_ICP_ERR_ARG, "cloud_create: error_projector_ must be symmetric");
+    double *r = &rec[(size_t)i * kRecStride];
+    r[0] = loc[3 * i]; r[1] = loc[3 * i + 1]; r[2] = loc[3 * i + 2];
+    r[3] = P[0]; r[4] = P[1]; r[5] = P[2]; r[6] = P[4]; r[7] = P[5]; r[8] = P[8];
+    double s = strength ? strength[i] : 0.0;
+    r[9] = float_strength ? (double)(float)s : s;
+  }
+  lrr_icp_cloud *c = new (std::nothrow) lrr_icp_cloud;
+  if (!c) return fail(ctx, LRR_ICP_ERR_HIP, "out of host memory");
+  c->ctx = ctx; c->n = n; c->float_strength = float_strength;
+  // uniform grid, ~2 points per cell; counting sort by cell id
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int64_t i = 0; i < n; ++i)
+    for (int d = 0; d < 3; ++d) {
+      double v = loc[3 * i + d];
+      if (!std::isfinite(v)) { delete c; return fail(ctx, LRR_ICP_ERR_ARG, "cloud_create: non-finite location"); }
+      if (i == 0 || v < lo[d]) lo[d] = v;
+      if (i == 0 || v > hi[d]) hi[d] = v;
+    }
+  double ext[3], maxext = 0.0, maxabs = 0.0;
+  for (int d = 0; d < 3; ++d) {
+    ext[d] = hi[d] - lo[d];
+    maxext = std::max(maxext, ext[d]);
+    maxabs = std::max(maxabs, std::max(std::fabs(lo[d]), std::fabs(hi[d])));
+  }
+  double h = 1.0;
+  if (n > 0 && maxext > 0.0) {
+    double vol = 1.0;
+    for (int d = 0; d < 3; ++d) vol *= std::max(ext[d], maxext * 1e-3);
+    h = std::cbrt(vol / std::max<double>(1.0, (double)n / 2.0));
+    h = std::max(h, maxext / 512.0);
+  }
+  int dim[3];
+  for (int d = 0; d < 3; ++d) dim[d] = (int)std::min<double>(512.0, std::floor(ext[d] / h) + 1.0);
+  int64_t ncell = (int64_t)dim[0] * dim[1] * dim[2];
+  c->h = h; c->inv_h = 1.0 / h;
+  for (int d = 0; d < 3; ++d) { c->lo[d] = lo[d]; c->dim[d] = dim[d]; }
+  c->tol = 1e-9 * (maxabs + maxext + h);
+  std::vector<int> cell((size_t)std::max<int64_t>(n, 1)), start((size_t)ncell + 1, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    int cc[3];
+    for (int d = 0; d < 3; ++d) {
+      int v = (int)std::floor((loc[3 * i + d] - lo[d]) * c->inv_h);
+      cc[d] = v < 0 ? 0 : (v > dim[d] - 1 ? dim[d] - 1 : v);
+    }
+    int id = (cc[2] * dim[1] + cc[1]) * dim[0] + cc[0];
+    cell[(size_t)i] = id;
+    start[(size_t)id + 1]++;
+  }
+  for (int64_t k = 0; k < ncell; ++k) start[(size_t)k + 1] += start[(size_t)k];
+  std::vector<int> cursor(start.begin(), start.end() - 1), gidx((size_t)std::max<int64_t>(n, 1));
+  std::vector<double> gx((size_t)std::max<int64_t>(n, 1)), gy(gx.size()), gz(gx.size());
+  for (int64_t i = 0; i < n; ++i) {  // ascending i: original order kept inside a cell
+    int pos = cursor[(size_t)cell[(size_t)i]]++;
+    gidx[(size_t)pos] = (int)i;
+    gx[(size_t)pos] = loc[3 * i]; gy[(size_t)pos] = loc[3 * i + 1]; gz[(size_t)pos] = loc[3 * i + 2];
+  }
+  auto cleanup = [&](int code, const std::string &msg) { lrr_icp_cloud_destroy(c); return fail(ctx, code, msg); };
+  size_t m = (size_t)std::max<int64_t>(n, 1);
+  if (hipMalloc(&c->rec, sizeof(double) * m * kRecStride) != hipSuccess ||
+      hipMalloc(&c->gx, sizeof(double) * m) != hipSuccess || hipMalloc(&c->gy, sizeof(double) * m) != hipSuccess ||
+      hipMalloc(&c->gz, sizeof(double) * m) != hipSuccess || hipMalloc(&c->gidx, sizeof(int) * m) != hipSuccess ||
+      hipMalloc(&c->cell_start, sizeof(int) * ((size_t)ncell + 1)) != hipSuccess)
+    return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
+  if (hipMemcpy(c->rec, rec.data(), sizeof(double) * m * kRecStride, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->gx, gx.data(), sizeof(double) * m, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->gy, gy.data(), sizeof(double) * m, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->gz, gz.data(), sizeof(double) * m, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->gidx, gidx.data(), sizeof(int) * m, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), hipMemcpyHostToDevice) != hipSuccess)
+    return cleanup(LRR_ICP_ERR_HIP, "cloud_create: upload failed");
+  *out = c;
+  return LRR_ICP_OK;
+}
+
+void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
+  if (!c) return;
+  if (c->ctx) (void)hipSetDevice(c->ctx->device);
+  void *ptrs[] = {c->rec, c->gx, c->gy, c->gz, c->gidx, c->cell_start};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete c;
+}
+
+int64_t lrr_icp_cloud_size(const lrr_icp_cloud *c) { return c ? c->n : 0; }
+
+// ---- directions ------------------------------------------------------------------------------
+int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to, lrr_icp_dir **out) {
+  if (!ctx || !from || !to || !out) return fail(ctx, LRR_ICP_ERR_ARG, "dir_create: bad argument");
+  lrr_icp_dir *d = new (std::nothrow) lrr_icp_dir;
+  if (!d) return fail(ctx, LRR_ICP_ERR_HIP, "out of host memory");
+  d->ctx = ctx; d->from = from; d->to = to;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  d->flag_cap = std::max<int64_t>(to->n, 1);
+  if (hipMalloc(&d->flag, sizeof(unsigned) * d->flag_cap) != hipSuccess) { delete d; return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: hipMalloc failed"); }
+  *out = d;
+  return LRR_ICP_OK;
+}
+
+void lrr_icp_dir_destroy(lrr_icp_dir *d) {
+  if (!d) return;
+  if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
+  void *ptrs[] = {d->m_from, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->flag};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete d;
+}
+
+int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
+  if (!d || !from) return LRR_ICP_ERR_ARG;
+  d->from = from;
+  d->n = 0;
+  d->from_is_copy = 0;
+  return LRR_ICP_OK;
+}
+
+int64_t lrr_icp_dir_num_matches(const lrr_icp_dir *d) { return d ? d->n : 0; }
+
+void lrr_icp_perm_keys(uint64_t *state, uint32_t keys[4]) {
+  for (int r = 0; r < 4; ++r) {
+    uint64_t z = (*state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    keys[r] = (uint32_t)(z >> 32);
+  }
+}
+
+int64_t lrr_icp_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]) {
+  int half = perm_half(n);
+  uint32_t mask = (uint32_t)((1u << half) - 1u);
+  uint64_t x = (uint64_t)i;
+  do {
+    uint32_t L = (uint32_t)(x >> half), R = (uint32_t)(x & mask);
+    for (int r = 0; r < 4; ++r) {
+      uint32_t F = host_fmix32(R ^ keys[r]) & mask;
+      uint32_t nL = R;
+      R = L ^ F;
+      L = nL;
+    }
+    x = ((uint64_t)L << half) | R;
+  } while (x >= (uint64_t)n);
+  return (int64_t)x;
+}
+
+int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4], const int64_t *order,
+                  int64_t n_points, int method) {
+  if (!d || !xf || n_points < 0) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  if (n_points > d->from->n) return fail(ctx, LRR_ICP_ERR_ARG, "match: n_points exceeds the from-cloud");
+  if (!keys && !order && n_points > 0) return fail(ctx, LRR_ICP_ERR_ARG, "match: need keys or an explicit order");
+  if (n_points > 0 && d->to->n <= 0) return fail(ctx, LRR_ICP_ERR_ARG, "match: empty to-cloud");
+  for (int k = 0; k < 9; ++k) if (!std::isfinite(xf->A[k])) return fail(ctx, LRR_ICP_ERR_ARG, "match: non-finite transform");
+  for (int k = 0; k < 3; ++k) if (!std::isfinite(xf->t[k]) || !std::isfinite(xf->c[k])) return fail(ctx, LRR_ICP_ERR_ARG, "match: non-finite transform");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_dir_capacity(d, n_points);
+  if (rc) return rc;
+  d->from_is_copy = 0;
+  d->n = n_points;
+  if (n_points == 0) return LRR_ICP_OK;
+  QuerySrc qs;
+  qs.rec = d->from->rec; qs.stride = kRecStride; qs.order = nullptr; qs.use_keys = 0;
+  qs.nsrc = (int)d->from->n; qs.half = perm_half(d->from->n);
+  std::memset(&qs.keys, 0, sizeof qs.keys);
+  if (order) {
+    if ((size_t)n_points > ctx->order_cap) {
+      if (ctx->d_order) (void)hipFree(ctx->d_order);
+      ctx->order_cap = 0;
+      HIPCHK(ctx, hipMalloc(&ctx->d_order, sizeof(int) * (size_t)n_points));
+      ctx->order_cap = (size_t)n_points;
+    }
+    std::vector<int> o32((size_t)n_points);
+    for (int64_t i = 0; i < n_points; ++i) {
+      if (order[i] < 0 || order[i] >= d->from->n) return fail(ctx, LRR_ICP_ERR_ARG, "match: order index out of range");
+      o32[(size_t)i] = (int)order[i];
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_order, o32.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // o32 is pageable and dies at scope exit
+    qs.order = ctx->d_order;
+  } else {
+    qs.use_keys = 1;
+    for (int r = 0; r < 4; ++r) qs.keys.k[r] = keys[r];
+  }
+  if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
+  rc = launch_match(ctx, d->to, qs, to_dev(xf), (int)n_points, method, d->m_from, d->m_to);
+  if (rc) return rc;
+  // temporarily set weight to 1.0 (cdcl .txx:645)
+  hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_points)), dim3(kBlock), 0, ctx->stream, d->w, (int)n_points, 1.0);
+  HIPCHK(ctx, hipGetLastError());
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_premap(lrr_icp_dir *d, const lrr_icp_xform *G) {
+  if (!d || !G) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  if (d->n == 0) { d->from_is_copy = 1; return LRR_ICP_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairSrc ps = pairs_of(d);
+  // in place is safe: each thread reads its own 3 doubles before writing them
+  hipLaunchKernelGGL(k_premap, dim3(blocks_for(d->n)), dim3(kBlock), 0, ctx->stream, ps, to_dev(G), (int)d->n, d->from_loc);
+  HIPCHK(ctx, hipGetLastError());
+  d->from_is_copy = 1;
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_residual_pass(lrr_icp_dir *d, const lrr_icp_xform *xf, const lrr_icp_norm *norm, double *S, double *W) {
+  if (!d || !xf) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  if (S) *S = 0.0;
+  if (W) *W = 0.0;
+  if (d->n == 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int nb = grid_for(d->n);
+  hipLaunchKernelGGL(k_residual, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(d), to_dev(xf), to_dev(norm), (int)d->n, d->w, d->r2, d->key_s, ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  double out[2];
+  int rc = finish_reduce(ctx, nb, 2, out);
+  if (rc) return rc;
+  if (S) *S = out[0];
+  if (W) *W = out[1];
+  return LRR_ICP_OK;
+}
+
+// MUSE order-statistic tables (restated from the published VXL rrel_muse_table; not
+// reference-verified: VXL is absent)
+static double norm_inv_cdf(double p) {
+  static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+  static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01};
+  static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+  static const double dd[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+  double x;
+  if (p < 0.02425) {
+    double q = std::sqrt(-2 * std::log(p));
+    x = (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((dd[0] * q + dd[1]) * q + dd[2]) * q + dd[3]) * q + 1);
+  } else if (p <= 1 - 0.02425) {
+    double q = p - 0.5, r = q * q;
+    x = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q / (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1);
+  } else {
+    double q = std::sqrt(-2 * std::log(1 - p));
+    x = -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((dd[0] * q + dd[1]) * q + dd[2]) * q + dd[3]) * q + 1);
+  }
+  double e = 0.5 * std::erfc(-x / std::sqrt(2.0)) - p;
+  double u = e * std::sqrt(2.0 * M_PI) * std::exp(x * x / 2.0);
+  return x - u / (1.0 + x * u / 2.0);
+}
+
+int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
+  if (!d || !sigma) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  *sigma = 0.0;
+  int64_t n = d->n;
+  if (n <= 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // rrel_muset_obj(0,false): trimmed MUSE over inlier fractions 0.25..0.95 step 0.05
+  struct Cand { int64_t k; double ek, sd, div; };
+  std::vector<Cand> cands;
+  std::vector<SelJob> jobs;
+  for (double frac = 0.25; frac <= 0.95 + 0.00001; frac += 0.05) {
+    int64_t k = (int64_t)std::floor(frac * (double)n + 0.5);
+    if (k > n) k = n;
+    if (k <= 0) k = 1;
+    double pk = (double)k / (double)(n + 1), qk = 1.0 - pk;
+    double Qk = norm_inv_cdf((1.0 + pk) / 2.0);
+    double pQk = std::sqrt(2.0 / M_PI) * std::exp(-Qk * Qk / 2.0);
+    double Qp = 1.0 / pQk, Qpp = Qk / (pQk * pQk), Qppp = (1.0 + 2.0 * Qk * Qk) / (pQk * pQk * pQk);
+    double np2 = (double)n + 2.0;
+    double vrk = (pk * qk / np2) * Qp * Qp + (pk * qk / (np2 * np2)) * (2.0 * (qk - pk) * Qp * Qpp + pk * qk * (Qp * Qppp + Qpp * Qpp / 2.0));
+    double sd = std::sqrt(vrk);
+    if (Qk / sd < 3.0) continue;  // min_exp_kth_to_stddev_ratio
+    double div = (double)(n + 1) * std::sqrt(2.0 / M_PI) * (1.0 - std::exp(-Qk * Qk / 2.0));
+    cands.push_back({k, Qk, sd, div});
+    SelJob j; j.k0 = d->key_s; j.n0 = (int)n; j.k1 = nullptr; j.n1 = 0; j.k = k - 1; j.out = nullptr;
+    jobs.push_back(j);
+  }
+  std::vector<double> res(3 * jobs.size() + 3);
+  int rc = run_select(ctx, jobs, res.data());
+  if (rc) return rc;
+  bool at_start = true;
+  double best_sk = 0.0, best_obj = 0.0;
+  for (size_t c = 0; c < cands.size(); ++c) {
+    double vk = res[3 * c], sum_less = res[3 * c + 1], cnt_less = res[3 * c + 2];
+    // sum of the k smallest = sum of keys below the k-th value + copies of the k-th value
+    double sum_k = sum_less + ((double)cands[c].k - cnt_less) * vk;
+    double sk = sum_k / cands[c].div;
+    double obj = sk * cands[c].sd / cands[c].ek;
+    if (at_start || obj < best_obj) { at_start = false; best_sk = sk; best_obj = obj; }
+  }
+  *sigma = best_sk;
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_assign_weights(lrr_icp_dir *d, double sigma) {
+  if (!d) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  if (d->n == 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_assign, dim3(blocks_for(d->n)), dim3(kBlock), 0, ctx->stream, d->r2, sigma, (int)d->n, d->w);
+  HIPCHK(ctx, hipGetLastError());
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_normalize_stats(lrr_icp_dir *d, lrr_icp_norm *out) {
+  if (!d || !out) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int64_t n = d->n, nt = d->to->n;
+  PairSrc ps = pairs_of(d);
+  double r[4];
+  int nb = grid_for(n);
+  hipLaunchKernelGGL(k_from_sum, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, (int)n, ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  int rc = finish_reduce(ctx, nb, 3, r);
+  if (rc) return rc;
+  for (int k = 0; k < 3; ++k) out->cm[k] = r[k] / (double)n;
+  HIPCHK(ctx, hipMemsetAsync(d->flag, 0, sizeof(unsigned) * d->flag_cap, ctx->stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_mark, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, d->m_to, (int)n, d->flag);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  int nbt = grid_for(nt);
+  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kBlock), 0, ctx->stream, d->to->rec, d->flag, (int)nt, ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  rc = finish_reduce(ctx, nbt, 4, r);
+  if (rc) return rc;
+  double nd = r[3];
+  for (int k = 0; k < 3; ++k) out->cf[k] = r[k] / nd;
+  int nb2 = std::max(nb, nbt);
+  hipLaunchKernelGGL(k_radii, dim3(nb2), dim3(kBlock), 0, ctx->stream, ps, (int)n, d->to->rec, d->flag, (int)nt,
+                     out->cm[0], out->cm[1], out->cm[2], out->cf[0], out->cf[1], out->cf[2], ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  rc = finish_reduce(ctx, nb2, 2, r);
+  if (rc) return rc;
+  out->rm = r[0] / (double)n;
+  out->rf = r[1] / nd;
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_clone_weights(lrr_icp_dir *d) {
+  if (!d) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  if (d->n == 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_copy_w, dim3(blocks_for(d->n)), dim3(kBlock), 0, ctx->stream, d->w, d->wc, (int)d->n);
+  HIPCHK(ctx, hipGetLastError());
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_weight_by_strength(lrr_icp_dir *a, lrr_icp_dir *b, double *grad_scale) {
+  if (!a) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = a->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double cnt_a = 0.0, cnt_b = 0.0;
+  int rc;
+  if (a->n > 0) {
+    int nb = grid_for(a->n);
+    hipLaunchKernelGGL(k_strength, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(a), (int)a->n, a->from->float_strength, a->w, a->key_g, ctx->d_partials);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = finish_reduce(ctx, nb, 1, &cnt_a))) return rc;
+  }
+  if (b && b->n > 0) {
+    int nb = grid_for(b->n);
+    hipLaunchKernelGGL(k_strength, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(b), (int)b->n, b->from->float_strength, b->wc, b->key_g, ctx->d_partials);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = finish_reduce(ctx, nb, 1, &cnt_b))) return rc;
+  }
+  long long m = (long long)(cnt_a + cnt_b);
+  double gs = 0.0;
+  if (m > 1) {
+    // masked entries carry +inf keys and sort last, so rank k among the m finite keys is rank k overall
+    std::vector<SelJob> jobs(1);
+    jobs[0].k0 = a->key_g; jobs[0].n0 = (int)a->n;
+    jobs[0].k1 = b ? b->key_g : nullptr; jobs[0].n1 = b ? (int)b->n : 0;
+    jobs[0].k = mad_rank(m); jobs[0].out = nullptr;
+    double res[3];
+    if ((rc = run_select(ctx, jobs, res))) return rc;
+    gs = mad_from_kth(m, res[0]);
+  }
+  double f = 1.0 / gs;
+  if (a->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, a->w, (int)a->n, f); HIPCHK(ctx, hipGetLastError()); }
+  if (b && b->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(b->n)), dim3(kBlock), 0, ctx->stream, b->wc, (int)b->n, f); HIPCHK(ctx, hipGetLastError()); }
+  if (grad_scale) *grad_scale = gs;
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_weight_spatially(lrr_icp_dir *a, const lrr_icp_norm *norm_a, lrr_icp_dir *b, const lrr_icp_norm *norm_b, double *spatial_scale) {
+  if (!a) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = a->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (a->n > 0) {
+    hipLaunchKernelGGL(k_spatial, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, pairs_of(a), to_dev(norm_a), (int)a->n, 0, a->w, a->key_s);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  if (b && b->n > 0) {
+    hipLaunchKernelGGL(k_spatial, dim3(blocks_for(b->n)), dim3(kBlock), 0, ctx->stream, pairs_of(b), to_dev(norm_b), (int)b->n, 1, b->wc, b->key_s);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  long long m = (long long)a->n + (b ? (long long)b->n : 0);
+  double ss = 0.0;
+  int rc;
+  if (m > 1) {
+    std::vector<SelJob> jobs(1);
+    jobs[0].k0 = a->key_s; jobs[0].n0 = (int)a->n;
+    jobs[0].k1 = b ? b->key_s : nullptr; jobs[0].n1 = b ? (int)b->n : 0;
+    jobs[0].k = mad_rank(m); jobs[0].out = nullptr;
+    double res[3];
+    if ((rc = run_select(ctx, jobs, res))) return rc;
+    ss = mad_from_kth(m, res[0]);
+  }
+  double f = 1.0 / ss;
+  if (a->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, a->w, (int)a->n, f); HIPCHK(ctx, hipGetLastError()); }
+  if (b && b->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(b->n)), dim3(kBlock), 0, ctx->stream, b->wc, (int)b->n, f); HIPCHK(ctx, hipGetLastError()); }
+  if (spatial_scale) *spatial_scale = ss;
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_accumulate(lrr_icp_dir *d, int dof, const double jac_centre[3], const lrr_icp_norm *norm, int flags, double *AtA, double *Atb) {
+  if (!d || !AtA || !Atb || !jac_centre || (dof != 6 && dof != 12)) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::memset(AtA, 0, sizeof(double) * dof * dof);
+  std::memset(Atb, 0, sizeof(double) * dof);
+  if (d->n == 0) return LRR_ICP_OK;
+  int nt = dof * (dof + 1) / 2, K = nt + dof;
+  // 90 fp64 accumulators per thread at dof 12: fewer, longer blocks
+  int nb = (int)std::min<int64_t>(std::max<int64_t>(1, (d->n + kBlock - 1) / kBlock), 512);
+  PairSrc ps = pairs_of(d);
+  NormD nm = to_dev(norm);
+  const double *w = (flags & LRR_ICP_ACC_CLONE_W) ? d->wc : d->w;
+  int rigid = (flags & LRR_ICP_ACC_RIGID_INCREMENT) ? 1 : 0, rev = (flags & LRR_ICP_ACC_REVERSED) ? 1 : 0;
+  bool premul = (flags & LRR_ICP_ACC_PREMUL_SKIP) != 0;
+  if (dof == 12 && premul) hipLaunchKernelGGL((k_accumulate<12, true>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, (int)d->n, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
+  else if (dof == 12) hipLaunchKernelGGL((k_accumulate<12, false>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, (int)d->n, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
+  else if (premul) hipLaunchKernelGGL((k_accumulate<6, true>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, (int)d->n, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
+  else hipLaunchKernelGGL((k_accumulate<6, false>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, (int)d->n, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  double r[kMaxRed];
+  int rc = finish_reduce(ctx, nb, K, r);
+  if (rc) return rc;
+  int t = 0;
+  for (int a = 0; a < dof; ++a)
+    for (int b = a; b < dof; ++b) { AtA[a * dof + b] = r[t]; AtA[b * dof + a] = r[t]; ++t; }
+  for (int a = 0; a < dof; ++a) Atb[a] = r[nt + a];
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, double *sum_wr, double *sum_w) {
+  if (!d || !xf) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  double r[3] = {0.0, 0.0, 0.0};
+  if (d->n > 0) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int nb = grid_for(d->n);
+    hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(d), to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), (int)d->n, d->w, ctx->d_partials);
+    HIPCHK(ctx, hipGetLastError());
+    int rc = finish_reduce(ctx, nb, 3, r);
+    if (rc) return rc;
+  }
+  if (sum_r2) *sum_r2 = r[0];
+  if (sum_wr) *sum_wr = r[1];
+  if (sum_w) *sum_w = r[2];
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_get_matches(lrr_icp_dir *d, int64_t *from_idx, int64_t *to_idx, double *w) {
+  if (!d) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  int64_t n = d->n;
+  if (n == 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<int> tmp((size_t)n);
+  if (from_idx) {
+    HIPCHK(ctx, hipMemcpy(tmp.data(), d->m_from, sizeof(int) * n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) from_idx[i] = tmp[(size_t)i];
+  }
+  if (to_idx) {
+    HIPCHK(ctx, hipMemcpy(tmp.data(), d->m_to, sizeof(int) * n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) to_idx[i] = tmp[(size_t)i];
+  }
+  if (w) HIPCHK(ctx, hipMemcpy(w, d->w, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int method, int64_t *idx) {
+  if (!cloud || nq < 0 || (nq > 0 && (!query || !idx))) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = cloud->ctx;
+  if (nq == 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double *dq = nullptr;
+  int *dto = nullptr;
+  HIPCHK(ctx, hipMalloc(&dq, sizeof(double) * 3 * nq));
+  if (hipMalloc(&dto, sizeof(int) * nq) != hipSuccess) { (void)hipFree(dq); return fail(ctx, LRR_ICP_ERR_HIP, "nearest: hipMalloc failed"); }
+  int rc = LRR_ICP_OK;
+  if (hipMemcpy(dq, query, sizeof(double) * 3 * nq, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: upload failed");
+  if (!rc) {
+    QuerySrc qs;
+    qs.rec = dq; qs.stride = 3; qs.order = nullptr; qs.use_keys = 0; qs.nsrc = (int)nq; qs.half = 1;
+    std::memset(&qs.keys, 0, sizeof qs.keys);
+    if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
+    rc = launch_match(ctx, cloud, qs, identity_xf(), (int)nq, method, nullptr, dto);
+  }
+  std::vector<int> tmp((size_t)nq);
+  if (!rc && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(tmp.data(), dto, sizeof(int) * nq, hipMemcpyDeviceToHost) != hipSuccess))
+    rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: download failed");
+  if (!rc) for (int64_t i = 0; i < nq; ++i) idx[i] = tmp[(size_t)i];
+  (void)hipFree(dq); (void)hipFree(dto);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,354 @@
+"""ctypes view of the C++ drop-in estimator classes (include/lrr_amd/*.h) and of the C-ABI.
+
+Python is plumbing here (tests, bench, the multi-GPU driver): the product is the HIP library
+``liblrr_icp_hip.so`` (C-ABI: include/lrr_icp.h) and the C++ classes above it.  There is no CPU
+fallback: loading fails loudly when the libraries are missing, and creating an estimator fails
+loudly when no GPU is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(_HERE, "liblrr_icp_hip.so")
+EST_SO = os.path.join(_HERE, "liblrr_est.so")
+
+CDCL_FORWARD, RRL_FORWARD, CDCL_SYMMETRIC, RRL_SYMMETRIC = 0, 1, 2, 3
+NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+# every symbol include/lrr_icp.h declares
+ICP_SYMBOLS = [
+    "lrr_icp_create", "lrr_icp_destroy", "lrr_icp_last_error", "lrr_icp_synchronize",
+    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile",
+    "lrr_icp_cloud_create", "lrr_icp_cloud_destroy", "lrr_icp_cloud_size",
+    "lrr_icp_dir_create", "lrr_icp_dir_destroy", "lrr_icp_dir_set_from", "lrr_icp_dir_num_matches",
+    "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_premap",
+    "lrr_icp_residual_pass", "lrr_icp_muse_scale", "lrr_icp_assign_weights",
+    "lrr_icp_normalize_stats", "lrr_icp_clone_weights", "lrr_icp_weight_by_strength",
+    "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_get_matches",
+    "lrr_icp_nearest",
+]
+
+
+class _Features(C.Structure):
+    _fields_ = [("n", C.c_int64), ("loc", _dp), ("proj", _dp), ("strength", _dp),
+                ("shape", C.POINTER(C.c_uint8)), ("dirs", _dp)]
+
+
+class Xform(C.Structure):
+    _fields_ = [("A", C.c_double * 9), ("t", C.c_double * 3), ("c", C.c_double * 3)]
+
+
+class Norm(C.Structure):
+    _fields_ = [("cm", C.c_double * 3), ("rm", C.c_double), ("cf", C.c_double * 3), ("rf", C.c_double)]
+
+
+_hip = None
+_est = None
+
+
+def hip_lib() -> C.CDLL:
+    """The HIP library (C-ABI of include/lrr_icp.h)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise RuntimeError(f"{HIP_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the ICP hot path has no CPU fallback)")
+        L = C.CDLL(HIP_SO, mode=C.RTLD_GLOBAL)
+        L.lrr_icp_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.lrr_icp_destroy.argtypes = [C.c_void_p]
+        L.lrr_icp_last_error.argtypes = [C.c_void_p]
+        L.lrr_icp_last_error.restype = C.c_char_p
+        L.lrr_icp_synchronize.argtypes = [C.c_void_p]
+        L.lrr_icp_timer_start.argtypes = [C.c_void_p]
+        L.lrr_icp_timer_stop.argtypes = [C.c_void_p, _dp]
+        L.lrr_icp_match_profile.argtypes = [C.c_void_p, C.c_int, _dp, _ip, C.c_int]
+        L.lrr_icp_cloud_create.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, C.c_int, C.POINTER(C.c_void_p)]
+        L.lrr_icp_cloud_destroy.argtypes = [C.c_void_p]
+        L.lrr_icp_cloud_size.argtypes = [C.c_void_p]
+        L.lrr_icp_cloud_size.restype = C.c_int64
+        L.lrr_icp_perm_keys.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        L.lrr_icp_subset_perm.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_uint32)]
+        L.lrr_icp_subset_perm.restype = C.c_int64
+        L.lrr_icp_nearest.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int, _ip]
+        _hip = L
+    return _hip
+
+
+def est_lib() -> C.CDLL:
+    """The host C++ estimator classes behind their flat ctypes view."""
+    global _est
+    if _est is None:
+        hip_lib()
+        if not os.path.exists(EST_SO):
+            raise RuntimeError(f"{EST_SO} is missing: run __graft_entry__.build()")
+        L = C.CDLL(EST_SO)
+        L.lrr_est_last_error.restype = C.c_char_p
+        L.lrr_est_set_device.argtypes = [C.c_int]
+        L.lrr_est_context.restype = C.c_void_p
+        L.lrr_est_create.restype = C.c_void_p
+        L.lrr_est_create.argtypes = [C.c_int, C.c_int, C.POINTER(_Features), C.POINTER(_Features),
+                                     C.POINTER(_Features), C.POINTER(_Features), _dp, _dp, _dp,
+                                     C.c_uint64, C.c_int]
+        L.lrr_est_destroy.argtypes = [C.c_void_p]
+        L.lrr_est_set_transform.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.lrr_est_set_features.argtypes = [C.c_void_p, C.POINTER(_Features), C.POINTER(_Features)]
+        L.lrr_est_weight_by_strength.argtypes = [C.c_void_p, C.c_int]
+        L.lrr_est_normalize_matches.argtypes = [C.c_void_p]
+        L.lrr_est_set_number_points.argtypes = [C.c_void_p, C.c_int64]
+        L.lrr_est_inject_initial_scale.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.lrr_est_set_subset_order.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int64]
+        L.lrr_est_set_nn_method.argtypes = [C.c_void_p, C.c_int]
+        L.lrr_est_find_closest_euclidean.argtypes = [C.c_void_p]
+        L.lrr_est_one_iteration.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
+        L.lrr_est_run.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+        L.lrr_est_estimate_LS.argtypes = [C.c_void_p, C.c_int]
+        L.lrr_est_estimate_LS_backward.argtypes = [C.c_void_p, C.c_int]
+        L.lrr_est_get_transform.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
+        L.lrr_est_RMS_error.argtypes = [C.c_void_p, _dp]
+        for name in ("weighted_error", "sheet_angles", "tube_angles", "last_scale"):
+            getattr(L, "lrr_est_" + name).argtypes = [C.c_void_p, C.c_int, _dp]
+        L.lrr_est_compute_transfer_error_covariance.argtypes = [C.c_void_p, _dp, _dp]
+        L.lrr_est_oscillated.argtypes = [C.c_void_p]
+        L.lrr_est_finest_level.argtypes = [C.c_void_p]
+        L.lrr_est_num_matches.argtypes = [C.c_void_p, C.c_int]
+        L.lrr_est_num_matches.restype = C.c_int64
+        L.lrr_est_get_matches.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _dp]
+        L.lrr_est_get_number_points.argtypes = [C.c_void_p, C.c_int]
+        L.lrr_est_get_number_points.restype = C.c_int64
+        L.lrr_est_last_normal_equations.argtypes = [C.c_void_p, _dp, _dp]
+        _est = L
+    return _est
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _features(fs, keep):
+    if fs is None:
+        return None
+    loc = np.ascontiguousarray(fs.loc, dtype=np.float64)
+    proj = np.ascontiguousarray(fs.proj, dtype=np.float64)
+    st = np.ascontiguousarray(fs.strength, dtype=np.float64)
+    sh = np.ascontiguousarray(fs.shape, dtype=np.uint8)
+    di = np.ascontiguousarray(fs.dirs, dtype=np.float64)
+    keep.extend([loc, proj, st, sh, di])
+    return _Features(loc.shape[0], _d(loc), _d(proj), _d(st), sh.ctypes.data_as(C.POINTER(C.c_uint8)), _d(di))
+
+
+def set_device(index: int) -> None:
+    if est_lib().lrr_est_set_device(int(index)) != 0:
+        raise RuntimeError(est_lib().lrr_est_last_error().decode())
+
+
+def context() -> int:
+    """lrr_icp_ctx* of the calling thread (for the timing helpers)."""
+    h = est_lib().lrr_est_context()
+    if not h:
+        raise RuntimeError(est_lib().lrr_est_last_error().decode())
+    return h
+
+
+class DeviceTimer:
+    """HIP-event stopwatch on the estimator stream + accumulated match-kernel time."""
+
+    def __init__(self):
+        self.ctx = context()
+        self.L = hip_lib()
+
+    def start(self):
+        self.L.lrr_icp_timer_start(self.ctx)
+
+    def stop(self) -> float:
+        ms = C.c_double(0.0)
+        if self.L.lrr_icp_timer_stop(self.ctx, C.byref(ms)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+        return ms.value
+
+    def match_profile(self, enable=True, reset=False):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        if self.L.lrr_icp_match_profile(self.ctx, int(enable), C.byref(ms), C.byref(n), int(reset)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+        return ms.value, n.value
+
+    def synchronize(self):
+        self.L.lrr_icp_synchronize(self.ctx)
+
+
+class DeviceCloud:
+    """A feature cloud in HBM (tests of the stand-alone nearest-neighbour entry point)."""
+
+    def __init__(self, fs, float_strength=False):
+        self.L = hip_lib()
+        self.ctx = context()
+        keep = []
+        f = _features(fs, keep)
+        h = C.c_void_p()
+        if self.L.lrr_icp_cloud_create(self.ctx, f.n, f.loc, f.proj, f.strength, int(float_strength), C.byref(h)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+        self.h = h
+
+    def nearest(self, query, method=NN_GRID):
+        q = np.ascontiguousarray(query, dtype=np.float64)
+        out = np.empty(q.shape[0], dtype=np.int64)
+        if self.L.lrr_icp_nearest(self.h, _d(q), q.shape[0], method, out.ctypes.data_as(_ip)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lrr_icp_cloud_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def subset_perm(n: int, seed: int):
+    """The keyed subset permutation the match kernel evaluates (host copy, for tests)."""
+    L = hip_lib()
+    st = C.c_uint64(seed)
+    keys = (C.c_uint32 * 4)()
+    L.lrr_icp_perm_keys(C.byref(st), keys)
+    return np.array([L.lrr_icp_subset_perm(i, n, keys) for i in range(n)], dtype=np.int64), st.value
+
+
+class Estimator:
+    """The reference estimator classes' public methods, running on the GPU.
+
+    kind: CDCL_FORWARD / RRL_FORWARD -> cdcl_/rrl_estimation_ICP_matching_all<3,dof>,
+          CDCL_SYMMETRIC / RRL_SYMMETRIC -> cdcl_/rrl_estimation_symmetric_ICP_matching_all<3,dof>.
+    """
+
+    def __init__(self, kind, dof, moving, fixed, A, t, c, moving_inside=None, fixed_inside=None,
+                 seed=1, nn_method=NN_AUTO):
+        self.kind, self.dof = kind, dof
+        L = est_lib()
+        keep = []
+        fm, ff = _features(moving, keep), _features(fixed, keep)
+        fmi, ffi = _features(moving_inside, keep), _features(fixed_inside, keep)
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        self._h = L.lrr_est_create(kind, dof, C.byref(fm), C.byref(ff),
+                                   C.byref(fmi) if fmi is not None else None,
+                                   C.byref(ffi) if ffi is not None else None,
+                                   _d(A), _d(t), _d(c), seed, nn_method)
+        if not self._h:
+            raise RuntimeError("lrr_est_create: " + L.lrr_est_last_error().decode())
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(est_lib().lrr_est_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            est_lib().lrr_est_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_transform(self, A, t, c):
+        A, t, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, t, c))
+        self._ck(est_lib().lrr_est_set_transform(self._h, _d(A), _d(t), _d(c)))
+
+    def set_features(self, moving_inside, fixed_inside=None):
+        keep = []
+        a, b = _features(moving_inside, keep), _features(fixed_inside, keep)
+        self._ck(est_lib().lrr_est_set_features(self._h, C.byref(a), C.byref(b) if b is not None else None))
+
+    def weight_by_strength(self, flag=True):
+        self._ck(est_lib().lrr_est_weight_by_strength(self._h, int(flag)))
+
+    def normalize_matches(self):
+        self._ck(est_lib().lrr_est_normalize_matches(self._h))
+
+    def set_number_points(self, n):
+        self._ck(est_lib().lrr_est_set_number_points(self._h, int(n)))
+
+    def inject_initial_scale(self, fwd, bwd=-1.0):
+        self._ck(est_lib().lrr_est_inject_initial_scale(self._h, float(fwd), float(bwd)))
+
+    def set_subset_order(self, direction, order):
+        o = np.ascontiguousarray(order, dtype=np.int64)
+        self._ck(est_lib().lrr_est_set_subset_order(self._h, direction, o.ctypes.data_as(_ip), o.shape[0]))
+
+    def set_nn_method(self, method):
+        self._ck(est_lib().lrr_est_set_nn_method(self._h, int(method)))
+
+    def find_closest_euclidean(self):
+        self._ck(est_lib().lrr_est_find_closest_euclidean(self._h))
+
+    def one_iteration(self, iteration=0):
+        conv = C.c_int(0)
+        self._ck(est_lib().lrr_est_one_iteration(self._h, iteration, C.byref(conv)))
+        return bool(conv.value)
+
+    def run(self, max_iterations=30):
+        n, conv = C.c_uint(0), C.c_int(0)
+        self._ck(est_lib().lrr_est_run(self._h, max_iterations, C.byref(n), C.byref(conv)))
+        return bool(conv.value), int(n.value)
+
+    def estimate_LS(self, estimate_parameters=True):
+        self._ck(est_lib().lrr_est_estimate_LS(self._h, int(estimate_parameters)))
+
+    def estimate_LS_backward(self, estimate_parameters=False):
+        self._ck(est_lib().lrr_est_estimate_LS_backward(self._h, int(estimate_parameters)))
+
+    def get_transform(self, direction=0):
+        A, t, c = np.empty((3, 3)), np.empty(3), np.empty(3)
+        cov = np.empty((self.dof, self.dof))
+        self._ck(est_lib().lrr_est_get_transform(self._h, direction, _d(A), _d(t), _d(c), _d(cov)))
+        return A, t, c, cov
+
+    def _scalar(self, fn, *args):
+        out = C.c_double(0.0)
+        self._ck(fn(self._h, *args, C.byref(out)))
+        return out.value
+
+    def RMS_error(self):
+        return self._scalar(est_lib().lrr_est_RMS_error)
+
+    def weighted_error(self, direction=0):
+        return self._scalar(est_lib().lrr_est_weighted_error, direction)
+
+    def sheet_angles(self, direction=0):
+        return self._scalar(est_lib().lrr_est_sheet_angles, direction)
+
+    def tube_angles(self, direction=0):
+        return self._scalar(est_lib().lrr_est_tube_angles, direction)
+
+    def last_scale(self, direction=0):
+        return self._scalar(est_lib().lrr_est_last_scale, direction)
+
+    def compute_transfer_error_covariance(self):
+        a, b = np.zeros((3, 3)), np.zeros((3, 3))
+        self._ck(est_lib().lrr_est_compute_transfer_error_covariance(self._h, _d(a), _d(b)))
+        return a, b
+
+    def oscillated(self):
+        return bool(est_lib().lrr_est_oscillated(self._h))
+
+    def finest_level(self):
+        return bool(est_lib().lrr_est_finest_level(self._h))
+
+    def matches(self, direction=0):
+        n = est_lib().lrr_est_num_matches(self._h, direction)
+        f, t = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        w = np.empty(n, dtype=np.float64)
+        self._ck(est_lib().lrr_est_get_matches(self._h, direction, f.ctypes.data_as(_ip), t.ctypes.data_as(_ip), _d(w)))
+        return f, t, w
+
+    def number_points(self, direction=0):
+        return est_lib().lrr_est_get_number_points(self._h, direction)
+
+    def normal_equations(self):
+        AtA, Atb = np.empty((self.dof, self.dof)), np.empty(self.dof)
+        self._ck(est_lib().lrr_est_last_normal_equations(self._h, _d(AtA), _d(Atb)))
+        return AtA, Atb

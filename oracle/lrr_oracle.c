@@ -14,7 +14,8 @@
  *   - vnl_svd<double>::inverse/U/V  -> Jacobi eigen / one-sided Jacobi SVD
  *
  * Documented deviations from the reference (all invisible at 1e-10):
- *   - std::random_shuffle(rand()) -> seeded splitmix64 Fisher-Yates (lrr_oracle_shuffle)
+ *   - std::random_shuffle(rand()) -> a fresh seeded keyed permutation per call (lrr_oracle_shuffle);
+ *     the reference's shuffles are cumulative, which no caller can observe
  *   - std::set<smart_ptr> iteration (heap-address order) -> ascending feature index
  *   - the unused indices_vector shuffles in the symmetric estimate_LS are skipped
  *     (they only burn rand() state in the reference)
@@ -465,19 +466,46 @@ double lrr_oracle_muse_scale(const double *res, int64_t n) {
   return best_sk;
 }
 
-/* deterministic stand-in for std::random_shuffle (unseeded rand() in the reference,
- * cdcl/cdcl_estimation_ICP_matching_all.txx:557): splitmix64 + Fisher-Yates. */
+/* Deterministic stand-in for std::random_shuffle (unseeded rand() in the reference,
+ * cdcl/cdcl_estimation_ICP_matching_all.txx:557).  Each call draws a fresh keyed pseudo-random
+ * PERMUTATION of [0, n) that is computable per element (so the HIP match kernel evaluates it
+ * in-register): a 4-round Feistel network over the next even power of two, cycle-walked into
+ * [0, n).  Keys come from a splitmix64 stream.  Shared, bit for bit, with the product
+ * (include/lrr_icp.h: lrr_icp_perm_keys / the device function subset_perm). */
 static uint64_t splitmix64(uint64_t *s) {
   uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
   return z ^ (z >> 31);
 }
+static inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+void lrr_oracle_perm_keys(uint64_t *state, uint32_t keys[4]) {
+  for (int r = 0; r < 4; ++r) keys[r] = (uint32_t)(splitmix64(state) >> 32);
+}
+int64_t lrr_oracle_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]) {
+  int half = 1;
+  while ((1LL << (2 * half)) < n) ++half;
+  uint32_t mask = (uint32_t)((1u << half) - 1u);
+  uint64_t x = (uint64_t)i;
+  do {
+    uint32_t L = (uint32_t)(x >> half), R = (uint32_t)(x & mask);
+    for (int r = 0; r < 4; ++r) {
+      uint32_t F = fmix32(R ^ keys[r]) & mask;
+      uint32_t nL = R;
+      R = L ^ F;
+      L = nL;
+    }
+    x = ((uint64_t)L << half) | R;
+  } while (x >= (uint64_t)n);
+  return (int64_t)x;
+}
 void lrr_oracle_shuffle(int64_t *order, int64_t n, uint64_t *state) {
-  for (int64_t i = n - 1; i > 0; --i) {
-    int64_t j = (int64_t)(splitmix64(state) % (uint64_t)(i + 1));
-    int64_t tmp = order[i]; order[i] = order[j]; order[j] = tmp;
-  }
+  uint32_t keys[4];
+  lrr_oracle_perm_keys(state, keys);
+  for (int64_t i = 0; i < n; ++i) order[i] = lrr_oracle_subset_perm(i, n, keys);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -670,7 +698,7 @@ typedef struct {
   cloud fixed;          /* fixed_[res_]  */
   kdtree *kd;           /* kd_tree_[res_] (built from the un-normalised locations, once) */
   int nn_backend;
-  int64_t *order;       /* current order of the moving_ vector (cumulative shuffles) */
+  int64_t *order;       /* current order of the moving_ vector */
   int64_t number_points;
   trans tr;             /* trans_ */
   int normalize_matches, weight_by_strength, scale_estimated;

@@ -97,6 +97,8 @@ double lrr_oracle_muse_scale(const double *abs_res, int64_t n);
 double lrr_oracle_mad_scale(double *v, int64_t n);            /* permutes v */
 double lrr_oracle_weight_BT(double u);
 void   lrr_oracle_shuffle(int64_t *order, int64_t n, uint64_t *state);
+void   lrr_oracle_perm_keys(uint64_t *state, uint32_t keys[4]);
+int64_t lrr_oracle_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]);
 void   lrr_oracle_sym_pinv(int n, const double *M, double *out);
 void   lrr_oracle_svd3(const double *M, double *U, double *s, double *V);
 

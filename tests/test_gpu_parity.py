@@ -1,0 +1,244 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI and
+the C++ drop-in classes, against the CPU oracle on the same seeded inputs and against the
+committed golden fixtures.  Bars: match sets bit-exact (integer/index work); floating point
+within 1e-9 relative per stage (only the ORDER of the reductions differs from the oracle) and
+final transforms far inside the 1e-4 the north star asks for."""
+import numpy as np
+import pytest
+
+from lrr_amd import synth
+from tests.common import GOLDEN_CASES, check_against_golden, load_golden, make_estimator, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lrr_amd import estimation
+    estimation.hip_lib()
+    estimation.set_device(0)
+    return estimation
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    binding.build()
+    return binding
+
+
+# ---- K1: exact nearest neighbour ---------------------------------------------------------------
+@pytest.mark.parametrize("n,nq", [(1, 5), (7, 64), (4000, 3000), (50000, 20000)])
+def test_nearest_grid_and_brute_equal_oracle(E, ob, n, nq):
+    rng = np.random.default_rng(n)
+    pair = synth.make_pair(n, max(nq, 2), 7 + n)
+    fx = pair.fixed
+    if n >= 400:  # exact duplicates and lattice points: distance ties, lowest index must win
+        fx.loc[100:200] = fx.loc[0:100]
+        fx.loc[300:400] = np.round(fx.loc[300:400])
+    q = np.concatenate([
+        pair.planted.map(pair.moving.loc)[: nq // 2],
+        rng.uniform(-50, 350, size=(nq // 4, 3)),              # outside the bounding box too
+        fx.loc[rng.integers(0, n, size=nq // 8)],              # queries that ARE fixed points
+        rng.uniform(2000, 3000, size=(max(nq // 8, 1), 3)),    # far away: brute-force fallback list
+    ])
+    want = ob.nn(fx.loc, q, ob.NN_BRUTE)
+    cloud = E.DeviceCloud(fx)
+    assert np.array_equal(cloud.nearest(q, E.NN_GRID), want)
+    assert np.array_equal(cloud.nearest(q, E.NN_BRUTE), want)
+    cloud.close()
+
+
+def test_nearest_degenerate_clouds(E, ob):
+    rng = np.random.default_rng(5)
+    for loc in (np.zeros((50, 3)),                                              # all identical
+                np.c_[rng.uniform(0, 10, 500), np.zeros(500), np.zeros(500)],   # on a line
+                np.c_[rng.uniform(0, 10, (500, 2)), np.full(500, 3.0)]):        # on a plane
+        fs = synth.FeatureSet(loc, np.tile(np.eye(3).ravel(), (loc.shape[0], 1)), np.ones(loc.shape[0]),
+                              np.zeros(loc.shape[0], np.uint8), np.zeros((loc.shape[0], 6)))
+        q = rng.uniform(-5, 15, size=(300, 3))
+        cloud = E.DeviceCloud(fs)
+        want = ob.nn(loc, q, ob.NN_BRUTE)
+        assert np.array_equal(cloud.nearest(q, E.NN_GRID), want)
+        assert np.array_equal(cloud.nearest(q, E.NN_BRUTE), want)
+        cloud.close()
+
+
+def test_asymmetric_projector_rejected(E):
+    pair = synth.make_pair(10, 10, 3)
+    pair.fixed.proj[0, 1] += 1e-3
+    with pytest.raises(RuntimeError, match="symmetric"):
+        E.DeviceCloud(pair.fixed)
+
+
+# ---- golden fixtures ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("method", ["grid", "brute"])
+def test_gpu_reproduces_golden(E, name, method):
+    g, mv, fx = load_golden(name)
+    e = make_estimator(E.Estimator, g, mv, fx, nn_method=E.NN_GRID if method == "grid" else E.NN_BRUTE)
+    # MUSE sums the trimmed residuals in a different order: 1e-9 still holds
+    check_against_golden(e, g, match_exact=True, rtol=1e-9, param_rtol=1e-7)
+    e.close()
+
+
+# ---- live oracle comparisons at sizes the oracle finishes in seconds ---------------------------
+def _both(E, ob, kind, dof, pair, T0, seed, sym, n_points=None, normalize=False, strength=False, inject=None):
+    args = dict(moving_inside=pair.moving if sym else None, fixed_inside=pair.fixed if sym else None, seed=seed)
+    g = E.Estimator(kind, dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c, **args)
+    c = ob.OracleEstimator(kind, dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c, **args)
+    for e in (g, c):
+        if not sym:
+            if normalize:
+                e.normalize_matches()
+            e.weight_by_strength(strength)
+        if inject:
+            e.inject_initial_scale(*inject)
+        e.set_transform(T0.A, T0.t, T0.c)
+        if n_points:
+            e.set_number_points(n_points)
+    return g, c
+
+
+def _compare_iteration(g, c, it, dirs, tol=1e-8):
+    cg, cc = g.one_iteration(it), c.one_iteration(it)
+    assert cg == cc, f"iteration {it}: converged flag"
+    for d in dirs:
+        fg, tg, wg = g.matches(d)
+        fc, tc, wc = c.matches(d)
+        assert np.array_equal(fg, fc), f"it {it} dir {d}: subset"
+        assert np.array_equal(tg, tc), f"it {it} dir {d}: match set"
+        assert np.allclose(wg, wc, rtol=tol, atol=1e-12 * np.abs(wc).max()), f"it {it} dir {d}: weights"
+        assert abs(g.last_scale(d) - c.last_scale(d)) <= tol * c.last_scale(d), f"it {it} dir {d}: scale"
+        Ag, t_g, c_g, _ = g.get_transform(d)
+        Ac, t_c, c_c, _ = c.get_transform(d)
+        assert rel(Ag, Ac) < 1e-7 and rel(t_g, t_c) < 1e-7, f"it {it} dir {d}: transform"
+    return cg
+
+
+@pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("RRL_FORWARD", 12)])
+def test_forward_run_matches_oracle_config1(E, ob, kind_name, dof):
+    """config 1: 5k x 5k, rigid3d init = identity, faithful run() (1000 points, <= 30 iterations)"""
+    pair = synth.make_pair(5000, 5000, 20241, kind="rigid" if dof == 6 else "affine")
+    ident = synth.Transform(np.eye(3), np.zeros(3), np.zeros(3))
+    g, c = _both(E, ob, getattr(E, kind_name), dof, pair, ident, 11, False)
+    rg, rc = g.run(30), c.run(30)
+    assert rg == rc, "converged flag / iteration count"
+    assert np.array_equal(g.matches(0)[1], c.matches(0)[1])
+    Ag, tg, _, _ = g.get_transform()
+    Ac, tc, _, _ = c.get_transform()
+    assert rel(Ag, Ac) < 1e-6 and rel(tg, tc) < 1e-6
+    g.close()
+
+
+def test_forward_50k_single_estimate_config2(E, ob):
+    """config 2: 50k x 50k, single ICP estimate at n = all points, MUSE scale included"""
+    pair = synth.make_pair(50000, 50000, 20242, kind="rigid")
+    T0 = synth.perturbed(pair.planted, 2)
+    g, c = _both(E, ob, E.CDCL_FORWARD, 6, pair, T0, 12, False, n_points=50000)
+    for it in range(3):
+        _compare_iteration(g, c, it, (0,))
+    g.close()
+
+
+@pytest.mark.parametrize("kind_name,dof", [("RRL_SYMMETRIC", 12), ("CDCL_SYMMETRIC", 12), ("CDCL_SYMMETRIC", 6)])
+def test_symmetric_full_schedule_matches_oracle(E, ob, kind_name, dof):
+    """the faithful coarse-to-fine schedule (1000 -> ... -> all points), every iteration compared"""
+    pair = synth.make_pair(12000, 11000, 20243, kind="rigid" if dof == 6 else "affine")
+    T0 = synth.perturbed(pair.planted, 3)
+    g, c = _both(E, ob, getattr(E, kind_name), dof, pair, T0, 13, True)
+    its = 0
+    for it in range(40):
+        its += 1
+        if _compare_iteration(g, c, it, (0, 1)):
+            break
+    assert g.finest_level() == c.finest_level()
+    assert g.number_points(0) == c.number_points(0) and g.number_points(1) == c.number_points(1)
+    assert abs(g.weighted_error(1) - c.weighted_error(1)) < 1e-8 * max(1.0, c.weighted_error(1))
+    if kind_name == "RRL_SYMMETRIC":
+        assert abs(g.sheet_angles(0) - c.sheet_angles(0)) < 1e-9 and abs(g.tube_angles(0) - c.tube_angles(0)) < 1e-9
+        cg, cb = g.compute_transfer_error_covariance()
+        oc, obk = c.compute_transfer_error_covariance()
+        assert rel(cg, oc) < 1e-5 and rel(cb, obk) < 1e-5
+        g.estimate_LS_backward(False)
+        c.estimate_LS_backward(False)
+        assert rel(g.get_transform(1)[3], c.get_transform(1)[3]) < 1e-5
+    g.close()
+
+
+def test_roi_queries_set_features(E, ob):
+    """config 5 in miniature: one estimator object re-used over query locations
+    (set_features + set_transform, rrl/itkLocationRegistration.cxx:1635-1637)"""
+    pair = synth.make_pair(40000, 40000, 20245, kind="affine")
+    rois = synth.query_rois(pair, 3, 20245, half=50.0)
+    assert len(rois) == 3
+    T0 = synth.perturbed(pair.planted, 5)
+    g = c = None
+    for (_, _, mi, fi) in rois:
+        m_in, f_in = pair.moving.subset(mi), pair.fixed.subset(fi)
+        if g is None:
+            args = dict(moving_inside=m_in, fixed_inside=f_in, seed=15)
+            g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, **args)
+            c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, **args)
+        else:
+            for e in (g, c):
+                e.set_features(m_in, f_in)
+                e.set_transform(T0.A, T0.t, T0.c)
+        for it in range(12):
+            if _compare_iteration(g, c, it, (0, 1)):
+                break
+    g.close()
+
+
+def test_small_and_ragged_inputs(E, ob):
+    """fewer than 1000 points, unequal sizes, a single moving point"""
+    for nm, nf in ((1, 40), (37, 900), (999, 1001)):
+        pair = synth.make_pair(nf, nm, 30 + nm, kind="affine", outlier_frac=0.0)
+        T0 = synth.perturbed(pair.planted, 6)
+        g, c = _both(E, ob, E.CDCL_FORWARD, 12, pair, T0, 16, False, inject=(1.0, 1.0))
+        g.find_closest_euclidean()
+        c.find_closest_euclidean()
+        assert np.array_equal(g.matches(0)[0], c.matches(0)[0]) and np.array_equal(g.matches(0)[1], c.matches(0)[1])
+        assert abs(g.RMS_error() - c.RMS_error()) <= 1e-10 * max(1.0, c.RMS_error())
+        assert abs(g.weighted_error() - c.weighted_error()) <= 1e-10 * max(1.0, c.weighted_error())
+        g.close()
+
+
+# ---- full-size, oracle-free properties ---------------------------------------------------------
+def test_full_size_properties_200k(E):
+    """BASELINE size (200k x 200k): the two exact matchers agree, the match of an exact copy is the
+    identity, a noiseless planted transform is a fixed point and is recovered from a perturbation"""
+    n = 200000
+    pair = synth.make_pair(n, n, 20246, kind="affine", noise=0.0, outlier_frac=0.0)
+    cloud = E.DeviceCloud(pair.fixed)
+    q = pair.planted.map(pair.moving.loc)
+    a = cloud.nearest(q, E.NN_GRID)
+    b = cloud.nearest(q, E.NN_BRUTE)
+    assert np.array_equal(a, b)
+    d = np.linalg.norm(pair.fixed.loc[a] - q, axis=1)
+    sub = np.random.default_rng(0).integers(0, n, 200)
+    for i in sub[:50]:  # spot-check against numpy brute force
+        assert a[i] == ((pair.fixed.loc - q[i]) ** 2).sum(1).argmin()
+    assert np.array_equal(cloud.nearest(pair.fixed.loc, E.NN_GRID), np.arange(n))  # self-match
+    cloud.close()
+    # exact twin clouds: moving = planted^-1(fixed)
+    mv = synth._pull_back(pair.fixed, pair.planted)
+    T0 = synth.perturbed(pair.planted, 7, rot_deg=0.05, trans_mm=0.1)
+    e = E.Estimator(E.RRL_SYMMETRIC, 12, mv, pair.fixed, T0.A, T0.t, T0.c, moving_inside=mv, fixed_inside=pair.fixed, seed=17)
+    conv = False
+    for it in range(70):
+        conv = e.one_iteration(it)
+        if conv:
+            break
+    assert conv and e.finest_level() and e.number_points(0) == n
+    A, t, c, _ = e.get_transform()
+    x = mv.loc[:1000]
+    assert np.abs(synth.Transform(A, t, c).map(x) - pair.planted.map(x)).max() < 1e-6
+    f, tt, w = e.matches(0)
+    assert np.array_equal(np.sort(f), np.arange(n)) and np.array_equal(tt, f)  # every point found its twin
+    Ab, tb, cb, _ = e.get_transform(1)
+    Ti = synth.Transform(A, t, c).inverse()
+    assert rel(Ab, Ti.A) < 1e-10 and rel(tb, Ti.t) < 1e-10  # backward = inverse(forward)
+    e.close()
