@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the ICP hot path on MI355X — BASELINE.json's metric:
+matched-feature-pairs/s (+ ms/iteration) on 200k x 200k synthetic 3-D features.
+
+A "step" is ONE iteration of rrl_estimation_symmetric_ICP_matching_all<3,12>::one_iteration at
+the finest level (every point of both ROIs matched: 200k forward + 200k backward pairs), i.e.
+config[2] of BASELINE.json, which fits one GPU.  Inputs are resident in HBM before the timed
+region (uploaded by the estimator constructor).  N > 1 (one process per GPU, launched by
+torch.distributed.run): every rank runs an independent problem of the same size (weak scaling:
+the path shards over independent query problems), then ONE all_gather of the
+final transforms over RCCL.
+
+Prints one JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FEATURES = 200_000
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+# algorithmic bytes per matched pair, SURVEY.md §8(d): K1 = moving xyz 24 B + index write 4 B +
+# one stream of the fixed cloud 24*Nf/n B; whole fused iteration = 180 B/pair
+K1_BYTES_PER_PAIR_FIXED = 28.0
+ITER_BYTES_PER_PAIR = 180.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_FEATURES, help="features per volume (default: BASELINE size)")
+    ap.add_argument("--nn", choices=["grid", "brute"], default="grid")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=20)
+    return ap.parse_args()
+
+
+def cpu_baseline(pair, T0, n, iters):
+    """The CPU oracle (reference restatement; kd-tree NN like the reference's rsdl_kd_tree path),
+    1 thread as the reference is single-threaded (rrl sym .txx:760), on a bounded sample of the
+    same workload: `iters` finest-level symmetric iterations."""
+    from oracle import binding as ob
+    e = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                           moving_inside=pair.moving, fixed_inside=pair.fixed, seed=7, nn_backend=ob.NN_KDTREE)
+    e.set_number_points(10**9)  # finest level directly
+    e.one_iteration(0)          # warm-up (includes the MUSE scale)
+    t0 = time.perf_counter()
+    for it in range(iters):
+        e.one_iteration(it + 1)
+    dt = time.perf_counter() - t0
+    pairs = iters * 2 * n
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "ms_per_iteration": 1e3 * dt / iters,
+            "sample": f"{iters} finest-level symmetric iterations of the same {n}x{n} workload "
+                      f"(C oracle, kd-tree NN, {dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ICP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from lrr_amd import estimation as E
+    from lrr_amd import multi_gpu, synth
+
+    E.set_device(local_rank)
+    n = args.n
+    # independent problem per rank: same surfaces family, different seed
+    pair = synth.make_pair(n, n, 20243 + rank, kind="affine")
+    T0 = synth.perturbed(pair.planted, 3 + rank)
+    nn = E.NN_GRID if args.nn == "grid" else E.NN_BRUTE
+    t_up = time.perf_counter()
+    est = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                      moving_inside=pair.moving, fixed_inside=pair.fixed, seed=7, nn_method=nn)
+    upload_s = time.perf_counter() - t_up
+    timer = E.DeviceTimer()
+
+    # reach the finest level with the faithful coarse-to-fine schedule, then warm up
+    it = 0
+    while not est.finest_level() and it < 70:
+        est.one_iteration(it)
+        it += 1
+    schedule_iters = it
+    for _ in range(args.warmup):
+        est.one_iteration(it)
+        it += 1
+    n_pairs_step = est.number_points(0) + est.number_points(1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        timer.synchronize()
+
+    timer.match_profile(enable=True, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        est.one_iteration(it)
+        it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    match_ms, match_launches = timer.match_profile(enable=False, reset=False)
+
+    A, t, c, _ = est.get_transform()
+    row = multi_gpu.pack_result(rank, True, it, A, t, c, est.weighted_error(), est.RMS_error())
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        rows = multi_gpu.gather_results(row[None], world, device=torch.device("cuda", local_rank))
+    else:
+        rows = row[None]
+
+    if rank == 0:
+        total_pairs = args.steps * n_pairs_step * world
+        value = total_pairs / dt
+        k1_ms = match_ms / max(match_launches, 1)
+        n_dir = n_pairs_step // 2
+        k1_bytes = n_dir * K1_BYTES_PER_PAIR_FIXED + 24.0 * n  # per launch: n_dir queries vs one n-point cloud
+        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        out = {
+            "metric": "ICP matched-feature-pairs/sec",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{n}x{n} synthetic 3-D features, symmetric ICP "
+                                   "(rrl_estimation_symmetric_ICP_matching_all<3,12>), finest-level iteration, "
+                                   f"{n_pairs_step} matched pairs per step per GPU",
+                       "nn": args.nn, "schedule_iterations_before_timing": schedule_iters,
+                       "parallelism": f"{world} independent problem(s), one per GPU; one all_gather of the final transforms"},
+            "roofline": {"bound": "hbm", "kernel": "k_match_grid" if args.nn == "grid" else "k_match_brute",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k1_ms, "launches": match_launches,
+                         "algorithmic_bytes_per_launch": k1_bytes,
+                         "iteration_achieved_GBs": value / world * ITER_BYTES_PER_PAIR / 1e9,
+                         "iteration_frac": value / world * ITER_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS},
+            "upload_s": upload_s,
+            "final_weighted_error": float(rows[0, 17]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pair, T0, n, args.cpu_iters)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    est.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -232,13 +233,13 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
   void weight_by_strength() {
     double gs = 0;
     check(lrr_icp_weight_by_strength(dir_, nullptr, &gs), "weight_by_strength");
-    matches_dirty_ = true;
+    touch();
   }
   // (cdcl .txx:973-1004; rrl .txx:756-778)
   void weight_spatially() {
     double ss = 0;
     check(lrr_icp_weight_spatially(dir_, &norm_, nullptr, nullptr, &ss), "weight_spatially");
-    matches_dirty_ = true;
+    touch();
   }
   // (cdcl .txx:113-135): the search structure of the fixed set (here: upload + uniform grid)
   void build_kd_trees() {
@@ -256,7 +257,7 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     check(lrr_icp_match(dir_, &xf, keys, order, (int64_t)number_points_, nn_method_), "find_closest_euclidean");
     explicit_order_.clear();
     norm_ = identity_norm();
-    matches_dirty_ = true;
+    touch();
     premapped_ = false;
     premap_G_ = trans_sptr_type();
   }
@@ -275,7 +276,7 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     }
     check(lrr_icp_assign_weights(dir_, scale), "assign weights");
     last_scale_ = scale;
-    matches_dirty_ = true;
+    touch();
     return scale;
   }
   // (cdcl .txx:1009-1093; rrl .txx:783-859)
@@ -388,6 +389,8 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     matches_dirty_ = true;
     premapped_ = false;
     iterations_run_ = 0;
+    state_version_ = 1;
+    err_version_ = 0;
     for (unsigned i = 0; i < dof * dof; ++i) last_AtA_[i] = 0.0;
     for (unsigned i = 0; i < dof; ++i) last_Atb_[i] = 0.0;
   }
@@ -404,14 +407,25 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
   }
   void invalidate_matches() {
     matches_.clear();
-    matches_dirty_ = true;
+    touch();
     premapped_ = false;
     norm_ = identity_norm();
   }
+  // RMS_error / weighted_error share one device pass; its three sums are kept until the
+  // matches, the weights or the transform values change (the symmetric driver asks for the same
+  // weighted error at the end of one iteration and at the start of the next)
   void errors(double &s2, double &swr, double &sw) {
     lrr_icp_xform xf = xform_of(trans_);
+    if (err_version_ == state_version_ && std::memcmp(&xf, &err_xf_, sizeof xf) == 0) {
+      s2 = err_sums_[0]; swr = err_sums_[1]; sw = err_sums_[2];
+      return;
+    }
     check(lrr_icp_errors(dir_, &xf, &s2, &swr, &sw), "error metrics");
+    err_version_ = state_version_;
+    err_xf_ = xf;
+    err_sums_[0] = s2; err_sums_[1] = swr; err_sums_[2] = sw;
   }
+  void touch() { ++state_version_; matches_dirty_ = true; }
   void accumulate(trans_sptr_type const &jac_trans, int flags, double *AtA, double *Atb) {
     double c[3] = {jac_trans->center_moving_[0], jac_trans->center_moving_[1], jac_trans->center_moving_[2]};
     check(lrr_icp_accumulate(dir_, (int)dof, c, &norm_, flags, AtA, Atb), "normal equations");
@@ -442,7 +456,7 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     check(lrr_icp_premap(dir_, &G), "rigid pre-map");
     premapped_ = true;
     premap_G_ = global_transform->clone();
-    matches_dirty_ = true;
+    touch();
     trans_->set_parameterization(vnl_vector<double>(6, 0.0));
     return global_transform;
   }
@@ -503,6 +517,9 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
   std::vector<int64_t> explicit_order_;
   unsigned iterations_run_;
   double last_AtA_[dof * dof], last_Atb_[dof];
+  uint64_t state_version_, err_version_;
+  lrr_icp_xform err_xf_;
+  double err_sums_[3];
 };
 
 // =============================================================================================
@@ -618,7 +635,9 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     return converged && finest_level_;
   }
 
-  // (rrl sym .txx:699-918; cdcl sym .txx:398-701)
+  // (rrl sym .txx:699-918; cdcl sym .txx:398-701).  The per-match work of both lists is ONE fused,
+  // sync-free device submission (lrr_icp_estimate_symmetric); the host applies the returned
+  // statistics to the transform objects, solves the dof x dof system and un-normalises.
   void estimate_LS(bool estimate_parameters) {
     estimation_type &F = *forward_, &B = *backward_;
     trans_sptr_type forward_global, backward_global;
@@ -627,46 +646,39 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
       forward_global = F.begin_rigid_increment();
       if (B.is_rigid()) backward_global = B.begin_rigid_increment();
     }
-    F.estimate_scale_and_assign_weight();  // un-normalised coordinates
-    B.estimate_scale_and_assign_weight();
+    lrr_icp_sym_opts o;
+    o.dof = (int)dof;
+    o.rrl = RRL ? 1 : 0;
+    o.normalize = normalize_matches_ ? 1 : 0;
+    o.strength_f = F.weight_by_strength_ ? 1 : 0;
+    o.strength_b = B.weight_by_strength_ ? 1 : 0;
+    o.rigid_increment = rigid ? 1 : 0;
+    o.scale_mode_f = scale_mode(F, o.injected_f);
+    o.scale_mode_b = scale_mode(B, o.injected_b);
+    // centre of the forward transform as the accumulation sees it: the affine normalize() zeroes
+    // it (cdcl_trans_affine.txx:252), the rigid one keeps it (cdcl_trans_rigid3d.cxx:260-280)
+    for (int d = 0; d < 3; ++d) o.jac_centre[d] = (normalize_matches_ && dof == 12) ? 0.0 : F.trans_->center_moving_[d];
+    lrr_icp_xform xf = estimation_type::xform_of(F.trans_), xb = estimation_type::xform_of(B.trans_);
+    lrr_icp_sym_out r;
+    check(lrr_icp_estimate_symmetric(F.dir_, B.dir_, &xf, &xb, &o, &r), "fused symmetric estimate");
+    F.scale_estimated_ = B.scale_estimated_ = true;
+    F.last_scale_ = r.sigma_f;
+    B.last_scale_ = r.sigma_b;
+    F.touch();
+    B.touch();
     location_type cm(0.0), cf(0.0);
     double rm = 0.0, rf = 0.0;
     if (normalize_matches_) {
-      F.cdcl_normalize_matches(cm, rm, cf, rf);
+      for (int d = 0; d < 3; ++d) { cm[d] = r.norm.cm[d]; cf[d] = r.norm.cf[d]; }
+      rm = r.norm.rm;
+      rf = r.norm.rf;
       F.trans_->normalize(rm, rf, cm, cf);
-      B.cdcl_normalize_matches_known(cf, rf, cm, rm);  // flipped centres and radii
-      B.trans_->normalize(rf, rm, cf, cm);
+      B.trans_->normalize(rf, rm, cf, cm);  // flipped centres and radii
     }
-    double AtA[dof * dof], Atb[dof], AtA2[dof * dof], Atb2[dof];
-    if (RRL) {
-      if (F.weight_by_strength_) F.weight_by_strength();
-      if (B.weight_by_strength_) B.weight_by_strength();
-      F.weight_spatially();
-      B.weight_spatially();
-      F.accumulate(F.trans_, LRR_ICP_ACC_PREMUL_SKIP, AtA, Atb);
-      // backward term: Jacobian of the FORWARD transform at the backward to_, projector and
-      // right-hand side from the backward from_ (rrl sym .txx:557-646)
-      B.accumulate(F.trans_, LRR_ICP_ACC_PREMUL_SKIP | LRR_ICP_ACC_REVERSED, AtA2, Atb2);
-    } else {
-      // add_constraints (cdcl sym .txx:367-393, 541-546): the role-reversed clones of the backward
-      // matches are weighted together with the forward list, then dropped again
-      double gs = 0, ss = 0;
-      check(lrr_icp_clone_weights(B.dir_), "clone weights");
-      if (F.weight_by_strength_) check(lrr_icp_weight_by_strength(F.dir_, B.dir_, &gs), "merged weight_by_strength");
-      check(lrr_icp_weight_spatially(F.dir_, &F.norm_, B.dir_, &B.norm_, &ss), "merged weight_spatially");
-      F.matches_dirty_ = true;
-      const int rg = rigid ? LRR_ICP_ACC_RIGID_INCREMENT : 0;
-      F.accumulate(F.trans_, rg, AtA, Atb);
-      B.accumulate(F.trans_, rg | LRR_ICP_ACC_REVERSED | LRR_ICP_ACC_CLONE_W, AtA2, Atb2);
-    }
-    for (unsigned i = 0; i < dof * dof; ++i) AtA[i] += AtA2[i];
-    for (unsigned i = 0; i < dof; ++i) Atb[i] += Atb2[i];
-    F.solve_and_set(F.trans_, AtA, Atb, estimate_parameters);
+    F.solve_and_set(F.trans_, r.AtA, r.Atb, estimate_parameters);
     if (normalize_matches_) {
       F.trans_->unnormalize(rm, rf, cm, cf);
-      F.cdcl_unnormalize_matches(cm, rm, cf, rf);
       B.trans_->unnormalize(rf, rm, cf, cm);
-      B.cdcl_unnormalize_matches(cf, rf, cm, rm);
     }
     if (rigid) F.end_rigid_increment(forward_global);
     if (estimate_parameters) B.trans_ = F.trans_->inverse();
@@ -720,6 +732,14 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
       if (in) out.push_back(new feature_type(*(all[i])));
     }
     return out;
+  }
+  // first estimate after set_transform: MUSE (or the injected test value); afterwards the RMS of
+  // the residuals under the previous weights (rrl .txx:620-641)
+  static int scale_mode(estimation_type &D, double &injected) {
+    injected = 0.0;
+    if (D.scale_estimated_) return LRR_ICP_SCALE_RMS;
+    if (D.injected_scale_ > 0.0) { injected = D.injected_scale_; return LRR_ICP_SCALE_INJECTED; }
+    return LRR_ICP_SCALE_MUSE;
   }
   void reset_schedule() {
     oscillation_count_ = 0;

@@ -135,6 +135,36 @@ int  lrr_icp_accumulate(lrr_icp_dir *dir, int dof, const double jac_centre[3],
 int  lrr_icp_errors(lrr_icp_dir *dir, const lrr_icp_xform *xf, double *sum_r2, double *sum_wr,
                     double *sum_w);
 
+/* ---- fused symmetric estimate ----------------------------------------------------------------
+ * The device part of {cdcl,rrl}_estimation_symmetric_ICP_matching_all::estimate_LS
+ * (rrl sym .txx:699-878; cdcl sym .txx:458-628) as ONE asynchronous submission with a single
+ * device->host copy at the end: residuals and scales of both directions, normalisation
+ * statistics of the forward list, strength / spatial re-weighting with their MAD scales
+ * (order statistics on the device), and the summed normal equations of the forward list and
+ * the role-reversed backward list.  Same arithmetic as the granular calls above; scalars that
+ * the granular path hands back to the host between kernels stay in HBM here. */
+enum { LRR_ICP_SCALE_RMS = 0, LRR_ICP_SCALE_MUSE = 1, LRR_ICP_SCALE_INJECTED = 2 };
+typedef struct {
+  int dof;              /* 6 or 12 */
+  int rrl;              /* 1: rrl flavour (per-list weighting, pre-multiplied projector, skip w<1e-4);
+                           0: cdcl flavour (merged list weighting, clone weights for the backward list) */
+  int normalize;        /* normalize_matches_ */
+  int strength_f, strength_b; /* weight_by_strength_ of the two directions */
+  int rigid_increment;  /* b = q - p */
+  int scale_mode_f, scale_mode_b;
+  double injected_f, injected_b;
+  double jac_centre[3]; /* center_moving_ of the forward transform as the accumulation sees it */
+} lrr_icp_sym_opts;
+typedef struct {
+  lrr_icp_norm norm;    /* (cm, rm, cf, rf) of the forward list; identity when !normalize */
+  double sigma_f, sigma_b;
+  double grad_scale[2], spatial_scale[2]; /* [0] forward (or merged), [1] backward */
+  double AtA[144], Atb[12];
+} lrr_icp_sym_out;
+int  lrr_icp_estimate_symmetric(lrr_icp_dir *fwd, lrr_icp_dir *bwd, const lrr_icp_xform *xf_fwd,
+                                const lrr_icp_xform *xf_bwd, const lrr_icp_sym_opts *opts,
+                                lrr_icp_sym_out *out);
+
 /* matches_ on demand (callbacks, sheet/tube angles): from/to indices into the clouds, weights */
 int  lrr_icp_get_matches(lrr_icp_dir *dir, int64_t *from_idx, int64_t *to_idx, double *w);
 

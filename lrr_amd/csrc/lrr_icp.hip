@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -31,19 +32,26 @@
 namespace {
 
 constexpr int kBlock = 256;          // 4 wavefronts of 64
-constexpr int kMaxBlocks = 1024;     // reduction grids: 4 blocks / CU on 256 CUs
+constexpr int kMaxBlocks = 512;      // reduction grids: 2 blocks / CU on 256 CUs
 constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 for dof 12)
 constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
 constexpr int kRingMax = 6;          // grid search rings before the brute-force fallback
 constexpr int kSelThreads = 1024;
 constexpr int kMaxSelJobs = 32;
 constexpr int kProfEvents = 4096;
+// fused scratch: P1 (2*512 x 5), P2 (512 x 4), P3 (512 x 2), P4 (2*512 x 1), P6 (2*512 x 96), output block
+constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * 512 * 5, kFusedP3 = kFusedP2 + 512 * 4,
+              kFusedP4 = kFusedP3 + 512 * 2, kFusedP6 = kFusedP4 + 2 * 512, kFusedOut = kFusedP6 + 2 * 512 * 96,
+              kFusedDoubles = kFusedOut + 256;
 
 struct SelJob {
   const double *k0; int n0;
   const double *k1; int n1;
-  long long k;     // 0-based rank
-  double *out;     // out[0] = k-th smallest, out[1] = sum of keys < it, out[2] = their count
+  long long k;     // 0-based rank; < 0: MAD rank (m-1)/2+1 of the m counted keys (cnt rows below)
+  double *out;     // out[0] = k-th smallest, out[1] = sum of keys < it, out[2] = their count, out[3] = m
+  const double *cnt;               // per-block partial counts (1 double per row) or nullptr
+  int cnt_a0, cnt_a1, cnt_b0, cnt_b1;  // two row ranges whose sum is m
+  long long m_fixed;               // m when cnt == nullptr
 };
 
 }  // namespace
@@ -58,6 +66,8 @@ struct lrr_icp_ctx {
   double *h_pinned = nullptr;    // results staging
   SelJob *d_jobs = nullptr;
   SelJob *h_jobs = nullptr;
+  double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
+  double *h_fused = nullptr;
   // brute-force partial argmin scratch
   double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;
   int *d_overflow = nullptr; size_t overflow_cap = 0; int *d_overflow_count = nullptr;
@@ -198,12 +208,14 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *parti
   }
 }
 
-__global__ void k_reduce_partials(const double *partials, int nblocks, int K, double *out) {
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
+// one wavefront per output value: lane l sums blocks l, l+64, ... in order, then the fixed
+// shuffle tree — deterministic for a given (nblocks, K)
+__global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, int nblocks, int K, double *out) {
+  int k = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * K + k];
-  out[k] = s;
+  for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * K + k];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[k] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -236,20 +248,38 @@ __device__ __forceinline__ void scan_range(const GridView &g, int s, int e, doub
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// One thread per query: ring search over the uniform grid.  After ring r every unvisited point
-// lies beyond one of the interior faces of the (2r+1)^3 block, so the search stops as soon as
-// the best squared distance is strictly below (distance to the nearest such face - tol)^2.
-// Queries that are not settled after kRingMax rings go to the brute-force fallback list.
-__global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, XfD xf, int n,
-                                                       int *m_from, int *m_to, int *overflow,
-                                                       int *overflow_count) {
-  int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  int p = query_index(qs, i);
-  const double *pr = qs.rec + (size_t)p * qs.stride;
-  double yx, yy, yz;
-  map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
-  if (m_from) m_from[i] = p;
+__device__ __forceinline__ int subset_perm_inv(int p, int n, int half, const Keys &keys) {
+  unsigned mask = (1u << half) - 1u;
+  unsigned long long x = (unsigned)p;
+  do {
+    unsigned L = (unsigned)(x >> half), R = (unsigned)(x & mask);
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+      unsigned pR = L;
+      unsigned pL = R ^ (fmix32(L ^ keys.k[r]) & mask);
+      L = pL;
+      R = pR;
+    }
+    x = ((unsigned long long)L << half) | R;
+  } while (x >= (unsigned long long)n);
+  return (int)x;
+}
+
+// distance from coordinate v to the slab [lo, hi] widened by tol (cells own their points up to
+// rounding: tol covers the difference between floor((x-lo)/h) and the exact cell walls)
+__device__ __forceinline__ double slab_gap(double v, double lo, double hi, double tol) {
+  double g = v < lo ? lo - v : (v > hi ? v - hi : 0.0);
+  g -= tol;
+  return g > 0.0 ? g : 0.0;
+}
+
+// Exact nearest neighbour by ring search over the uniform grid.  Ring r = the cells at Chebyshev
+// distance r from the query's cell.  Inside a ring a row / cell is skipped when its box is
+// farther than the best distance so far (strictly: an equally distant point with a lower index
+// must still be seen); after ring r every unvisited point lies beyond an interior face of the
+// (2r+1)^3 block, so the search stops once best < (distance to the nearest such face - tol)^2.
+// Returns false when kRingMax rings did not settle the query (-> brute-force fallback list).
+__device__ __forceinline__ bool grid_search(const GridView &g, double yx, double yy, double yz, int &best) {
   int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
   int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
   int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
@@ -260,17 +290,38 @@ __global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, 
     int x0 = max(cx - r, 0), x1 = min(cx + r, g.dx - 1);
     int y0 = max(cy - r, 0), y1 = min(cy + r, g.dy - 1);
     int z0 = max(cz - r, 0), z1 = min(cz + r, g.dz - 1);
-    for (int z = z0; z <= z1; ++z)
+    for (int z = z0; z <= z1; ++z) {
+      double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
+      double dz2 = gz_ * gz_;
+      if (dz2 > bd) continue;
       for (int y = y0; y <= y1; ++y) {
+        double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
+        double dyz2 = dz2 + gy_ * gy_;
+        if (dyz2 > bd) continue;
         int row = (z * g.dy + y) * g.dx;
         bool shell = (z - cz == r) || (cz - z == r) || (y - cy == r) || (cy - y == r);
         if (shell) {
-          scan_range(g, g.cell_start[row + x0], g.cell_start[row + x1 + 1], yx, yy, yz, bd, bi);
+          int xa = x0, xb = x1;
+          if (bd < INFINITY) {  // only the cells whose x-slab meets [yx - rad, yx + rad]
+            double rad = sqrt(bd - dyz2) + 2.0 * g.tol;
+            xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
+            xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
+          }
+          if (xa <= xb) scan_range(g, g.cell_start[row + xa], g.cell_start[row + xb + 1], yx, yy, yz, bd, bi);
         } else {
-          if (cx - r >= 0) scan_range(g, g.cell_start[row + cx - r], g.cell_start[row + cx - r + 1], yx, yy, yz, bd, bi);
-          if (cx + r <= g.dx - 1) scan_range(g, g.cell_start[row + cx + r], g.cell_start[row + cx + r + 1], yx, yy, yz, bd, bi);
+          int xc = cx - r;
+          if (xc >= 0) {
+            double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
+            if (dyz2 + gx_ * gx_ <= bd) scan_range(g, g.cell_start[row + xc], g.cell_start[row + xc + 1], yx, yy, yz, bd, bi);
+          }
+          xc = cx + r;
+          if (xc <= g.dx - 1) {
+            double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
+            if (dyz2 + gx_ * gx_ <= bd) scan_range(g, g.cell_start[row + xc], g.cell_start[row + xc + 1], yx, yy, yz, bd, bi);
+          }
         }
       }
+    }
     double lb = INFINITY;
     if (cx - r > 0) lb = fmin(lb, yx - (g.lox + (cx - r) * g.h));
     if (cx + r < g.dx - 1) lb = fmin(lb, (g.lox + (cx + r + 1) * g.h) - yx);
@@ -284,11 +335,50 @@ __global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, 
       if (lb > 0.0 && bd < lb * lb) done = true;
     }
   }
-  if (done) m_to[i] = (bi == 0x7fffffff) ? 0 : bi;  // only reachable with non-finite input
+  best = (bi == 0x7fffffff) ? 0 : bi;  // 0x7fffffff only with non-finite input
+  return done;
+}
+
+// K1, query order = match-list order (explicit orders, coarse levels, stand-alone queries)
+__global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, XfD xf, int n,
+                                                       int *m_from, int *m_to, int *overflow,
+                                                       int *overflow_count) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int p = query_index(qs, i);
+  const double *pr = qs.rec + (size_t)p * qs.stride;
+  double yx, yy, yz;
+  map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
+  if (m_from) m_from[i] = p;
+  int bi;
+  if (grid_search(g, yx, yy, yz, bi)) m_to[i] = bi;
   else {
     m_to[i] = -1;
-    int slot = atomicAdd(overflow_count, 1);
-    overflow[slot] = i;
+    overflow[atomicAdd(overflow_count, 1)] = i;
+  }
+}
+
+// K1, spatially coherent form for the fine levels: thread s takes the s-th point of the
+// from-cloud in ITS grid order (coalesced loads; neighbouring lanes query neighbouring cells of
+// the target grid, so they share cache lines and ring counts) and writes the result into match
+// slot j = perm^-1(point), which keeps the match list identical to the direct form.
+__global__ __launch_bounds__(kBlock) void k_match_grid_coherent(GridView g, GridView gfrom, Keys keys,
+                                                                int half, int n_points, XfD xf,
+                                                                int *m_from, int *m_to, int *overflow,
+                                                                int *overflow_count) {
+  int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= gfrom.n) return;
+  int p = gfrom.gidx[s];
+  int j = subset_perm_inv(p, gfrom.n, half, keys);
+  if (j >= n_points) return;
+  double yx, yy, yz;
+  map_loc(xf, gfrom.gx[s], gfrom.gy[s], gfrom.gz[s], yx, yy, yz);
+  m_from[j] = p;
+  int bi;
+  if (grid_search(g, yx, yy, yz, bi)) m_to[j] = bi;
+  else {
+    m_to[j] = -1;
+    overflow[atomicAdd(overflow_count, 1)] = j;
   }
 }
 
@@ -574,6 +664,83 @@ __global__ void k_scale_w(double *w, int n, double f) {
 // so that only the ORDER of the sum differs from the CPU path.
 template <int DOF> struct Tri { static constexpr int N = DOF * (DOF + 1) / 2; };
 
+// per-pair update of the upper triangle (NT values) and the right-hand side (DOF values).
+// (jx,jy,jz): point the Jacobian is taken at; (b0,b1,b2): right-hand-side point; P: symmetric
+// projector (6 unique); (c0,c1,c2): centre of the transform.
+template <int DOF, bool PREMUL>
+__device__ __forceinline__ void accumulate_pair(double *acc, double wi, double jx, double jy, double jz,
+                                                double b0, double b1, double b2, double *P, double c0,
+                                                double c1, double c2, int rigid_increment) {
+  constexpr int NT = Tri<DOF>::N;
+  if (rigid_increment) { b0 = b0 - jx; b1 = b1 - jy; b2 = b2 - jz; }
+  if (PREMUL) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) P[k] = P[k] * wi;
+  }
+  const double Pm[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
+  double l0 = jx - c0, l1 = jy - c1, l2 = jz - c2;
+  if (DOF == 12) {
+    // affine Jacobian: J[d][3d+k] = l_k, J[d][9+d] = 1 (cdcl_trans_affine.txx:141-161);
+    // one non-zero per column, so (J^T P)[a][c] = lt[k_a] * P[d_a][c] exactly
+    const double lt[4] = {l0, l1, l2, 1.0};
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+      const int da = a < 9 ? a / 3 : a - 9, ka = a < 9 ? a % 3 : 3;
+      double Ma0 = lt[ka] * Pm[da][0], Ma1 = lt[ka] * Pm[da][1], Ma2 = lt[ka] * Pm[da][2];
+      const double Ma[3] = {Ma0, Ma1, Ma2};
+#pragma unroll
+      for (int b = a; b < 12; ++b) {
+        const int db = b < 9 ? b / 3 : b - 9, kb = b < 9 ? b % 3 : 3;
+        double v = Ma[db] * lt[kb];
+        acc[t++] += PREMUL ? v : v * wi;
+      }
+      double r = (Ma0 * b0 + Ma1 * b1) + Ma2 * b2;
+      acc[NT + a] += PREMUL ? r : r * wi;
+    }
+  } else {
+    // rigid small-angle Jacobian [-[l]x , I] (cdcl_trans_rigid3d.cxx:197-225)
+    const double J[3][6] = {{0.0, l2, -l1, 1.0, 0.0, 0.0}, {-l2, 0.0, l0, 0.0, 1.0, 0.0}, {l1, -l0, 0.0, 0.0, 0.0, 1.0}};
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double Ma[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Ma[c] = (J[0][a] * Pm[0][c] + J[1][a] * Pm[1][c]) + J[2][a] * Pm[2][c];
+#pragma unroll
+      for (int b = a; b < 6; ++b) {
+        double v = (Ma[0] * J[0][b] + Ma[1] * J[1][b]) + Ma[2] * J[2][b];
+        acc[t++] += PREMUL ? v : v * wi;
+      }
+      double r = (Ma[0] * b0 + Ma[1] * b1) + Ma[2] * b2;
+      acc[NT + a] += PREMUL ? r : r * wi;
+    }
+  }
+}
+
+// loads one match in normalised coordinates and orients it (reversed: role-reversed term)
+__device__ __forceinline__ void load_oriented(const PairSrc &ps, int i, const NormD &nm, int reversed,
+                                              double &jx, double &jy, double &jz, double &b0, double &b1,
+                                              double &b2, double *P) {
+  double p0, p1, p2;
+  load_from(ps, i, p0, p1, p2);
+  p0 = (p0 - nm.cm[0]) / nm.rm; p1 = (p1 - nm.cm[1]) / nm.rm; p2 = (p2 - nm.cm[2]) / nm.rm;
+  const double *qr = ps.to_rec + (size_t)ps.m_to[i] * kRecStride;
+  double q0 = (qr[0] - nm.cf[0]) / nm.rf, q1 = (qr[1] - nm.cf[1]) / nm.rf, q2 = (qr[2] - nm.cf[2]) / nm.rf;
+  if (!reversed) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) P[k] = qr[3 + k];
+    jx = p0; jy = p1; jz = p2;
+    b0 = q0; b1 = q1; b2 = q2;
+  } else {
+    const double *pr = ps.from_rec + (size_t)ps.m_from[i] * kRecStride;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) P[k] = pr[3 + k];
+    jx = q0; jy = q1; jz = q2;
+    b0 = p0; b1 = p1; b2 = p2;
+  }
+}
+
 template <int DOF, bool PREMUL>
 __global__ __launch_bounds__(kBlock) void k_accumulate(PairSrc ps, NormD nm, int n, const double *w,
                                                        double c0, double c1, double c2,
@@ -586,70 +753,9 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PairSrc ps, NormD nm, int
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     double wi = w[i];
     if (PREMUL && wi < 1e-4) continue;
-    double p0, p1, p2;
-    load_from(ps, i, p0, p1, p2);
-    p0 = (p0 - nm.cm[0]) / nm.rm; p1 = (p1 - nm.cm[1]) / nm.rm; p2 = (p2 - nm.cm[2]) / nm.rm;
-    const double *qr = ps.to_rec + (size_t)ps.m_to[i] * kRecStride;
-    double q0 = (qr[0] - nm.cf[0]) / nm.rf, q1 = (qr[1] - nm.cf[1]) / nm.rf, q2 = (qr[2] - nm.cf[2]) / nm.rf;
-    double P[6];
-    double jx, jy, jz, b0, b1, b2;
-    if (!reversed) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) P[k] = qr[3 + k];
-      jx = p0; jy = p1; jz = p2;
-      b0 = q0; b1 = q1; b2 = q2;
-    } else {
-      const double *pr = ps.from_rec + (size_t)ps.m_from[i] * kRecStride;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) P[k] = pr[3 + k];
-      jx = q0; jy = q1; jz = q2;
-      b0 = p0; b1 = p1; b2 = p2;
-    }
-    if (rigid_increment) { b0 = b0 - jx; b1 = b1 - jy; b2 = b2 - jz; }
-    if (PREMUL) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) P[k] = P[k] * wi;
-    }
-    // symmetric projector as a full 3x3
-    const double Pm[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
-    double l0 = jx - c0, l1 = jy - c1, l2 = jz - c2;
-    if (DOF == 12) {
-      // affine Jacobian: J[d][3d+k] = l_k, J[d][9+d] = 1 (cdcl_trans_affine.txx:141-161);
-      // one non-zero per column, so (J^T P)[a][c] = lt[k_a] * P[d_a][c] exactly
-      const double lt[4] = {l0, l1, l2, 1.0};
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < 12; ++a) {
-        const int da = a < 9 ? a / 3 : a - 9, ka = a < 9 ? a % 3 : 3;
-        double Ma0 = lt[ka] * Pm[da][0], Ma1 = lt[ka] * Pm[da][1], Ma2 = lt[ka] * Pm[da][2];
-        const double Ma[3] = {Ma0, Ma1, Ma2};
-#pragma unroll
-        for (int b = a; b < 12; ++b) {
-          const int db = b < 9 ? b / 3 : b - 9, kb = b < 9 ? b % 3 : 3;
-          double v = Ma[db] * lt[kb];
-          acc[t++] += PREMUL ? v : v * wi;
-        }
-        double r = (Ma0 * b0 + Ma1 * b1) + Ma2 * b2;
-        acc[NT + a] += PREMUL ? r : r * wi;
-      }
-    } else {
-      // rigid small-angle Jacobian [-[l]x , I] (cdcl_trans_rigid3d.cxx:197-225)
-      const double J[3][6] = {{0.0, l2, -l1, 1.0, 0.0, 0.0}, {-l2, 0.0, l0, 0.0, 1.0, 0.0}, {l1, -l0, 0.0, 0.0, 0.0, 1.0}};
-      int t = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        double Ma[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Ma[c] = (J[0][a] * Pm[0][c] + J[1][a] * Pm[1][c]) + J[2][a] * Pm[2][c];
-#pragma unroll
-        for (int b = a; b < 6; ++b) {
-          double v = (Ma[0] * J[0][b] + Ma[1] * J[1][b]) + Ma[2] * J[2][b];
-          acc[t++] += PREMUL ? v : v * wi;
-        }
-        double r = (Ma[0] * b0 + Ma[1] * b1) + Ma[2] * b2;
-        acc[NT + a] += PREMUL ? r : r * wi;
-      }
-    }
+    double jx, jy, jz, b0, b1, b2, P[6];
+    load_oriented(ps, i, nm, reversed, jx, jy, jz, b0, b1, b2, P);
+    accumulate_pair<DOF, PREMUL>(acc, wi, jx, jy, jz, b0, b1, b2, P, c0, c1, c2, rigid_increment);
   }
   block_reduce_store<NT + DOF>(acc, partials);
 }
@@ -672,21 +778,54 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
   __shared__ double red_c[kSelThreads / 64];
   SelJob job = jobs[blockIdx.x];
   int n = job.n0 + job.n1;
-  if (n <= 0 || job.k < 0 || job.k >= n) {
-    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; }
+  long long k = job.k, m = job.m_fixed;
+  if (job.cnt) {  // uniform branch: the whole block sums the partial counts in a fixed order
+    double c = 0.0;
+    for (int b = job.cnt_a0 + (int)threadIdx.x; b < job.cnt_a1; b += kSelThreads) c += job.cnt[b];
+    for (int b = job.cnt_b0 + (int)threadIdx.x; b < job.cnt_b1; b += kSelThreads) c += job.cnt[b];
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) red_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += red_c[w2];
+    __syncthreads();
+    m = (long long)tot;
+  }
+  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
+  if (n <= 0 || k < 0 || k >= n) {
+    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m; }
     return;
   }
   unsigned long long prefix = 0, mask = 0;
-  long long k = job.k;
   const int shifts[6] = {53, 42, 31, 20, 9, 0};
   const int widths[6] = {11, 11, 11, 11, 11, 9};
   for (int pass = 0; pass < 6; ++pass) {
     int shift = shifts[pass], bins = 1 << widths[pass];
     for (int b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kSelThreads) {
-      unsigned long long key = job_key(job, i);
-      if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & (unsigned long long)(bins - 1))], 1);
+    for (int base = 0; base < n; base += kSelThreads) {
+      int i = base + threadIdx.x;
+      bool act = false;
+      int dgt = 0;
+      if (i < n) {
+        unsigned long long key = job_key(job, i);
+        act = (key & mask) == prefix;
+        dgt = (int)((key >> shift) & (unsigned long long)(bins - 1));
+      }
+      // keys of similar magnitude share their leading digits: let one lane add the whole group
+      // (two rounds), the stragglers use their own LDS atomic
+      int lane = threadIdx.x & 63;
+#pragma unroll
+      for (int round = 0; round < 2; ++round) {
+        unsigned long long m = __ballot(act);
+        if (m == 0ull) break;
+        int leader = __ffsll((long long)m) - 1;
+        int d0 = __shfl(dgt, leader, 64);
+        unsigned long long same = __ballot(act && dgt == d0);
+        if (lane == leader) atomicAdd(&hist[d0], (int)__popcll(same));
+        if (dgt == d0) act = false;
+      }
+      if (act) atomicAdd(&hist[dgt], 1);
     }
     __syncthreads();
     // each thread owns 2 bins; block-wide exclusive scan of the pair sums
@@ -725,8 +864,222 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
   if (threadIdx.x == 0) {
     double s2 = 0.0, c2 = 0.0;
     for (int w2 = 0; w2 < kSelThreads / 64; ++w2) { s2 += red_s[w2]; c2 += red_c[w2]; }
-    job.out[0] = value; job.out[1] = s2; job.out[2] = c2;
+    job.out[0] = value; job.out[1] = s2; job.out[2] = c2; job.out[3] = (double)m;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused symmetric estimate: six kernels, no host round trip in between.  Scalars (scales,
+// normalisation statistics, MAD factors) are re-derived in each consumer kernel's prologue from
+// the producer's per-block partials, summed by every block in the same fixed order.
+// ---------------------------------------------------------------------------------------------
+struct DirArgs {
+  PairSrc ps;
+  int n;
+  double *w, *wc, *r2, *key_s, *key_g;
+  unsigned *flag;
+  int float_product;
+};
+
+// scalar block layout (doubles) inside the fused output buffer
+enum { SC_CM = 0, SC_RM = 3, SC_CF = 4, SC_RF = 7, SC_ND = 8, SC_SIGF = 9, SC_SIGB = 10, SC_SIZE = 16,
+       SEL_OFF = 16, SEL_SIZE = 16, FIN_OFF = 32, FUSED_OUT = 32 + kMaxRed };
+
+// sum of column k over rows [r0, r1) of a row-major partials table; same value in every thread
+__device__ __forceinline__ double block_total(const double *P, int r0, int r1, int K, int k) {
+  __shared__ double sh[kBlock / 64];
+  double s = 0.0;
+  for (int b = r0 + (int)threadIdx.x; b < r1; b += kBlock) s += P[(size_t)b * K + k];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double tot = sh[0];
+#pragma unroll
+  for (int w2 = 1; w2 < kBlock / 64; ++w2) tot += sh[w2];
+  __syncthreads();
+  return tot;
+}
+
+// F1: residuals of both lists (un-normalised coordinates: rrl sym .txx:701-705), sums for the
+// RMS scale, centroid sums and distinct-target marks of the forward list
+__global__ __launch_bounds__(kBlock) void k_f_residual(DirArgs F, DirArgs B, int nbF, int nbB, XfD xfF,
+                                                       XfD xfB, NormD ident, int want_stats, double *P1) {
+  const bool isF = (int)blockIdx.x < nbF;
+  const DirArgs &D = isF ? F : B;
+  const XfD &xf = isF ? xfF : xfB;
+  const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = lb * kBlock + threadIdx.x; i < D.n; i += nb * kBlock) {
+    double r2 = pair_residual2(D.ps, i, xf, ident);
+    double wp = D.w[i];
+    acc[0] += wp * r2;
+    acc[1] += wp;
+    D.r2[i] = r2;
+    D.key_s[i] = sqrt(r2);
+    if (isF && want_stats) {
+      double p0, p1, p2;
+      load_from(D.ps, i, p0, p1, p2);
+      acc[2] += p0; acc[3] += p1; acc[4] += p2;
+      D.flag[D.ps.m_to[i]] = 1u;
+    }
+  }
+  block_reduce_store<5>(acc, P1);
+}
+
+// F3: mean radii about the centroids (cdcl .txx:1195-1213)
+__global__ __launch_bounds__(kBlock) void k_f_radii(DirArgs F, int nbF, const double *P1, const double *P2,
+                                                    int nbT, const double *to_rec, int nt, double *P3,
+                                                    double *SC) {
+  double cm[3], cf[3];
+  for (int k = 0; k < 3; ++k) cm[k] = block_total(P1, 0, nbF, 5, 2 + k) / (double)F.n;
+  double nd = block_total(P2, 0, nbT, 4, 3);
+  for (int k = 0; k < 3; ++k) cf[k] = block_total(P2, 0, nbT, 4, k) / nd;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < 3; ++k) { SC[SC_CM + k] = cm[k]; SC[SC_CF + k] = cf[k]; }
+    SC[SC_ND] = nd;
+  }
+  double acc[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < F.n; i += gridDim.x * kBlock) {
+    double p0, p1, p2;
+    load_from(F.ps, i, p0, p1, p2);
+    p0 -= cm[0]; p1 -= cm[1]; p2 -= cm[2];
+    acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
+  }
+  for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
+    if (F.flag[j]) {
+      const double *q = to_rec + (size_t)j * kRecStride;
+      double q0 = q[0] - cf[0], q1 = q[1] - cf[1], q2 = q[2] - cf[2];
+      acc[1] += sqrt((q0 * q0 + q1 * q1) + q2 * q2);
+    }
+  }
+  block_reduce_store<2>(acc, P3);
+}
+
+struct WeightOpts {
+  int rrl, normalize, strength_f, strength_b;
+  int mode_f, mode_b;       // LRR_ICP_SCALE_*; MUSE arrives here as an injected value
+  double inj_f, inj_b;
+};
+
+__device__ __forceinline__ NormD norm_from_scalars(const double *SC, bool flipped) {
+  NormD nm;
+  if (!flipped) {
+    for (int k = 0; k < 3; ++k) { nm.cm[k] = SC[SC_CM + k]; nm.cf[k] = SC[SC_CF + k]; }
+    nm.rm = SC[SC_RM]; nm.rf = SC[SC_RF];
+  } else {  // backward list: flipped centres and radii (rrl sym .txx:719-720)
+    for (int k = 0; k < 3; ++k) { nm.cm[k] = SC[SC_CF + k]; nm.cf[k] = SC[SC_CM + k]; }
+    nm.rm = SC[SC_RF]; nm.rf = SC[SC_RM];
+  }
+  return nm;
+}
+
+// F4: Beaton-Tukey weights, strength gain and spatial keys.  The multiplications by 1/MADscale
+// are deferred to F6, in the reference's order: w = BT/s^2 ; w *= g ; w *= 1/gs ; w *= sw ; w *= 1/ss.
+__global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
+                                                      const double *P1, const double *P3, int nb3,
+                                                      double *SC, double *P4) {
+  const bool isF = (int)blockIdx.x < nbF;
+  const DirArgs &D = isF ? F : B;
+  const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
+  const int r0 = isF ? 0 : nbF, r1 = isF ? nbF : nbF + nbB;
+  const int mode = isF ? o.mode_f : o.mode_b;
+  double scale;
+  if (mode == LRR_ICP_SCALE_RMS) {
+    double S = block_total(P1, r0, r1, 5, 0), W = block_total(P1, r0, r1, 5, 1);
+    scale = sqrt(S / W);
+  } else {
+    scale = isF ? o.inj_f : o.inj_b;
+  }
+  __shared__ double sc_norm[8];
+  if (o.normalize) {
+    double rm = block_total(P3, 0, nb3, 2, 0) / (double)F.n;
+    double rf = block_total(P3, 0, nb3, 2, 1) / SC[SC_ND];
+    if (threadIdx.x == 0) {
+      for (int k = 0; k < 3; ++k) { sc_norm[k] = SC[SC_CM + k]; sc_norm[4 + k] = SC[SC_CF + k]; }
+      sc_norm[3] = rm; sc_norm[7] = rf;
+      if (blockIdx.x == 0) { SC[SC_RM] = rm; SC[SC_RF] = rf; }
+    }
+  } else if (threadIdx.x == 0) {
+    for (int k = 0; k < 8; ++k) sc_norm[k] = (k == 3 || k == 7) ? 1.0 : 0.0;
+    if (blockIdx.x == 0) for (int k = 0; k < 8; ++k) SC[k] = sc_norm[k];
+  }
+  if (lb == 0 && threadIdx.x == 0) SC[isF ? SC_SIGF : SC_SIGB] = scale;
+  __syncthreads();
+  NormD nm = norm_from_scalars(sc_norm, !isF);
+  const bool clone = !o.rrl && !isF;                 // cdcl: backward matches enter as role-reversed clones
+  const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
+  double *wdst = clone ? D.wc : D.w;
+  const double scale2 = scale * scale;
+  double acc[1] = {0.0};
+  for (int i = lb * kBlock + threadIdx.x; i < D.n; i += nb * kBlock) {
+    double u = D.r2[i] / scale2, bt = 0.0;
+    if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
+    double wi = bt / scale2;
+    if (clone) D.w[i] = wi;  // the backward list itself keeps its Beaton-Tukey weights (cdcl sym .txx:665)
+    double key = INFINITY;
+    if (strength && wi != 0) {
+      double sp = D.ps.from_rec[(size_t)D.ps.m_from[i] * kRecStride + 9];
+      double sq = D.ps.to_rec[(size_t)D.ps.m_to[i] * kRecStride + 9];
+      double g = D.float_product ? (double)((float)sp * (float)sq) : sp * sq;
+      if (g > 90000.0) g = 90000.0;
+      wi = wi * g;
+      key = g;
+      acc[0] += 1.0;
+    }
+    D.key_g[i] = key;
+    double q0, q1, q2;
+    if (clone) {  // the clone's to_ is this list's from_
+      load_from(D.ps, i, q0, q1, q2);
+      q0 = (q0 - nm.cm[0]) / nm.rm; q1 = (q1 - nm.cm[1]) / nm.rm; q2 = (q2 - nm.cm[2]) / nm.rm;
+    } else {
+      const double *q = D.ps.to_rec + (size_t)D.ps.m_to[i] * kRecStride;
+      q0 = (q[0] - nm.cf[0]) / nm.rf; q1 = (q[1] - nm.cf[1]) / nm.rf; q2 = (q[2] - nm.cf[2]) / nm.rf;
+    }
+    double d = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
+    D.key_s[i] = 1.0 / (1.0 + 5.0 * d * d);
+    wdst[i] = wi;
+  }
+  block_reduce_store<1>(acc, P4);
+}
+
+__device__ __forceinline__ double mad_factor(const double *sel) {  // 1 / rrel_util_median_abs_dev_scale
+  double m = sel[3];
+  double gs = m > 1.0 ? 1.4826 * (1 + 5.0 / (m - 1.0)) * sel[0] : 0.0;
+  return 1.0 / gs;
+}
+
+// F6: final weights and the normal equations of both lists (backward list role-reversed)
+template <int DOF, bool PREMUL>
+__global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
+                                                         const double *SC, const double *SEL, double c0,
+                                                         double c1, double c2, int rigid_increment,
+                                                         double *P6) {
+  constexpr int NT = Tri<DOF>::N;
+  const bool isF = (int)blockIdx.x < nbF;
+  const DirArgs &D = isF ? F : B;
+  const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
+  NormD nm = norm_from_scalars(SC, !isF);
+  const bool clone = !o.rrl && !isF;
+  const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
+  // selection slots: rrl {F.g, B.g, F.s, B.s}; cdcl {merged g, merged s}
+  const double fg = strength ? mad_factor(SEL + 4 * (o.rrl ? (isF ? 0 : 1) : 0)) : 1.0;
+  const double fs = mad_factor(SEL + 4 * (o.rrl ? (isF ? 2 : 3) : 1));
+  double *wbuf = clone ? D.wc : D.w;
+  double acc[NT + DOF];
+#pragma unroll
+  for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
+  for (int i = lb * kBlock + threadIdx.x; i < D.n; i += nb * kBlock) {
+    double wi = wbuf[i];
+    if (strength) wi = wi * fg;
+    wi = wi * D.key_s[i];
+    wi = wi * fs;
+    wbuf[i] = wi;
+    if (PREMUL && wi < 1e-4) continue;
+    double jx, jy, jz, b0, b1, b2, P[6];
+    load_oriented(D.ps, i, nm, isF ? 0 : 1, jx, jy, jz, b0, b1, b2, P);
+    accumulate_pair<DOF, PREMUL>(acc, wi, jx, jy, jz, b0, b1, b2, P, c0, c1, c2, rigid_increment);
+  }
+  block_reduce_store<NT + DOF>(acc, P6);
 }
 
 __global__ void k_copy_w(const double *src, double *dst, int n) {
@@ -799,7 +1152,7 @@ PairSrc pairs_of(const lrr_icp_dir *d) {
 
 // finish a block-partials reduction: final sum on device, copy K doubles to host, synchronise
 int finish_reduce(lrr_icp_ctx *ctx, int nblocks, int K, double *host_out) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3((K + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_partials, nblocks, K, ctx->d_final);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, ctx->stream, ctx->d_partials, nblocks, K, ctx->d_final);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_final, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -807,19 +1160,19 @@ int finish_reduce(lrr_icp_ctx *ctx, int nblocks, int K, double *host_out) {
   return LRR_ICP_OK;
 }
 
-// run up to kMaxSelJobs selection jobs; results (3 doubles per job) land in host_out
+// run up to kMaxSelJobs selection jobs; results (4 doubles per job) land in host_out
 int run_select(lrr_icp_ctx *ctx, std::vector<SelJob> &jobs, double *host_out) {
   int nj = (int)jobs.size();
   if (nj == 0) return LRR_ICP_OK;
   if (nj > kMaxSelJobs) return fail(ctx, LRR_ICP_ERR_ARG, "too many selection jobs");
   double *d_out = ctx->d_final + kMaxRed;
-  for (int j = 0; j < nj; ++j) { jobs[j].out = d_out + 3 * j; ctx->h_jobs[j] = jobs[j]; }
+  for (int j = 0; j < nj; ++j) { jobs[j].out = d_out + 4 * j; ctx->h_jobs[j] = jobs[j]; }
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, ctx->h_jobs, sizeof(SelJob) * nj, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_select, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, d_out, sizeof(double) * 3 * nj, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, d_out, sizeof(double) * 4 * nj, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  std::memcpy(host_out, ctx->h_pinned, sizeof(double) * 3 * nj);
+  std::memcpy(host_out, ctx->h_pinned, sizeof(double) * 4 * nj);
   return LRR_ICP_OK;
 }
 
@@ -858,8 +1211,8 @@ unsigned host_fmix32(unsigned h) {
 }
 
 // launch the exact NN search of n queries against `to`; results in m_to (and m_from when given)
-int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const QuerySrc &qs, const XfD &xf, int n,
-                 int method, int *m_from, int *m_to) {
+int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const lrr_icp_cloud *from_cloud, const QuerySrc &qs,
+                 const XfD &xf, int n, int method, int *m_from, int *m_to) {
   if (n <= 0) return LRR_ICP_OK;
   if (to->n <= 0) {
     HIPCHK(ctx, hipMemsetAsync(m_to, 0xff, sizeof(int) * n, ctx->stream));
@@ -897,7 +1250,12 @@ int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const QuerySrc &qs, const 
       ctx->overflow_cap = (size_t)n;
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow_count, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_match_grid, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, m_from, m_to, ctx->d_overflow, ctx->d_overflow_count);
+    if (from_cloud && qs.use_keys && !qs.order && m_from && (int64_t)n * 4 >= from_cloud->n) {
+      GridView gf = view_of(from_cloud);
+      hipLaunchKernelGGL(k_match_grid_coherent, dim3(blocks_for(from_cloud->n)), dim3(kBlock), 0, ctx->stream, g, gf, qs.keys, qs.half, n, xf, m_from, m_to, ctx->d_overflow, ctx->d_overflow_count);
+    } else {
+      hipLaunchKernelGGL(k_match_grid, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, m_from, m_to, ctx->d_overflow, ctx->d_overflow_count);
+    }
     HIPCHK(ctx, hipGetLastError());
     // exits immediately when the overflow list is empty; every block reaches its loop bound
     hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, ctx->stream, g, qs, xf, ctx->d_overflow, ctx->d_overflow_count, m_to);
@@ -945,11 +1303,13 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return bail(e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_partials, sizeof(double) * kMaxBlocks * kMaxRed)) != hipSuccess) return bail(e);
-  if ((e = hipMalloc(&ctx->d_final, sizeof(double) * (kMaxRed + 3 * kMaxSelJobs))) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 3 * kMaxSelJobs))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_final, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs))) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_overflow_count, sizeof(int))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256)) != hipSuccess) return bail(e);
   *out = ctx;
   return LRR_ICP_OK;
 }
@@ -971,6 +1331,8 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
   if (ctx->d_overflow_count) (void)hipFree(ctx->d_overflow_count);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
+  if (ctx->d_fused) (void)hipFree(ctx->d_fused);
+  if (ctx->h_fused) (void)hipHostFree(ctx->h_fused);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1053,7 +1415,9 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
   if (n > 0 && maxext > 0.0) {
     double vol = 1.0;
     for (int d = 0; d < 3; ++d) vol *= std::max(ext[d], maxext * 1e-3);
-    h = std::cbrt(vol / std::max<double>(1.0, (double)n / 2.0));
+    double ppc = 0.5;  // target points per cell (surfaces make occupied cells far denser)
+    if (const char *e = std::getenv("LRR_ICP_GRID_PPC")) { double v = std::atof(e); if (v > 0.0) ppc = v; }
+    h = std::cbrt(vol / std::max<double>(1.0, (double)n / ppc));
     h = std::max(h, maxext / 512.0);
   }
   int dim[3];
@@ -1206,7 +1570,7 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
     for (int r = 0; r < 4; ++r) qs.keys.k[r] = keys[r];
   }
   if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
-  rc = launch_match(ctx, d->to, qs, to_dev(xf), (int)n_points, method, d->m_from, d->m_to);
+  rc = launch_match(ctx, d->to, d->from, qs, to_dev(xf), (int)n_points, method, d->m_from, d->m_to);
   if (rc) return rc;
   // temporarily set weight to 1.0 (cdcl .txx:645)
   hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_points)), dim3(kBlock), 0, ctx->stream, d->w, (int)n_points, 1.0);
@@ -1293,16 +1657,16 @@ int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
     if (Qk / sd < 3.0) continue;  // min_exp_kth_to_stddev_ratio
     double div = (double)(n + 1) * std::sqrt(2.0 / M_PI) * (1.0 - std::exp(-Qk * Qk / 2.0));
     cands.push_back({k, Qk, sd, div});
-    SelJob j; j.k0 = d->key_s; j.n0 = (int)n; j.k1 = nullptr; j.n1 = 0; j.k = k - 1; j.out = nullptr;
+    SelJob j{}; j.k0 = d->key_s; j.n0 = (int)n; j.k1 = nullptr; j.n1 = 0; j.k = k - 1; j.out = nullptr; j.cnt = nullptr; j.m_fixed = n;
     jobs.push_back(j);
   }
-  std::vector<double> res(3 * jobs.size() + 3);
+  std::vector<double> res(4 * jobs.size() + 4);
   int rc = run_select(ctx, jobs, res.data());
   if (rc) return rc;
   bool at_start = true;
   double best_sk = 0.0, best_obj = 0.0;
   for (size_t c = 0; c < cands.size(); ++c) {
-    double vk = res[3 * c], sum_less = res[3 * c + 1], cnt_less = res[3 * c + 2];
+    double vk = res[4 * c], sum_less = res[4 * c + 1], cnt_less = res[4 * c + 2];
     // sum of the k smallest = sum of keys below the k-th value + copies of the k-th value
     double sum_k = sum_less + ((double)cands[c].k - cnt_less) * vk;
     double sk = sum_k / cands[c].div;
@@ -1392,10 +1756,11 @@ int lrr_icp_weight_by_strength(lrr_icp_dir *a, lrr_icp_dir *b, double *grad_scal
   if (m > 1) {
     // masked entries carry +inf keys and sort last, so rank k among the m finite keys is rank k overall
     std::vector<SelJob> jobs(1);
+    jobs[0] = SelJob{};
     jobs[0].k0 = a->key_g; jobs[0].n0 = (int)a->n;
     jobs[0].k1 = b ? b->key_g : nullptr; jobs[0].n1 = b ? (int)b->n : 0;
-    jobs[0].k = mad_rank(m); jobs[0].out = nullptr;
-    double res[3];
+    jobs[0].k = mad_rank(m); jobs[0].out = nullptr; jobs[0].cnt = nullptr; jobs[0].m_fixed = m;
+    double res[4];
     if ((rc = run_select(ctx, jobs, res))) return rc;
     gs = mad_from_kth(m, res[0]);
   }
@@ -1423,10 +1788,11 @@ int lrr_icp_weight_spatially(lrr_icp_dir *a, const lrr_icp_norm *norm_a, lrr_icp
   int rc;
   if (m > 1) {
     std::vector<SelJob> jobs(1);
+    jobs[0] = SelJob{};
     jobs[0].k0 = a->key_s; jobs[0].n0 = (int)a->n;
     jobs[0].k1 = b ? b->key_s : nullptr; jobs[0].n1 = b ? (int)b->n : 0;
-    jobs[0].k = mad_rank(m); jobs[0].out = nullptr;
-    double res[3];
+    jobs[0].k = mad_rank(m); jobs[0].out = nullptr; jobs[0].cnt = nullptr; jobs[0].m_fixed = m;
+    double res[4];
     if ((rc = run_select(ctx, jobs, res))) return rc;
     ss = mad_from_kth(m, res[0]);
   }
@@ -1485,6 +1851,99 @@ int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, doub
   return LRR_ICP_OK;
 }
 
+static DirArgs dir_args(lrr_icp_dir *d) {
+  DirArgs a;
+  a.ps = pairs_of(d);
+  a.n = (int)d->n;
+  a.w = d->w; a.wc = d->wc; a.r2 = d->r2; a.key_s = d->key_s; a.key_g = d->key_g;
+  a.flag = d->flag;
+  a.float_product = d->from->float_strength;
+  return a;
+}
+
+int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xform *xfF, const lrr_icp_xform *xfB,
+                               const lrr_icp_sym_opts *o, lrr_icp_sym_out *out) {
+  if (!F || !B || !xfF || !xfB || !o || !out || (o->dof != 6 && o->dof != 12)) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = F->ctx;
+  if (B->ctx != ctx) return fail(ctx, LRR_ICP_ERR_ARG, "estimate_symmetric: directions of different contexts");
+  if (F->n <= 0 || B->n <= 0) return fail(ctx, LRR_ICP_ERR_STATE, "estimate_symmetric: both directions need matches");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double *P1 = ctx->d_fused + kFusedP1, *P2 = ctx->d_fused + kFusedP2, *P3 = ctx->d_fused + kFusedP3;
+  double *P4 = ctx->d_fused + kFusedP4, *P6 = ctx->d_fused + kFusedP6, *OUT = ctx->d_fused + kFusedOut;
+  double *SC = OUT, *SEL = OUT + SEL_OFF, *FIN = OUT + FIN_OFF;
+  DirArgs aF = dir_args(F), aB = dir_args(B);
+  int nbF = grid_for(F->n), nbB = grid_for(B->n), nt = (int)F->to->n, nbT = grid_for(nt);
+  int nb3 = std::max(nbF, nbT);
+  NormD ident = to_dev((const lrr_icp_norm *)nullptr);
+  // F1
+  if (o->normalize) HIPCHK(ctx, hipMemsetAsync(F->flag, 0, sizeof(unsigned) * F->flag_cap, st));
+  hipLaunchKernelGGL(k_f_residual, dim3(nbF + nbB), dim3(kBlock), 0, st, aF, aB, nbF, nbB, to_dev(xfF), to_dev(xfB), ident, o->normalize, P1);
+  HIPCHK(ctx, hipGetLastError());
+  // scale modes; MUSE needs the sorted residuals: its tables and argmin stay on the host (first
+  // estimate after set_transform only)
+  WeightOpts wo;
+  wo.rrl = o->rrl; wo.normalize = o->normalize; wo.strength_f = o->strength_f; wo.strength_b = o->strength_b;
+  wo.mode_f = o->scale_mode_f; wo.mode_b = o->scale_mode_b; wo.inj_f = o->injected_f; wo.inj_b = o->injected_b;
+  if (wo.mode_f == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &wo.inj_f); if (rc) return rc; wo.mode_f = LRR_ICP_SCALE_INJECTED; }
+  if (wo.mode_b == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(B, &wo.inj_b); if (rc) return rc; wo.mode_b = LRR_ICP_SCALE_INJECTED; }
+  if (o->normalize) {
+    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kBlock), 0, st, F->to->rec, F->flag, nt, P2);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kBlock), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_f_weights, dim3(nbF + nbB), dim3(kBlock), 0, st, aF, aB, nbF, nbB, wo, P1, P3, nb3, SC, P4);
+  HIPCHK(ctx, hipGetLastError());
+  // order statistics: ranks of the strength jobs come from the device-side counts
+  SelJob *hj = ctx->h_jobs;
+  int nj = 0;
+  auto job = [&](const double *k0, int n0, const double *k1, int n1, bool counted, int a0, int a1, int b0, int b1) {
+    SelJob j{};
+    j.k0 = k0; j.n0 = n0; j.k1 = k1; j.n1 = n1; j.k = -1; j.out = SEL + 4 * nj;
+    j.cnt = counted ? P4 : nullptr; j.cnt_a0 = a0; j.cnt_a1 = a1; j.cnt_b0 = b0; j.cnt_b1 = b1;
+    j.m_fixed = (long long)n0 + n1;
+    hj[nj++] = j;
+  };
+  if (o->rrl) {
+    job(F->key_g, aF.n, nullptr, 0, true, 0, nbF, 0, 0);
+    job(B->key_g, aB.n, nullptr, 0, true, nbF, nbF + nbB, 0, 0);
+    job(F->key_s, aF.n, nullptr, 0, false, 0, 0, 0, 0);
+    job(B->key_s, aB.n, nullptr, 0, false, 0, 0, 0, 0);
+  } else {
+    job(F->key_g, aF.n, B->key_g, aB.n, true, 0, nbF, nbF, nbF + nbB);
+    job(F->key_s, aF.n, B->key_s, aB.n, false, 0, 0, 0, 0);
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, hj, sizeof(SelJob) * nj, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_select, dim3(nj), dim3(kSelThreads), 0, st, ctx->d_jobs);
+  HIPCHK(ctx, hipGetLastError());
+  // F6 + final reduction
+  int nbAF = std::min(nbF, 256), nbAB = std::min(nbB, 256);
+  const double *c = o->jac_centre;
+  const int nt2 = o->dof * (o->dof + 1) / 2, K = nt2 + o->dof;
+  if (o->dof == 12 && o->rrl) hipLaunchKernelGGL((k_f_accumulate<12, true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  else if (o->dof == 12) hipLaunchKernelGGL((k_f_accumulate<12, false>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  else if (o->rrl) hipLaunchKernelGGL((k_f_accumulate<6, true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  else hipLaunchKernelGGL((k_f_accumulate<6, false>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_fused, OUT, sizeof(double) * (FIN_OFF + K), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  const double *h = ctx->h_fused;
+  for (int k = 0; k < 3; ++k) { out->norm.cm[k] = h[SC_CM + k]; out->norm.cf[k] = h[SC_CF + k]; }
+  out->norm.rm = h[SC_RM]; out->norm.rf = h[SC_RF];
+  out->sigma_f = h[SC_SIGF]; out->sigma_b = h[SC_SIGB];
+  auto mad = [&](int slot) { const double *sl = h + SEL_OFF + 4 * slot; return sl[3] > 1.0 ? 1.4826 * (1 + 5.0 / (sl[3] - 1.0)) * sl[0] : 0.0; };
+  if (o->rrl) { out->grad_scale[0] = mad(0); out->grad_scale[1] = mad(1); out->spatial_scale[0] = mad(2); out->spatial_scale[1] = mad(3); }
+  else { out->grad_scale[0] = out->grad_scale[1] = mad(0); out->spatial_scale[0] = out->spatial_scale[1] = mad(1); }
+  int t = 0;
+  for (int a = 0; a < o->dof; ++a)
+    for (int b = a; b < o->dof; ++b) { out->AtA[a * o->dof + b] = h[FIN_OFF + t]; out->AtA[b * o->dof + a] = h[FIN_OFF + t]; ++t; }
+  for (int a = 0; a < o->dof; ++a) out->Atb[a] = h[FIN_OFF + nt2 + a];
+  return LRR_ICP_OK;
+}
+
 int lrr_icp_get_matches(lrr_icp_dir *d, int64_t *from_idx, int64_t *to_idx, double *w) {
   if (!d) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = d->ctx;
@@ -1521,7 +1980,7 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
     qs.rec = dq; qs.stride = 3; qs.order = nullptr; qs.use_keys = 0; qs.nsrc = (int)nq; qs.half = 1;
     std::memset(&qs.keys, 0, sizeof qs.keys);
     if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
-    rc = launch_match(ctx, cloud, qs, identity_xf(), (int)nq, method, nullptr, dto);
+    rc = launch_match(ctx, cloud, nullptr, qs, identity_xf(), (int)nq, method, nullptr, dto);
   }
   std::vector<int> tmp((size_t)nq);
   if (!rc && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(tmp.data(), dto, sizeof(int) * nq, hipMemcpyDeviceToHost) != hipSuccess))
