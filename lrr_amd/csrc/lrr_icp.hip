@@ -44,6 +44,9 @@ constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * 512 * 5, kFusedP3 = kFused
               kFusedP4 = kFusedP3 + 512 * 2, kFusedP6 = kFusedP4 + 2 * 512, kFusedOut = kFusedP6 + 2 * 512 * 96,
               kFusedDoubles = kFusedOut + 256;
 
+struct GridPoint { double x, y, z; long long idx; };  // 32 B: one candidate = two 16-B loads
+struct SelState { unsigned long long prefix, mask; long long k, m; };  // radix-select progress of one job
+
 struct SelJob {
   const double *k0; int n0;
   const double *k1; int n1;
@@ -66,6 +69,8 @@ struct lrr_icp_ctx {
   double *h_pinned = nullptr;    // results staging
   SelJob *d_jobs = nullptr;
   SelJob *h_jobs = nullptr;
+  SelState *d_selstate = nullptr;
+  int *d_selhist = nullptr;      // kMaxSelJobs x 2048
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
   double *h_fused = nullptr;
   // brute-force partial argmin scratch
@@ -85,8 +90,7 @@ struct lrr_icp_cloud {
   int64_t n = 0;
   int float_strength = 0;
   double *rec = nullptr;                       // n x 10, original order (gather target)
-  double *gx = nullptr, *gy = nullptr, *gz = nullptr;  // sorted by grid cell
-  int *gidx = nullptr;                         // original index of sorted point
+  GridPoint *gp = nullptr;                     // points sorted by grid cell (+ original index)
   int *cell_start = nullptr;                   // ncell + 1
   double lo[3] = {0, 0, 0}, h = 1.0, inv_h = 1.0, tol = 0.0;
   int dim[3] = {1, 1, 1};
@@ -126,8 +130,8 @@ struct NormD { double cm[3], rm, cf[3], rf; };
 struct Keys { unsigned k[4]; };
 
 struct GridView {
-  const double *gx, *gy, *gz;
-  const int *gidx, *cell_start;
+  const GridPoint *gp;   // points sorted by grid cell
+  const int *cell_start;
   double lox, loy, loz, h, inv_h, tol;
   int dx, dy, dz, n;
 };
@@ -240,8 +244,9 @@ __device__ __forceinline__ int query_index(const QuerySrc &q, int i) {
 __device__ __forceinline__ void scan_range(const GridView &g, int s, int e, double yx, double yy,
                                            double yz, double &bd, int &bi) {
   for (int j = s; j < e; ++j) {
-    double d = dist2(yx, yy, yz, g.gx[j], g.gy[j], g.gz[j]);
-    int oi = g.gidx[j];
+    GridPoint pt = g.gp[j];
+    double d = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
+    int oi = (int)pt.idx;
     if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
   }
 }
@@ -341,8 +346,8 @@ __device__ __forceinline__ bool grid_search(const GridView &g, double yx, double
 
 // K1, query order = match-list order (explicit orders, coarse levels, stand-alone queries)
 __global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, XfD xf, int n,
-                                                       int *m_from, int *m_to, int *overflow,
-                                                       int *overflow_count) {
+                                                       int *m_from, int *m_to, double *w_out,
+                                                       int *overflow, int *overflow_count) {
   int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   int p = query_index(qs, i);
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, 
   double yx, yy, yz;
   map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
   if (m_from) m_from[i] = p;
+  if (w_out) w_out[i] = 1.0;
   int bi;
   if (grid_search(g, yx, yy, yz, bi)) m_to[i] = bi;
   else {
@@ -364,16 +370,18 @@ __global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, 
 // slot j = perm^-1(point), which keeps the match list identical to the direct form.
 __global__ __launch_bounds__(kBlock) void k_match_grid_coherent(GridView g, GridView gfrom, Keys keys,
                                                                 int half, int n_points, XfD xf,
-                                                                int *m_from, int *m_to, int *overflow,
-                                                                int *overflow_count) {
+                                                                int *m_from, int *m_to, double *w_out,
+                                                                int *overflow, int *overflow_count) {
   int s = blockIdx.x * kBlock + threadIdx.x;
   if (s >= gfrom.n) return;
-  int p = gfrom.gidx[s];
+  GridPoint src = gfrom.gp[s];
+  int p = (int)src.idx;
   int j = subset_perm_inv(p, gfrom.n, half, keys);
   if (j >= n_points) return;
   double yx, yy, yz;
-  map_loc(xf, gfrom.gx[s], gfrom.gy[s], gfrom.gz[s], yx, yy, yz);
+  map_loc(xf, src.x, src.y, src.z, yx, yy, yz);
   m_from[j] = p;
+  w_out[j] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
   int bi;
   if (grid_search(g, yx, yy, yz, bi)) m_to[j] = bi;
   else {
@@ -398,8 +406,9 @@ __global__ __launch_bounds__(kBlock) void k_match_overflow(GridView g, QuerySrc 
     double bd = INFINITY;
     int bi = 0x7fffffff;
     for (int j = threadIdx.x; j < g.n; j += kBlock) {
-      double d = dist2(yx, yy, yz, g.gx[j], g.gy[j], g.gz[j]);
-      int oi = g.gidx[j];
+      GridPoint pt = g.gp[j];
+      double d = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
+      int oi = (int)pt.idx;
       if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
     }
     sd[threadIdx.x] = bd; si[threadIdx.x] = bi;
@@ -448,8 +457,9 @@ __global__ __launch_bounds__(kBlock) void k_match_brute(GridView g, QuerySrc qs,
     int tn = min(kBruteTile, end - base);
     __syncthreads();
     for (int j = threadIdx.x; j < tn; j += kBlock) {
-      sx[j] = g.gx[base + j]; sy[j] = g.gy[base + j]; sz[j] = g.gz[base + j];
-      sidx[j] = g.gidx[base + j];
+      GridPoint pt = g.gp[base + j];
+      sx[j] = pt.x; sy[j] = pt.y; sz[j] = pt.z;
+      sidx[j] = (int)pt.idx;
     }
     __syncthreads();
     for (int j = 0; j < tn; ++j) {
@@ -470,9 +480,10 @@ __global__ __launch_bounds__(kBlock) void k_match_brute(GridView g, QuerySrc qs,
     }
 }
 
-__global__ void k_brute_merge(const double *pd, const int *pi, int n, int S, int *m_to) {
+__global__ void k_brute_merge(const double *pd, const int *pi, int n, int S, int *m_to, double *w_out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (w_out) w_out[i] = 1.0;
   double bd = pd[i];
   int bi = pi[i];
   for (int s = 1; s < S; ++s) {
@@ -1082,6 +1093,106 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
   block_reduce_store<NT + DOF>(acc, P6);
 }
 
+// ---------------------------------------------------------------------------------------------
+// the same 6-pass MSB radix select spread over the chip: per pass one histogram kernel (many
+// blocks per job, LDS-private histograms flushed with integer atomics: order-independent, so
+// still deterministic) and one pick kernel (one block per job scans the 2048 bins, narrows the
+// prefix and clears the histogram).  Used for the MAD scales, where only the k-th value is needed.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSelHistBlocks = 64;   // blocks per job and pass
+
+__global__ __launch_bounds__(kBlock) void k_sel_init(const SelJob *jobs, SelState *st, int *hist) {
+  SelJob job = jobs[blockIdx.x];
+  long long m = job.m_fixed;
+  if (job.cnt) {
+    double tot = block_total(job.cnt, job.cnt_a0, job.cnt_a1, 1, 0) + block_total(job.cnt, job.cnt_b0, job.cnt_b1, 1, 0);
+    m = (long long)tot;
+  }
+  long long k = job.k;
+  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
+  if (k >= (long long)job.n0 + job.n1) k = -1;
+  for (int b = threadIdx.x; b < 2048; b += kBlock) hist[blockIdx.x * 2048 + b] = 0;
+  if (threadIdx.x == 0) { SelState s0; s0.prefix = 0; s0.mask = 0; s0.k = k; s0.m = m; st[blockIdx.x] = s0; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sel_hist(const SelJob *jobs, const SelState *st, int *hist, int shift, int bins) {
+  __shared__ int lh[2048];
+  SelJob job = jobs[blockIdx.y];
+  SelState s0 = st[blockIdx.y];
+  if (s0.k < 0) return;
+  for (int b = threadIdx.x; b < 2048; b += kBlock) lh[b] = 0;
+  __syncthreads();
+  int n = job.n0 + job.n1;
+  int per = (n + gridDim.x - 1) / gridDim.x;
+  int lo = blockIdx.x * per, hi = min(lo + per, n);
+  int lane = threadIdx.x & 63;
+  for (int base = lo; base < hi; base += kBlock) {
+    int i = base + threadIdx.x;
+    bool act = false;
+    int dgt = 0;
+    if (i < hi) {
+      unsigned long long key = job_key(job, i);
+      act = (key & s0.mask) == s0.prefix;
+      dgt = (int)((key >> shift) & (unsigned long long)(bins - 1));
+    }
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      unsigned long long mm = __ballot(act);
+      if (mm == 0ull) break;
+      int leader = __ffsll((long long)mm) - 1;
+      int d0 = __shfl(dgt, leader, 64);
+      unsigned long long same = __ballot(act && dgt == d0);
+      if (lane == leader) atomicAdd(&lh[d0], (int)__popcll(same));
+      if (dgt == d0) act = false;
+    }
+    if (act) atomicAdd(&lh[dgt], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += kBlock) {
+    int v = lh[b];
+    if (v) atomicAdd(&hist[blockIdx.y * 2048 + b], v);
+  }
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_sel_pick(const SelJob *jobs, SelState *st, int *hist, int shift, int bins, int last) {
+  __shared__ int wave_tot[kSelThreads / 64];
+  __shared__ int sel_bin, sel_before;
+  SelJob job = jobs[blockIdx.x];
+  SelState s0 = st[blockIdx.x];
+  int *h = hist + blockIdx.x * 2048;
+  if (s0.k < 0) {
+    if (last && threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
+    return;
+  }
+  int h0 = h[2 * threadIdx.x], h1 = h[2 * threadIdx.x + 1];
+  int s = h0 + h1, incl = s;
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
+  int excl = before + incl - s;
+  long long k = s0.k;
+  if (s > 0 && k >= excl && k < excl + s) {
+    if (k < excl + h0) { sel_bin = 2 * threadIdx.x; sel_before = excl; }
+    else { sel_bin = 2 * threadIdx.x + 1; sel_before = excl + h0; }
+  }
+  __syncthreads();
+  h[2 * threadIdx.x] = 0; h[2 * threadIdx.x + 1] = 0;  // ready for the next pass
+  if (threadIdx.x == 0) {
+    s0.prefix |= (unsigned long long)sel_bin << shift;
+    s0.mask |= (unsigned long long)(bins - 1) << shift;
+    s0.k = k - sel_before;
+    st[blockIdx.x] = s0;
+    if (last) { job.out[0] = __longlong_as_double((long long)s0.prefix); job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
+  }
+}
+
 __global__ void k_copy_w(const double *src, double *dst, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i];
@@ -1134,7 +1245,7 @@ XfD identity_xf() {
 
 GridView view_of(const lrr_icp_cloud *c) {
   GridView g;
-  g.gx = c->gx; g.gy = c->gy; g.gz = c->gz; g.gidx = c->gidx; g.cell_start = c->cell_start;
+  g.gp = c->gp; g.cell_start = c->cell_start;
   g.lox = c->lo[0]; g.loy = c->lo[1]; g.loz = c->lo[2];
   g.h = c->h; g.inv_h = c->inv_h; g.tol = c->tol;
   g.dx = c->dim[0]; g.dy = c->dim[1]; g.dz = c->dim[2];
@@ -1160,16 +1271,36 @@ int finish_reduce(lrr_icp_ctx *ctx, int nblocks, int K, double *host_out) {
   return LRR_ICP_OK;
 }
 
+// k-th values of nj jobs already uploaded to ctx->d_jobs: 1 + 6 x 2 asynchronous launches
+int launch_select_kth(lrr_icp_ctx *ctx, int nj) {
+  static const int shifts[6] = {53, 42, 31, 20, 9, 0};
+  static const int widths[6] = {11, 11, 11, 11, 11, 9};
+  hipLaunchKernelGGL(k_sel_init, dim3(nj), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_selstate, ctx->d_selhist);
+  HIPCHK(ctx, hipGetLastError());
+  for (int pass = 0; pass < 6; ++pass) {
+    hipLaunchKernelGGL(k_sel_hist, dim3(kSelHistBlocks, nj), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_selstate, ctx->d_selhist, shifts[pass], 1 << widths[pass]);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_sel_pick, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_selstate, ctx->d_selhist, shifts[pass], 1 << widths[pass], pass == 5 ? 1 : 0);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return LRR_ICP_OK;
+}
+
 // run up to kMaxSelJobs selection jobs; results (4 doubles per job) land in host_out
-int run_select(lrr_icp_ctx *ctx, std::vector<SelJob> &jobs, double *host_out) {
+int run_select(lrr_icp_ctx *ctx, std::vector<SelJob> &jobs, double *host_out, bool need_sums = false) {
   int nj = (int)jobs.size();
   if (nj == 0) return LRR_ICP_OK;
   if (nj > kMaxSelJobs) return fail(ctx, LRR_ICP_ERR_ARG, "too many selection jobs");
   double *d_out = ctx->d_final + kMaxRed;
   for (int j = 0; j < nj; ++j) { jobs[j].out = d_out + 4 * j; ctx->h_jobs[j] = jobs[j]; }
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, ctx->h_jobs, sizeof(SelJob) * nj, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_select, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs);
-  HIPCHK(ctx, hipGetLastError());
+  if (need_sums) {  // trimmed MUSE sums: single-block kernel that also accumulates the keys below the k-th
+    hipLaunchKernelGGL(k_select, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs);
+    HIPCHK(ctx, hipGetLastError());
+  } else {
+    int rc = launch_select_kth(ctx, nj);
+    if (rc) return rc;
+  }
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, d_out, sizeof(double) * 4 * nj, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   std::memcpy(host_out, ctx->h_pinned, sizeof(double) * 4 * nj);
@@ -1212,7 +1343,7 @@ unsigned host_fmix32(unsigned h) {
 
 // launch the exact NN search of n queries against `to`; results in m_to (and m_from when given)
 int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const lrr_icp_cloud *from_cloud, const QuerySrc &qs,
-                 const XfD &xf, int n, int method, int *m_from, int *m_to) {
+                 const XfD &xf, int n, int method, int *m_from, int *m_to, double *w_out) {
   if (n <= 0) return LRR_ICP_OK;
   if (to->n <= 0) {
     HIPCHK(ctx, hipMemsetAsync(m_to, 0xff, sizeof(int) * n, ctx->stream));
@@ -1240,7 +1371,7 @@ int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const lrr_icp_cloud *from_
     }
     hipLaunchKernelGGL(k_match_brute, dim3(bx, S), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, chunk, m_from, ctx->d_bd, ctx->d_bi);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_bd, ctx->d_bi, n, S, m_to);
+    hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_bd, ctx->d_bi, n, S, m_to, w_out);
     HIPCHK(ctx, hipGetLastError());
   } else {
     if ((size_t)n > ctx->overflow_cap) {
@@ -1250,11 +1381,11 @@ int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const lrr_icp_cloud *from_
       ctx->overflow_cap = (size_t)n;
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow_count, 0, sizeof(int), ctx->stream));
-    if (from_cloud && qs.use_keys && !qs.order && m_from && (int64_t)n * 4 >= from_cloud->n) {
+    if (from_cloud && qs.use_keys && !qs.order && m_from && w_out && (int64_t)n * 4 >= from_cloud->n) {
       GridView gf = view_of(from_cloud);
-      hipLaunchKernelGGL(k_match_grid_coherent, dim3(blocks_for(from_cloud->n)), dim3(kBlock), 0, ctx->stream, g, gf, qs.keys, qs.half, n, xf, m_from, m_to, ctx->d_overflow, ctx->d_overflow_count);
+      hipLaunchKernelGGL(k_match_grid_coherent, dim3(blocks_for(from_cloud->n)), dim3(kBlock), 0, ctx->stream, g, gf, qs.keys, qs.half, n, xf, m_from, m_to, w_out, ctx->d_overflow, ctx->d_overflow_count);
     } else {
-      hipLaunchKernelGGL(k_match_grid, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, m_from, m_to, ctx->d_overflow, ctx->d_overflow_count);
+      hipLaunchKernelGGL(k_match_grid, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, m_from, m_to, w_out, ctx->d_overflow, ctx->d_overflow_count);
     }
     HIPCHK(ctx, hipGetLastError());
     // exits immediately when the overflow list is empty; every block reaches its loop bound
@@ -1309,6 +1440,8 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipHostMalloc(&ctx->h_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_overflow_count, sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_selstate, sizeof(SelState) * kMaxSelJobs)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_selhist, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256)) != hipSuccess) return bail(e);
   *out = ctx;
   return LRR_ICP_OK;
@@ -1332,6 +1465,8 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->d_overflow_count) (void)hipFree(ctx->d_overflow_count);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
   if (ctx->d_fused) (void)hipFree(ctx->d_fused);
+  if (ctx->d_selstate) (void)hipFree(ctx->d_selstate);
+  if (ctx->d_selhist) (void)hipFree(ctx->d_selhist);
   if (ctx->h_fused) (void)hipHostFree(ctx->h_fused);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1438,25 +1573,20 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
     start[(size_t)id + 1]++;
   }
   for (int64_t k = 0; k < ncell; ++k) start[(size_t)k + 1] += start[(size_t)k];
-  std::vector<int> cursor(start.begin(), start.end() - 1), gidx((size_t)std::max<int64_t>(n, 1));
-  std::vector<double> gx((size_t)std::max<int64_t>(n, 1)), gy(gx.size()), gz(gx.size());
+  std::vector<int> cursor(start.begin(), start.end() - 1);
+  std::vector<GridPoint> gp((size_t)std::max<int64_t>(n, 1));
   for (int64_t i = 0; i < n; ++i) {  // ascending i: original order kept inside a cell
     int pos = cursor[(size_t)cell[(size_t)i]]++;
-    gidx[(size_t)pos] = (int)i;
-    gx[(size_t)pos] = loc[3 * i]; gy[(size_t)pos] = loc[3 * i + 1]; gz[(size_t)pos] = loc[3 * i + 2];
+    gp[(size_t)pos] = GridPoint{loc[3 * i], loc[3 * i + 1], loc[3 * i + 2], (long long)i};
   }
   auto cleanup = [&](int code, const std::string &msg) { lrr_icp_cloud_destroy(c); return fail(ctx, code, msg); };
   size_t m = (size_t)std::max<int64_t>(n, 1);
   if (hipMalloc(&c->rec, sizeof(double) * m * kRecStride) != hipSuccess ||
-      hipMalloc(&c->gx, sizeof(double) * m) != hipSuccess || hipMalloc(&c->gy, sizeof(double) * m) != hipSuccess ||
-      hipMalloc(&c->gz, sizeof(double) * m) != hipSuccess || hipMalloc(&c->gidx, sizeof(int) * m) != hipSuccess ||
+      hipMalloc(&c->gp, sizeof(GridPoint) * m) != hipSuccess ||
       hipMalloc(&c->cell_start, sizeof(int) * ((size_t)ncell + 1)) != hipSuccess)
     return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
   if (hipMemcpy(c->rec, rec.data(), sizeof(double) * m * kRecStride, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->gx, gx.data(), sizeof(double) * m, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->gy, gy.data(), sizeof(double) * m, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->gz, gz.data(), sizeof(double) * m, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->gidx, gidx.data(), sizeof(int) * m, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->gp, gp.data(), sizeof(GridPoint) * m, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), hipMemcpyHostToDevice) != hipSuccess)
     return cleanup(LRR_ICP_ERR_HIP, "cloud_create: upload failed");
   *out = c;
@@ -1466,7 +1596,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
 void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
-  void *ptrs[] = {c->rec, c->gx, c->gy, c->gz, c->gidx, c->cell_start};
+  void *ptrs[] = {c->rec, c->gp, c->cell_start};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
@@ -1570,12 +1700,8 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
     for (int r = 0; r < 4; ++r) qs.keys.k[r] = keys[r];
   }
   if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
-  rc = launch_match(ctx, d->to, d->from, qs, to_dev(xf), (int)n_points, method, d->m_from, d->m_to);
-  if (rc) return rc;
-  // temporarily set weight to 1.0 (cdcl .txx:645)
-  hipLaunchKernelGGL(k_fill, dim3(blocks_for(n_points)), dim3(kBlock), 0, ctx->stream, d->w, (int)n_points, 1.0);
-  HIPCHK(ctx, hipGetLastError());
-  return LRR_ICP_OK;
+  // the match kernels also set every weight to 1.0 (cdcl .txx:645)
+  return launch_match(ctx, d->to, d->from, qs, to_dev(xf), (int)n_points, method, d->m_from, d->m_to, d->w);
 }
 
 int lrr_icp_premap(lrr_icp_dir *d, const lrr_icp_xform *G) {
@@ -1661,7 +1787,7 @@ int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
     jobs.push_back(j);
   }
   std::vector<double> res(4 * jobs.size() + 4);
-  int rc = run_select(ctx, jobs, res.data());
+  int rc = run_select(ctx, jobs, res.data(), true);
   if (rc) return rc;
   bool at_start = true;
   double best_sk = 0.0, best_obj = 0.0;
@@ -1915,8 +2041,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
     job(F->key_s, aF.n, B->key_s, aB.n, false, 0, 0, 0, 0);
   }
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, hj, sizeof(SelJob) * nj, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_select, dim3(nj), dim3(kSelThreads), 0, st, ctx->d_jobs);
-  HIPCHK(ctx, hipGetLastError());
+  { int rc = launch_select_kth(ctx, nj); if (rc) return rc; }
   // F6 + final reduction
   int nbAF = std::min(nbF, 256), nbAB = std::min(nbB, 256);
   const double *c = o->jac_centre;
@@ -1980,7 +2105,7 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
     qs.rec = dq; qs.stride = 3; qs.order = nullptr; qs.use_keys = 0; qs.nsrc = (int)nq; qs.half = 1;
     std::memset(&qs.keys, 0, sizeof qs.keys);
     if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
-    rc = launch_match(ctx, cloud, nullptr, qs, identity_xf(), (int)nq, method, nullptr, dto);
+    rc = launch_match(ctx, cloud, nullptr, qs, identity_xf(), (int)nq, method, nullptr, dto, nullptr);
   }
   std::vector<int> tmp((size_t)nq);
   if (!rc && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(tmp.data(), dto, sizeof(int) * nq, hipMemcpyDeviceToHost) != hipSuccess))
