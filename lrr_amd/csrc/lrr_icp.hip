@@ -35,7 +35,10 @@ constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kMaxBlocks = 512;      // reduction grids: 2 blocks / CU on 256 CUs
 constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 for dof 12)
 constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
-constexpr int kRingMax = 6;          // grid search rings before the brute-force fallback
+constexpr int kScanUnroll = 8;       // candidate loads in flight per lane in the grid search
+constexpr int kEasyBudget = 48;      // candidate points a lane may scan in the thread-per-query phase
+constexpr int kRingEasy = 1;         // rings walked by the thread-per-query phase of the grid search
+constexpr int kRingMax = 8;          // rings walked by the wave-per-query phase before the brute-force fallback
 constexpr int kSelThreads = 1024;
 constexpr int kMaxSelJobs = 32;
 constexpr int kProfEvents = 4096;
@@ -75,7 +78,7 @@ struct lrr_icp_ctx {
   double *h_fused = nullptr;
   // brute-force partial argmin scratch
   double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;
-  int *d_overflow = nullptr; size_t overflow_cap = 0; int *d_overflow_count = nullptr;
+  int *d_overflow = nullptr, *d_hard = nullptr; size_t overflow_cap = 0; int *d_overflow_count = nullptr;  // [0] hard, [1] overflow
   int *d_order = nullptr; size_t order_cap = 0;
   // match-kernel profile (event pairs resolved lazily)
   bool prof = false;
@@ -243,11 +246,20 @@ __device__ __forceinline__ int query_index(const QuerySrc &q, int i) {
 
 __device__ __forceinline__ void scan_range(const GridView &g, int s, int e, double yx, double yy,
                                            double yz, double &bd, int &bi) {
-  for (int j = s; j < e; ++j) {
-    GridPoint pt = g.gp[j];
-    double d = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
-    int oi = (int)pt.idx;
-    if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+  // kScanUnroll candidates are loaded before any is compared: the loads are independent, so a lane
+  // keeps that many 32-B requests in flight instead of paying one L2 round trip per point
+  for (int j = s; j < e; j += kScanUnroll) {
+    GridPoint pt[kScanUnroll];
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u) pt[u] = g.gp[min(j + u, e - 1)];
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u) {
+      if (j + u < e) {
+        double d = dist2(yx, yy, yz, pt[u].x, pt[u].y, pt[u].z);
+        int oi = (int)pt[u].idx;
+        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+      }
+    }
   }
 }
 
@@ -283,15 +295,25 @@ __device__ __forceinline__ double slab_gap(double v, double lo, double hi, doubl
 // farther than the best distance so far (strictly: an equally distant point with a lower index
 // must still be seen); after ring r every unvisited point lies beyond an interior face of the
 // (2r+1)^3 block, so the search stops once best < (distance to the nearest such face - tol)^2.
-// Returns false when kRingMax rings did not settle the query (-> brute-force fallback list).
-__device__ __forceinline__ bool grid_search(const GridView &g, double yx, double yy, double yz, int &best) {
+// Returns false when the query is not settled inside rings 0..ring_max or would need more than
+// `budget` candidate points: such queries go to the wave-per-query kernel, so no lane of this
+// kernel ever walks a long serial chain (kernel time = slowest lane).
+__device__ __forceinline__ bool grid_search(const GridView &g, double yx, double yy, double yz, int ring_max,
+                                            int budget, int &best) {
   int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
   int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
   int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
   double bd = INFINITY;
   int bi = 0x7fffffff;
   bool done = false;
-  for (int r = 0; r <= kRingMax && !done; ++r) {
+#define LRR_SCAN(S, E)                                   \
+  {                                                      \
+    int s_ = (S), e_ = (E);                              \
+    budget -= e_ - s_;                                   \
+    if (budget < 0) return false;                        \
+    scan_range(g, s_, e_, yx, yy, yz, bd, bi);           \
+  }
+  for (int r = 0; r <= ring_max && !done; ++r) {
     int x0 = max(cx - r, 0), x1 = min(cx + r, g.dx - 1);
     int y0 = max(cy - r, 0), y1 = min(cy + r, g.dy - 1);
     int z0 = max(cz - r, 0), z1 = min(cz + r, g.dz - 1);
@@ -312,17 +334,17 @@ __device__ __forceinline__ bool grid_search(const GridView &g, double yx, double
             xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
             xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
           }
-          if (xa <= xb) scan_range(g, g.cell_start[row + xa], g.cell_start[row + xb + 1], yx, yy, yz, bd, bi);
+          if (xa <= xb) LRR_SCAN(g.cell_start[row + xa], g.cell_start[row + xb + 1])
         } else {
           int xc = cx - r;
           if (xc >= 0) {
             double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
-            if (dyz2 + gx_ * gx_ <= bd) scan_range(g, g.cell_start[row + xc], g.cell_start[row + xc + 1], yx, yy, yz, bd, bi);
+            if (dyz2 + gx_ * gx_ <= bd) LRR_SCAN(g.cell_start[row + xc], g.cell_start[row + xc + 1])
           }
           xc = cx + r;
           if (xc <= g.dx - 1) {
             double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
-            if (dyz2 + gx_ * gx_ <= bd) scan_range(g, g.cell_start[row + xc], g.cell_start[row + xc + 1], yx, yy, yz, bd, bi);
+            if (dyz2 + gx_ * gx_ <= bd) LRR_SCAN(g.cell_start[row + xc], g.cell_start[row + xc + 1])
           }
         }
       }
@@ -340,7 +362,106 @@ __device__ __forceinline__ bool grid_search(const GridView &g, double yx, double
       if (lb > 0.0 && bd < lb * lb) done = true;
     }
   }
+#undef LRR_SCAN
   best = (bi == 0x7fffffff) ? 0 : bi;  // 0x7fffffff only with non-finite input
+  return done;
+}
+
+// Phase-1 search specialised for rings 0..1 with ONE round trip for all cell boundaries: the 4
+// cell_start entries around the query's column are fetched for each of the (up to) 9 rows of the
+// 3x3x3 block before anything is scanned, so a row that survives the box pruning costs only its
+// point loads.  Order: own cell, ring-0 stopping test, then the other rows / cells of ring 1.
+// Returns false (-> wave-per-query kernel) when ring 1 does not settle the query or more than
+// `budget` candidates would have to be scanned by this lane.
+__device__ __forceinline__ bool grid_search_easy(const GridView &g, double yx, double yy, double yz, int budget,
+                                                 int &best) {
+  int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
+  int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
+  int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
+  // st[dz+1][dy+1][k] = cell_start[row + clamp(cx - 1 + k)], k = 0..3 (clamped reads stay inside
+  // the row's own [row, row + dx] entries, which always exist)
+  int st[3][3][4];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      int z = cz - 1 + a, y = cy - 1 + b;
+      bool ok = z >= 0 && z < g.dz && y >= 0 && y < g.dy;
+      int row = ok ? (z * g.dy + y) * g.dx : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) st[a][b][k] = ok ? g.cell_start[row + clampi(cx - 1 + k, 0, g.dx)] : 0;
+    }
+  double bd = INFINITY;
+  int bi = 0x7fffffff;
+#define LRR_SCAN(S, E)                                   \
+  {                                                      \
+    int s_ = (S), e_ = (E);                              \
+    budget -= e_ - s_;                                   \
+    if (budget < 0) return false;                        \
+    scan_range(g, s_, e_, yx, yy, yz, bd, bi);           \
+  }
+  // ring 0: the query's own cell = entries k = 1..2 of the centre row
+  LRR_SCAN(st[1][1][1], st[1][1][2])
+  bool done = false;
+  {
+    double lb = INFINITY;
+    if (cx > 0) lb = fmin(lb, yx - (g.lox + cx * g.h));
+    if (cx < g.dx - 1) lb = fmin(lb, (g.lox + (cx + 1) * g.h) - yx);
+    if (cy > 0) lb = fmin(lb, yy - (g.loy + cy * g.h));
+    if (cy < g.dy - 1) lb = fmin(lb, (g.loy + (cy + 1) * g.h) - yy);
+    if (cz > 0) lb = fmin(lb, yz - (g.loz + cz * g.h));
+    if (cz < g.dz - 1) lb = fmin(lb, (g.loz + (cz + 1) * g.h) - yz);
+    if (lb == INFINITY) done = true;
+    else { lb -= g.tol; if (lb > 0.0 && bd < lb * lb) done = true; }
+  }
+  if (!done) {
+    // ring 1
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int z = cz - 1 + a;
+      if (z < 0 || z >= g.dz) continue;
+      double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
+      double dz2 = gz_ * gz_;
+      if (dz2 > bd) continue;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        int y = cy - 1 + b;
+        if (y < 0 || y >= g.dy) continue;
+        double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
+        double dyz2 = dz2 + gy_ * gy_;
+        if (dyz2 > bd) continue;
+        if (a != 1 || b != 1) {  // shell row: the x-run cx-1..cx+1, narrowed by the best distance
+          int xa = max(cx - 1, 0), xb = min(cx + 1, g.dx - 1);
+          if (bd < INFINITY) {
+            double rad = sqrt(bd - dyz2) + 2.0 * g.tol;
+            xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
+            xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
+          }
+          if (xa <= xb) LRR_SCAN(st[a][b][xa - (cx - 1)], st[a][b][xb + 1 - (cx - 1)])
+        } else {  // centre row: the two end cells
+          if (cx - 1 >= 0) {
+            double gx_ = slab_gap(yx, g.lox + (cx - 1) * g.h, g.lox + cx * g.h, g.tol);
+            if (dyz2 + gx_ * gx_ <= bd) LRR_SCAN(st[1][1][0], st[1][1][1])
+          }
+          if (cx + 1 <= g.dx - 1) {
+            double gx_ = slab_gap(yx, g.lox + (cx + 1) * g.h, g.lox + (cx + 2) * g.h, g.tol);
+            if (dyz2 + gx_ * gx_ <= bd) LRR_SCAN(st[1][1][2], st[1][1][3])
+          }
+        }
+      }
+    }
+    double lb = INFINITY;
+    if (cx - 1 > 0) lb = fmin(lb, yx - (g.lox + (cx - 1) * g.h));
+    if (cx + 1 < g.dx - 1) lb = fmin(lb, (g.lox + (cx + 2) * g.h) - yx);
+    if (cy - 1 > 0) lb = fmin(lb, yy - (g.loy + (cy - 1) * g.h));
+    if (cy + 1 < g.dy - 1) lb = fmin(lb, (g.loy + (cy + 2) * g.h) - yy);
+    if (cz - 1 > 0) lb = fmin(lb, yz - (g.loz + (cz - 1) * g.h));
+    if (cz + 1 < g.dz - 1) lb = fmin(lb, (g.loz + (cz + 2) * g.h) - yz);
+    if (lb == INFINITY) done = true;
+    else { lb -= g.tol; if (lb > 0.0 && bd < lb * lb) done = true; }
+  }
+#undef LRR_SCAN
+  best = (bi == 0x7fffffff) ? 0 : bi;
   return done;
 }
 
@@ -357,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, 
   if (m_from) m_from[i] = p;
   if (w_out) w_out[i] = 1.0;
   int bi;
-  if (grid_search(g, yx, yy, yz, bi)) m_to[i] = bi;
+  if (grid_search_easy(g, yx, yy, yz, kEasyBudget, bi)) m_to[i] = bi;
   else {
     m_to[i] = -1;
     overflow[atomicAdd(overflow_count, 1)] = i;
@@ -383,10 +504,128 @@ __global__ __launch_bounds__(kBlock) void k_match_grid_coherent(GridView g, Grid
   m_from[j] = p;
   w_out[j] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
   int bi;
-  if (grid_search(g, yx, yy, yz, bi)) m_to[j] = bi;
+  if (grid_search_easy(g, yx, yy, yz, kEasyBudget, bi)) m_to[j] = bi;
   else {
     m_to[j] = -1;
     overflow[atomicAdd(overflow_count, 1)] = j;
+  }
+}
+
+// K1 phase 2: the queries phase 1 handed over (far from any target feature, or next to cells too
+// dense for one lane).  One WAVEFRONT per query.  For ring r the up to 2(2r+1)^2 cell runs (a
+// whole x-run for shell rows, the two end cells for interior rows) are taken 64 at a time: each
+// lane box-prunes one run and fetches its [start, end) range, a wave prefix sum turns the runs
+// into one candidate list, and the lanes stride over THAT list (binary search in LDS from
+// candidate number to run) — every lane busy whatever the point distribution.  Lanes are merged
+// by a lexicographic (distance, index) shuffle reduction; the stopping rule is grid_search's,
+// so the result is the same exact nearest neighbour.
+__global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QuerySrc qs, XfD xf, const int *hard,
+                                                       const int *hard_count, int *m_to, int *overflow,
+                                                       int *overflow_count) {
+  __shared__ int seg_s[kBlock / 64][64], seg_pre[kBlock / 64][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  const int cnt = *hard_count;
+  for (int o = wave; o < cnt; o += nwaves) {
+    int i = hard[o];
+    int p = query_index(qs, i);
+    const double *pr = qs.rec + (size_t)p * qs.stride;
+    double yx, yy, yz;
+    map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
+    int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
+    int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
+    int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
+    double bd = INFINITY;   // wave-uniform best so far
+    int bi = 0x7fffffff;
+    bool done = false;
+    for (int r = 0; r <= kRingMax && !done; ++r) {
+      const int side = 2 * r + 1, nitems = 2 * side * side;
+      for (int base = 0; base < nitems; base += 64) {
+        // one cell run per lane
+        int t = base + lane, s0 = 0, e0 = 0;
+        if (t < nitems) {
+          int rowi = t >> 1, which = t & 1;
+          int z = cz - r + rowi / side, y = cy - r + rowi % side;
+          if (z >= 0 && z < g.dz && y >= 0 && y < g.dy) {
+            double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
+            double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
+            double dyz2 = gz_ * gz_ + gy_ * gy_;
+            if (dyz2 <= bd) {
+              int row = (z * g.dy + y) * g.dx;
+              bool shell = (z - cz == r) || (cz - z == r) || (y - cy == r) || (cy - y == r);
+              if (shell) {
+                if (which == 0) {
+                  int xa = max(cx - r, 0), xb = min(cx + r, g.dx - 1);
+                  if (bd < INFINITY) {
+                    double rad = sqrt(bd - dyz2) + 2.0 * g.tol;
+                    xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
+                    xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
+                  }
+                  if (xa <= xb) { s0 = g.cell_start[row + xa]; e0 = g.cell_start[row + xb + 1]; }
+                }
+              } else if (r > 0) {
+                int xc = which == 0 ? cx - r : cx + r;
+                if (xc >= 0 && xc <= g.dx - 1) {
+                  double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
+                  if (dyz2 + gx_ * gx_ <= bd) { s0 = g.cell_start[row + xc]; e0 = g.cell_start[row + xc + 1]; }
+                }
+              }
+            }
+          }
+        }
+        int c0 = e0 - s0, incl = c0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          int v = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += v;
+        }
+        int total = __shfl(incl, 63, 64);
+        if (total > 0) {
+          seg_s[wv][lane] = s0;
+          seg_pre[wv][lane] = incl - c0;
+          __builtin_amdgcn_wave_barrier();
+          double ld = INFINITY;  // this lane's best in the chunk
+          int li = 0x7fffffff;
+          for (int c = lane; c < total; c += 64) {
+            int lo = 0, hi = 64;  // last run whose exclusive prefix is <= c
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+              int mid = (lo + hi) >> 1;
+              if (seg_pre[wv][mid] <= c) lo = mid; else hi = mid;
+            }
+            GridPoint pt = g.gp[seg_s[wv][lo] + (c - seg_pre[wv][lo])];
+            double d = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
+            int oi = (int)pt.idx;
+            if (d < ld || (d == ld && oi < li)) { ld = d; li = oi; }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // merge the lanes with the running best: smallest distance, ties to the lowest index
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            double d2 = __shfl_xor(ld, off, 64);
+            int i2 = __shfl_xor(li, off, 64);
+            if (d2 < ld || (d2 == ld && i2 < li)) { ld = d2; li = i2; }
+          }
+          if (ld < bd || (ld == bd && li < bi)) { bd = ld; bi = li; }
+        }
+      }
+      double lb = INFINITY;
+      if (cx - r > 0) lb = fmin(lb, yx - (g.lox + (cx - r) * g.h));
+      if (cx + r < g.dx - 1) lb = fmin(lb, (g.lox + (cx + r + 1) * g.h) - yx);
+      if (cy - r > 0) lb = fmin(lb, yy - (g.loy + (cy - r) * g.h));
+      if (cy + r < g.dy - 1) lb = fmin(lb, (g.loy + (cy + r + 1) * g.h) - yy);
+      if (cz - r > 0) lb = fmin(lb, yz - (g.loz + (cz - r) * g.h));
+      if (cz + r < g.dz - 1) lb = fmin(lb, (g.loz + (cz + r + 1) * g.h) - yz);
+      if (lb == INFINITY) done = true;
+      else {
+        lb -= g.tol;
+        if (lb > 0.0 && bd < lb * lb) done = true;
+      }
+    }
+    if (lane == 0) {
+      if (done) m_to[i] = (bi == 0x7fffffff) ? 0 : bi;
+      else overflow[atomicAdd(overflow_count, 1)] = i;
+    }
   }
 }
 
@@ -1376,20 +1615,28 @@ int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const lrr_icp_cloud *from_
   } else {
     if ((size_t)n > ctx->overflow_cap) {
       if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+      if (ctx->d_hard) (void)hipFree(ctx->d_hard);
       ctx->overflow_cap = 0;
       HIPCHK(ctx, hipMalloc(&ctx->d_overflow, sizeof(int) * (size_t)n));
+      HIPCHK(ctx, hipMalloc(&ctx->d_hard, sizeof(int) * (size_t)n));
       ctx->overflow_cap = (size_t)n;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow_count, 0, sizeof(int), ctx->stream));
+    int *hard_count = ctx->d_overflow_count, *over_count = ctx->d_overflow_count + 1;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow_count, 0, 2 * sizeof(int), ctx->stream));
+    // phase 1: rings 0..kRingEasy, one thread per query; unsettled queries -> hard list
     if (from_cloud && qs.use_keys && !qs.order && m_from && w_out && (int64_t)n * 4 >= from_cloud->n) {
       GridView gf = view_of(from_cloud);
-      hipLaunchKernelGGL(k_match_grid_coherent, dim3(blocks_for(from_cloud->n)), dim3(kBlock), 0, ctx->stream, g, gf, qs.keys, qs.half, n, xf, m_from, m_to, w_out, ctx->d_overflow, ctx->d_overflow_count);
+      hipLaunchKernelGGL(k_match_grid_coherent, dim3(blocks_for(from_cloud->n)), dim3(kBlock), 0, ctx->stream, g, gf, qs.keys, qs.half, n, xf, m_from, m_to, w_out, ctx->d_hard, hard_count);
     } else {
-      hipLaunchKernelGGL(k_match_grid, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, m_from, m_to, w_out, ctx->d_overflow, ctx->d_overflow_count);
+      hipLaunchKernelGGL(k_match_grid, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, m_from, m_to, w_out, ctx->d_hard, hard_count);
     }
     HIPCHK(ctx, hipGetLastError());
-    // exits immediately when the overflow list is empty; every block reaches its loop bound
-    hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, ctx->stream, g, qs, xf, ctx->d_overflow, ctx->d_overflow_count, m_to);
+    // phase 2: one wavefront per hard query; phase 3: brute force for what is still open.
+    // Both read their list length on the device and fall through when it is 0.
+    int hard_blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)n + 3) / 4));
+    hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, ctx->stream, g, qs, xf, ctx->d_hard, hard_count, m_to, ctx->d_overflow, over_count);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, ctx->stream, g, qs, xf, ctx->d_overflow, over_count, m_to);
     HIPCHK(ctx, hipGetLastError());
   }
   if (prof) {
@@ -1438,7 +1685,7 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
-  if ((e = hipMalloc(&ctx->d_overflow_count, sizeof(int))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_overflow_count, 2 * sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selstate, sizeof(SelState) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selhist, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
@@ -1462,6 +1709,7 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->d_bd) (void)hipFree(ctx->d_bd);
   if (ctx->d_bi) (void)hipFree(ctx->d_bi);
   if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+  if (ctx->d_hard) (void)hipFree(ctx->d_hard);
   if (ctx->d_overflow_count) (void)hipFree(ctx->d_overflow_count);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
   if (ctx->d_fused) (void)hipFree(ctx->d_fused);
