@@ -65,6 +65,20 @@ def cpu_baseline(pair, T0, n, iters):
                       f"(C oracle, kd-tree NN, {dt:.1f} s)"}
 
 
+def pmc_traffic(args):
+    """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the
+    gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is).  Counters cannot be collected from inside
+    this process; the value is the one measured on this code at the BASELINE size with the grid
+    matcher (profiles/pmc_traffic.json), null for any other configuration."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if args.nn != "grid" or args.n != N_FEATURES or not os.path.exists(path):
+        return None
+    try:
+        return float(json.load(open(path))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -155,9 +169,11 @@ def main():
                                    f"{n_pairs_step} matched pairs per step per GPU",
                        "nn": args.nn, "schedule_iterations_before_timing": schedule_iters,
                        "parallelism": f"{world} independent problem(s), one per GPU; one all_gather of the final transforms"},
-            "roofline": {"bound": "hbm", "kernel": "k_match_grid" if args.nn == "grid" else "k_match_brute",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("K1 find_closest_euclidean = k_match_grid_coherent + k_match_hard + k_match_overflow"
+                                    if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
                          "kernel_ms": k1_ms, "launches": match_launches,
                          "algorithmic_bytes_per_launch": k1_bytes,
                          "iteration_achieved_GBs": value / world * ITER_BYTES_PER_PAIR / 1e9,

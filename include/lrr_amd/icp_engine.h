@@ -34,6 +34,9 @@
 #include "lrr_icp.h"
 
 // ---- abstract interface (cdcl/cdcl_estimation_abs.h:20-65) -----------------------------------
+#ifdef LRR_AMD_USE_REFERENCE_TYPES
+#include "cdcl_estimation_abs.h"
+#else
 template <unsigned int dim, unsigned int dof, class feature_typeT = cdcl_feature<dim> >
 class cdcl_estimation_abs : public vbl_ref_count {
  public:
@@ -52,6 +55,7 @@ class cdcl_estimation_abs : public vbl_ref_count {
   virtual void initialize() = 0;
   virtual bool run(void *caller = 0, display_callback_type display_points = 0) = 0;
 };
+#endif
 
 namespace lrr_amd {
 
