@@ -1,10 +1,12 @@
 // lrr_icp.hip — hand-written HIP kernels (gfx950 / CDNA4) + the C-ABI of include/lrr_icp.h.
 //
 // The per-iteration hot path of LRR's robust ICP:
-//   K1  map moving features + exact nearest fixed feature      (k_match_grid / k_match_brute)
-//   K2  projected residuals, robust scale, Beaton-Tukey weights (k_residual, k_select, k_assign)
-//   K5  normalisation statistics                                (k_from_sum, k_to_sum, ...)
-//   K3  weighted normal equations J^T P J, J^T P b              (k_accumulate)
+//   K1  map moving features + exact nearest fixed feature      (k_match_tile / k_match_direct /
+//                                                               k_match_hard / k_match_overflow /
+//                                                               k_match_brute)
+//   K2  projected residuals, robust scale, Beaton-Tukey weights (k_f_residual, k_sel_*, k_f_weights)
+//   K5  normalisation statistics                                (k_to_sum, k_f_radii)
+//   K3  weighted normal equations J^T P J, J^T P b              (k_f_accumulate)
 //   K4  error metrics                                           (k_errors)
 // Everything is fp64: the reference is double throughout (cdcl/cdcl_feature.h:21) and "match
 // sets exactly" is a parity requirement.  This is distance search + small reductions: no MFMA.
@@ -12,6 +14,15 @@
 // the CPU restatement used as checker; the only fused operations are the explicit fma() calls
 // of dist2().  Reductions are two-stage with a fixed block->partial->final order, so results
 // are run-to-run deterministic (no floating-point atomics anywhere).
+//
+// Device-internal order.  A cloud is stored in CANONICAL order: features sorted by 8x8x8-cell
+// tile of the search grid, then by cell.  Per-match arrays of a direction are indexed by the
+// canonical position s of the match's from-feature (so every pass streams them coalesced and
+// gathers target records of neighbouring s from neighbouring memory); the target of a match is
+// kept as a canonical target index.  The reference's match-list order exists only as slot[s]
+// (list position of source s, -1 = not in the active subset) and is applied when matches are
+// handed back to the host.  Sums are order-independent up to rounding, so this changes nothing
+// observable beyond the last bits.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -35,19 +46,27 @@ constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kMaxBlocks = 512;      // reduction grids: 2 blocks / CU on 256 CUs
 constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 for dof 12)
 constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
-constexpr int kScanUnroll = 8;       // candidate loads in flight per lane in the grid search
-constexpr int kEasyBudget = 48;      // candidate points a lane may scan in the thread-per-query phase
-constexpr int kRingEasy = 1;         // rings walked by the thread-per-query phase of the grid search
+constexpr int kTile = 8;             // canonical order: tiles of kTile^3 grid cells
+constexpr int kScanUnroll = 8;       // candidate loads in flight per lane in the global-memory grid search
+constexpr int kEasyBudget = 48;      // candidate points a lane may scan in the thread-per-query global search
 constexpr int kRingMax = 8;          // rings walked by the wave-per-query phase before the brute-force fallback
+constexpr int kTileCap = 2048;       // target points a block may stage in LDS (64 KB) ...
+constexpr int kTileRows = 256;       // ... spread over at most this many (z,y) rows of the target grid
+constexpr int kTileNx = 20;          // ... of at most this many cells each
 constexpr int kSelThreads = 1024;
 constexpr int kMaxSelJobs = 32;
 constexpr int kProfEvents = 4096;
+constexpr int kSelHistBlocks = 64;   // blocks per job and pass of the multi-block radix select
 // fused scratch: P1 (2*512 x 5), P2 (512 x 4), P3 (512 x 2), P4 (2*512 x 1), P6 (2*512 x 96), output block
 constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * 512 * 5, kFusedP3 = kFusedP2 + 512 * 4,
               kFusedP4 = kFusedP3 + 512 * 2, kFusedP6 = kFusedP4 + 2 * 512, kFusedOut = kFusedP6 + 2 * 512 * 96,
               kFusedDoubles = kFusedOut + 256;
 
-struct GridPoint { double x, y, z; long long idx; };  // 32 B: one candidate = two 16-B loads
+// one candidate of the search grid: 32 B = two 16-B loads
+struct GridPoint { double x, y, z; int canon, orig; };
+// one source feature in canonical order
+struct SrcPoint { double x, y, z; long long orig; };
+struct Chunk { int start, count; };  // <= kBlock consecutive canonical features of ONE tile
 struct SelState { unsigned long long prefix, mask; long long k, m; };  // radix-select progress of one job
 
 struct SelJob {
@@ -76,9 +95,10 @@ struct lrr_icp_ctx {
   int *d_selhist = nullptr;      // kMaxSelJobs x 2048
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
   double *h_fused = nullptr;
-  // brute-force partial argmin scratch
-  double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;
-  int *d_overflow = nullptr, *d_hard = nullptr; size_t overflow_cap = 0; int *d_overflow_count = nullptr;  // [0] hard, [1] overflow
+  // K1 scratch
+  double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;   // brute-force partial argmin
+  int *d_hard = nullptr, *d_overflow = nullptr, *d_active = nullptr; size_t list_cap = 0;
+  int *d_counts = nullptr;       // [0] hard, [1] overflow, [2] active
   int *d_order = nullptr; size_t order_cap = 0;
   // match-kernel profile (event pairs resolved lazily)
   bool prof = false;
@@ -92,9 +112,13 @@ struct lrr_icp_cloud {
   lrr_icp_ctx *ctx = nullptr;
   int64_t n = 0;
   int float_strength = 0;
-  double *rec = nullptr;                       // n x 10, original order (gather target)
-  GridPoint *gp = nullptr;                     // points sorted by grid cell (+ original index)
-  int *cell_start = nullptr;                   // ncell + 1
+  double *rec = nullptr;        // n x 10, canonical order
+  SrcPoint *src = nullptr;      // n, canonical order (K1 source reads)
+  int *orig_of = nullptr;       // canonical -> original index
+  int *canon_of = nullptr;      // original -> canonical index
+  GridPoint *gp = nullptr;      // n, sorted by grid cell (raster z,y,x): the search structure
+  int *cell_start = nullptr;    // ncell + 1
+  Chunk *chunks = nullptr; int nchunks = 0;
   double lo[3] = {0, 0, 0}, h = 1.0, inv_h = 1.0, tol = 0.0;
   int dim[3] = {1, 1, 1};
 };
@@ -102,10 +126,12 @@ struct lrr_icp_cloud {
 struct lrr_icp_dir {
   lrr_icp_ctx *ctx = nullptr;
   lrr_icp_cloud *from = nullptr, *to = nullptr;
-  int64_t cap = 0, n = 0;
-  int *m_from = nullptr, *m_to = nullptr;
+  int64_t cap = 0;   // allocated length of the per-source arrays (>= from->n)
+  int64_t n = 0;     // active matches
+  int *slot = nullptr;   // list position of source s, -1 when s is not in the active subset
+  int *m_to = nullptr;   // canonical target index
   double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
-  double *from_loc = nullptr;  // 3 per match: pre-mapped copies
+  double *from_loc = nullptr;  // 3 per source: pre-mapped copies
   int from_is_copy = 0;
   unsigned *flag = nullptr; int64_t flag_cap = 0;
 };
@@ -189,6 +215,23 @@ __device__ __forceinline__ int subset_perm(int i, int n, int half, const Keys &k
   return (int)x;
 }
 
+__device__ __forceinline__ int subset_perm_inv(int p, int n, int half, const Keys &keys) {
+  unsigned mask = (1u << half) - 1u;
+  unsigned long long x = (unsigned)p;
+  do {
+    unsigned L = (unsigned)(x >> half), R = (unsigned)(x & mask);
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+      unsigned pR = L;
+      unsigned pL = R ^ (fmix32(L ^ keys.k[r]) & mask);
+      L = pL;
+      R = pR;
+    }
+    x = ((unsigned long long)L << half) | R;
+  } while (x >= (unsigned long long)n);
+  return (int)x;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -215,6 +258,21 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *parti
   }
 }
 
+// sum of column k over rows [r0, r1) of a row-major partials table; same value in every thread
+__device__ __forceinline__ double block_total(const double *P, int r0, int r1, int K, int k) {
+  __shared__ double sh[kBlock / 64];
+  double s = 0.0;
+  for (int b = r0 + (int)threadIdx.x; b < r1; b += kBlock) s += P[(size_t)b * K + k];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  double tot = sh[0];
+#pragma unroll
+  for (int w2 = 1; w2 < kBlock / 64; ++w2) tot += sh[w2];
+  __syncthreads();
+  return tot;
+}
+
 // one wavefront per output value: lane l sums blocks l, l+64, ... in order, then the fixed
 // shuffle tree — deterministic for a given (nblocks, K)
 __global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, int nblocks, int K, double *out) {
@@ -225,62 +283,7 @@ __global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, 
   if (threadIdx.x == 0) out[k] = s;
 }
 
-// ---------------------------------------------------------------------------------------------
-// K1: exact nearest neighbour
-// ---------------------------------------------------------------------------------------------
-struct QuerySrc {
-  const double *rec;   // query records
-  int stride;          // doubles per record (10 for a cloud, 3 for raw points)
-  const int *order;    // explicit permutation or nullptr
-  int use_keys;        // keyed permutation when order == nullptr
-  int nsrc;            // size of the source set (domain of the permutation)
-  int half;
-  Keys keys;
-};
-
-__device__ __forceinline__ int query_index(const QuerySrc &q, int i) {
-  if (q.order) return q.order[i];
-  if (q.use_keys) return subset_perm(i, q.nsrc, q.half, q.keys);
-  return i;
-}
-
-__device__ __forceinline__ void scan_range(const GridView &g, int s, int e, double yx, double yy,
-                                           double yz, double &bd, int &bi) {
-  // kScanUnroll candidates are loaded before any is compared: the loads are independent, so a lane
-  // keeps that many 32-B requests in flight instead of paying one L2 round trip per point
-  for (int j = s; j < e; j += kScanUnroll) {
-    GridPoint pt[kScanUnroll];
-#pragma unroll
-    for (int u = 0; u < kScanUnroll; ++u) pt[u] = g.gp[min(j + u, e - 1)];
-#pragma unroll
-    for (int u = 0; u < kScanUnroll; ++u) {
-      if (j + u < e) {
-        double d = dist2(yx, yy, yz, pt[u].x, pt[u].y, pt[u].z);
-        int oi = (int)pt[u].idx;
-        if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
-      }
-    }
-  }
-}
-
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-__device__ __forceinline__ int subset_perm_inv(int p, int n, int half, const Keys &keys) {
-  unsigned mask = (1u << half) - 1u;
-  unsigned long long x = (unsigned)p;
-  do {
-    unsigned L = (unsigned)(x >> half), R = (unsigned)(x & mask);
-#pragma unroll
-    for (int r = 3; r >= 0; --r) {
-      unsigned pR = L;
-      unsigned pL = R ^ (fmix32(L ^ keys.k[r]) & mask);
-      L = pL;
-      R = pR;
-    }
-    x = ((unsigned long long)L << half) | R;
-  } while (x >= (unsigned long long)n);
-  return (int)x;
-}
 
 // distance from coordinate v to the slab [lo, hi] widened by tol (cells own their points up to
 // rounding: tol covers the difference between floor((x-lo)/h) and the exact cell walls)
@@ -290,96 +293,79 @@ __device__ __forceinline__ double slab_gap(double v, double lo, double hi, doubl
   return g > 0.0 ? g : 0.0;
 }
 
-// Exact nearest neighbour by ring search over the uniform grid.  Ring r = the cells at Chebyshev
-// distance r from the query's cell.  Inside a ring a row / cell is skipped when its box is
-// farther than the best distance so far (strictly: an equally distant point with a lower index
-// must still be seen); after ring r every unvisited point lies beyond an interior face of the
-// (2r+1)^3 block, so the search stops once best < (distance to the nearest such face - tol)^2.
-// Returns false when the query is not settled inside rings 0..ring_max or would need more than
-// `budget` candidate points: such queries go to the wave-per-query kernel, so no lane of this
-// kernel ever walks a long serial chain (kernel time = slowest lane).
-__device__ __forceinline__ bool grid_search(const GridView &g, double yx, double yy, double yz, int ring_max,
-                                            int budget, int &best) {
-  int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
-  int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
-  int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
-  double bd = INFINITY;
-  int bi = 0x7fffffff;
-  bool done = false;
-#define LRR_SCAN(S, E)                                   \
-  {                                                      \
-    int s_ = (S), e_ = (E);                              \
-    budget -= e_ - s_;                                   \
-    if (budget < 0) return false;                        \
-    scan_range(g, s_, e_, yx, yy, yz, bd, bi);           \
-  }
-  for (int r = 0; r <= ring_max && !done; ++r) {
-    int x0 = max(cx - r, 0), x1 = min(cx + r, g.dx - 1);
-    int y0 = max(cy - r, 0), y1 = min(cy + r, g.dy - 1);
-    int z0 = max(cz - r, 0), z1 = min(cz + r, g.dz - 1);
-    for (int z = z0; z <= z1; ++z) {
-      double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
-      double dz2 = gz_ * gz_;
-      if (dz2 > bd) continue;
-      for (int y = y0; y <= y1; ++y) {
-        double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
-        double dyz2 = dz2 + gy_ * gy_;
-        if (dyz2 > bd) continue;
-        int row = (z * g.dy + y) * g.dx;
-        bool shell = (z - cz == r) || (cz - z == r) || (y - cy == r) || (cy - y == r);
-        if (shell) {
-          int xa = x0, xb = x1;
-          if (bd < INFINITY) {  // only the cells whose x-slab meets [yx - rad, yx + rad]
-            double rad = sqrt(bd - dyz2) + 2.0 * g.tol;
-            xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
-            xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
-          }
-          if (xa <= xb) LRR_SCAN(g.cell_start[row + xa], g.cell_start[row + xb + 1])
-        } else {
-          int xc = cx - r;
-          if (xc >= 0) {
-            double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
-            if (dyz2 + gx_ * gx_ <= bd) LRR_SCAN(g.cell_start[row + xc], g.cell_start[row + xc + 1])
-          }
-          xc = cx + r;
-          if (xc <= g.dx - 1) {
-            double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
-            if (dyz2 + gx_ * gx_ <= bd) LRR_SCAN(g.cell_start[row + xc], g.cell_start[row + xc + 1])
-          }
-        }
-      }
-    }
-    double lb = INFINITY;
-    if (cx - r > 0) lb = fmin(lb, yx - (g.lox + (cx - r) * g.h));
-    if (cx + r < g.dx - 1) lb = fmin(lb, (g.lox + (cx + r + 1) * g.h) - yx);
-    if (cy - r > 0) lb = fmin(lb, yy - (g.loy + (cy - r) * g.h));
-    if (cy + r < g.dy - 1) lb = fmin(lb, (g.loy + (cy + r + 1) * g.h) - yy);
-    if (cz - r > 0) lb = fmin(lb, yz - (g.loz + (cz - r) * g.h));
-    if (cz + r < g.dz - 1) lb = fmin(lb, (g.loz + (cz + r + 1) * g.h) - yz);
-    if (lb == INFINITY) done = true;  // the block covers the whole grid
-    else {
-      lb -= g.tol;
-      if (lb > 0.0 && bd < lb * lb) done = true;
-    }
-  }
-#undef LRR_SCAN
-  best = (bi == 0x7fffffff) ? 0 : bi;  // 0x7fffffff only with non-finite input
-  return done;
+// best candidate so far: squared distance, original index (tie-break: a linear scan in index
+// order returns the lowest index among equally distant points), canonical index (the result)
+struct Best { double d; int orig, canon; };
+__device__ __forceinline__ void consider(Best &b, double d, int orig, int canon) {
+  if (d < b.d || (d == b.d && orig < b.orig)) { b.d = d; b.orig = orig; b.canon = canon; }
 }
 
-// Phase-1 search specialised for rings 0..1 with ONE round trip for all cell boundaries: the 4
-// cell_start entries around the query's column are fetched for each of the (up to) 9 rows of the
-// 3x3x3 block before anything is scanned, so a row that survives the box pruning costs only its
-// point loads.  Order: own cell, ring-0 stopping test, then the other rows / cells of ring 1.
-// Returns false (-> wave-per-query kernel) when ring 1 does not settle the query or more than
-// `budget` candidates would have to be scanned by this lane.
+// stopping bound of the ring search: distance from the query to the nearest INTERIOR face of the
+// (2r+1)^3 block around its cell (faces on the grid boundary have nothing behind them)
+__device__ __forceinline__ double ring_bound(const GridView &g, int cx, int cy, int cz, int r, double yx,
+                                             double yy, double yz) {
+  double lb = INFINITY;
+  if (cx - r > 0) lb = fmin(lb, yx - (g.lox + (cx - r) * g.h));
+  if (cx + r < g.dx - 1) lb = fmin(lb, (g.lox + (cx + r + 1) * g.h) - yx);
+  if (cy - r > 0) lb = fmin(lb, yy - (g.loy + (cy - r) * g.h));
+  if (cy + r < g.dy - 1) lb = fmin(lb, (g.loy + (cy + r + 1) * g.h) - yy);
+  if (cz - r > 0) lb = fmin(lb, yz - (g.loz + (cz - r) * g.h));
+  if (cz + r < g.dz - 1) lb = fmin(lb, (g.loz + (cz + r + 1) * g.h) - yz);
+  return lb;
+}
+// true when no unvisited point can beat (or tie with a lower index) the best so far
+__device__ __forceinline__ bool ring_settled(double lb, double tol, double bd) {
+  if (lb == INFINITY) return true;  // the block covers the whole grid
+  lb -= tol;
+  return lb > 0.0 && bd < lb * lb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: exact nearest neighbour
+// ---------------------------------------------------------------------------------------------
+// where the queries of a K1 launch come from: the canonical source array of a cloud (results are
+// canonical target indices, written at the source's canonical position) or raw host points
+// (stand-alone queries: results are ORIGINAL target indices)
+struct QSrc {
+  const SrcPoint *src;
+  const double *raw;   // xyz triples when src == nullptr
+  int want_orig;
+};
+__device__ __forceinline__ void query_point(const QSrc &q, int s, double &x, double &y, double &z) {
+  if (q.src) { SrcPoint p = q.src[s]; x = p.x; y = p.y; z = p.z; }
+  else { x = q.raw[3 * (size_t)s]; y = q.raw[3 * (size_t)s + 1]; z = q.raw[3 * (size_t)s + 2]; }
+}
+__device__ __forceinline__ int result_index(const QSrc &q, const Best &b) {
+  if (b.orig == 0x7fffffff) return 0;  // only reachable with non-finite input
+  return q.want_orig ? b.orig : b.canon;
+}
+
+// candidates [s, e) of the global search structure; kScanUnroll loads are issued before any is
+// compared, so a lane keeps that many 32-B requests in flight
+__device__ __forceinline__ void scan_range(const GridView &g, int s, int e, double yx, double yy,
+                                           double yz, Best &b) {
+  for (int j = s; j < e; j += kScanUnroll) {
+    GridPoint pt[kScanUnroll];
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u) pt[u] = g.gp[min(j + u, e - 1)];
+#pragma unroll
+    for (int u = 0; u < kScanUnroll; ++u)
+      if (j + u < e) consider(b, dist2(yx, yy, yz, pt[u].x, pt[u].y, pt[u].z), pt[u].orig, pt[u].canon);
+  }
+}
+
+// Thread-per-query search in GLOBAL memory, rings 0..1 (used when the active subset is sparse:
+// coarse levels, explicit orders, stand-alone queries).  The 4 cell_start entries around the
+// query's column are fetched for each of the 9 rows of the 3x3x3 block in one round trip; a row
+// or cell whose box is farther than the best so far is skipped (strictly farther: an equally
+// distant point with a lower index must still be seen).  Returns false (-> wave-per-query
+// kernel) when ring 1 does not settle the query or more than `budget` candidates would have to
+// be scanned by this lane (kernel time = slowest lane).
 __device__ __forceinline__ bool grid_search_easy(const GridView &g, double yx, double yy, double yz, int budget,
-                                                 int &best) {
+                                                 Best &best) {
   int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
   int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
   int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
-  // st[dz+1][dy+1][k] = cell_start[row + clamp(cx - 1 + k)], k = 0..3 (clamped reads stay inside
-  // the row's own [row, row + dx] entries, which always exist)
   int st[3][3][4];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -391,135 +377,278 @@ __device__ __forceinline__ bool grid_search_easy(const GridView &g, double yx, d
 #pragma unroll
       for (int k = 0; k < 4; ++k) st[a][b][k] = ok ? g.cell_start[row + clampi(cx - 1 + k, 0, g.dx)] : 0;
     }
-  double bd = INFINITY;
-  int bi = 0x7fffffff;
+  best.d = INFINITY; best.orig = 0x7fffffff; best.canon = 0;
 #define LRR_SCAN(S, E)                                   \
   {                                                      \
     int s_ = (S), e_ = (E);                              \
     budget -= e_ - s_;                                   \
     if (budget < 0) return false;                        \
-    scan_range(g, s_, e_, yx, yy, yz, bd, bi);           \
+    scan_range(g, s_, e_, yx, yy, yz, best);             \
   }
-  // ring 0: the query's own cell = entries k = 1..2 of the centre row
-  LRR_SCAN(st[1][1][1], st[1][1][2])
-  bool done = false;
-  {
-    double lb = INFINITY;
-    if (cx > 0) lb = fmin(lb, yx - (g.lox + cx * g.h));
-    if (cx < g.dx - 1) lb = fmin(lb, (g.lox + (cx + 1) * g.h) - yx);
-    if (cy > 0) lb = fmin(lb, yy - (g.loy + cy * g.h));
-    if (cy < g.dy - 1) lb = fmin(lb, (g.loy + (cy + 1) * g.h) - yy);
-    if (cz > 0) lb = fmin(lb, yz - (g.loz + cz * g.h));
-    if (cz < g.dz - 1) lb = fmin(lb, (g.loz + (cz + 1) * g.h) - yz);
-    if (lb == INFINITY) done = true;
-    else { lb -= g.tol; if (lb > 0.0 && bd < lb * lb) done = true; }
-  }
-  if (!done) {
-    // ring 1
+  LRR_SCAN(st[1][1][1], st[1][1][2])  // ring 0: the query's own cell
+  if (ring_settled(ring_bound(g, cx, cy, cz, 0, yx, yy, yz), g.tol, best.d)) return true;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      int z = cz - 1 + a;
-      if (z < 0 || z >= g.dz) continue;
+  for (int a = 0; a < 3; ++a) {
+    int z = cz - 1 + a;
+    if (z < 0 || z >= g.dz) continue;
+    double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
+    double dz2 = gz_ * gz_;
+    if (dz2 > best.d) continue;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      int y = cy - 1 + b;
+      if (y < 0 || y >= g.dy) continue;
+      double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
+      double dyz2 = dz2 + gy_ * gy_;
+      if (dyz2 > best.d) continue;
+      if (a != 1 || b != 1) {  // shell row: the x-run cx-1..cx+1, narrowed by the best distance
+        int xa = max(cx - 1, 0), xb = min(cx + 1, g.dx - 1);
+        if (best.d < INFINITY) {
+          double rad = sqrt(best.d - dyz2) + 2.0 * g.tol;
+          xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
+          xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
+        }
+        if (xa <= xb) LRR_SCAN(st[a][b][xa - (cx - 1)], st[a][b][xb + 1 - (cx - 1)])
+      } else {  // centre row: the two end cells
+        if (cx - 1 >= 0) {
+          double gx_ = slab_gap(yx, g.lox + (cx - 1) * g.h, g.lox + cx * g.h, g.tol);
+          if (dyz2 + gx_ * gx_ <= best.d) LRR_SCAN(st[1][1][0], st[1][1][1])
+        }
+        if (cx + 1 <= g.dx - 1) {
+          double gx_ = slab_gap(yx, g.lox + (cx + 1) * g.h, g.lox + (cx + 2) * g.h, g.tol);
+          if (dyz2 + gx_ * gx_ <= best.d) LRR_SCAN(st[1][1][2], st[1][1][3])
+        }
+      }
+    }
+  }
+#undef LRR_SCAN
+  return ring_settled(ring_bound(g, cx, cy, cz, 1, yx, yy, yz), g.tol, best.d);
+}
+
+// K1, sparse form: one thread per match-list slot i (explicit order, keyed permutation of a coarse
+// level, or a raw query point)
+__global__ __launch_bounds__(kBlock) void k_match_direct(GridView g, QSrc q, const int *order, int use_keys,
+                                                         Keys keys, int half, int nsrc, const int *canon_of,
+                                                         XfD xf, int n, int *slot, int *m_to, double *w,
+                                                         int *hard, int *hard_count) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int s = i;
+  if (q.src) {
+    int p = order ? order[i] : (use_keys ? subset_perm(i, nsrc, half, keys) : i);
+    s = canon_of[p];
+    slot[s] = i;
+    w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+  }
+  double x, y, z, yx, yy, yz;
+  query_point(q, s, x, y, z);
+  map_loc(xf, x, y, z, yx, yy, yz);
+  Best b;
+  if (grid_search_easy(g, yx, yy, yz, kEasyBudget, b)) m_to[s] = result_index(q, b);
+  else {
+    m_to[s] = -1;
+    hard[atomicAdd(hard_count, 1)] = s;
+  }
+}
+
+// K1, dense form (fine levels): one block per chunk of <= 256 consecutive canonical source
+// features, all from one 8x8x8-cell tile of the SOURCE grid, so their mapped positions fall into
+// a small box of the TARGET grid.  The block stages that box (+1 cell all round) in LDS with
+// coalesced row-run copies, then every lane searches rings 0..1 from LDS: the divergent,
+// dependent accesses of the ring search cost LDS latency instead of a memory round trip each.
+// slot[s] = perm^-1(original index) keeps the match LIST identical to the direct form.
+// Blocks whose box does not fit (degenerate transforms) and queries ring 1 does not settle go to
+// the wave-per-query kernel.
+__global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoint *src, const Chunk *chunks,
+                                                       Keys keys, int half, int nsrc, int n_points, XfD xf,
+                                                       int *slot, int *m_to, double *w, int *hard,
+                                                       int *hard_count) {
+  __shared__ double px[kTileCap], py[kTileCap], pz[kTileCap];
+  __shared__ int pcan[kTileCap], porig[kTileCap];
+  __shared__ int row_goff[kTileRows], row_loff[kTileRows + 1];
+  __shared__ unsigned short cso[kTileRows][kTileNx + 1];
+  __shared__ int box[6], wave_tot[kBlock / 64];
+  const Chunk ck = chunks[blockIdx.x];
+  const int t = threadIdx.x, s = ck.start + t;
+  bool active = false;
+  double yx = 0, yy = 0, yz = 0;
+  int cx = 0, cy = 0, cz = 0;
+  if (t == 0) { box[0] = box[2] = box[4] = 0x7fffffff; box[1] = box[3] = box[5] = -1; }
+  __syncthreads();
+  if (t < ck.count) {
+    SrcPoint sp = src[s];
+    int j = subset_perm_inv((int)sp.orig, nsrc, half, keys);
+    active = j < n_points;
+    slot[s] = active ? j : -1;
+    if (active) {
+      w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+      map_loc(xf, sp.x, sp.y, sp.z, yx, yy, yz);
+      cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
+      cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
+      cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
+    }
+  }
+  {  // bounding box of the active queries' cells: wave min/max by shuffles, one LDS atomic per wave
+    int lo3[3] = {active ? cx : 0x7fffffff, active ? cy : 0x7fffffff, active ? cz : 0x7fffffff};
+    int hi3[3] = {active ? cx : -1, active ? cy : -1, active ? cz : -1};
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        lo3[k] = min(lo3[k], __shfl_xor(lo3[k], off, 64));
+        hi3[k] = max(hi3[k], __shfl_xor(hi3[k], off, 64));
+      }
+    if ((t & 63) == 0)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { atomicMin(&box[2 * k], lo3[k]); atomicMax(&box[2 * k + 1], hi3[k]); }
+  }
+  __syncthreads();
+  if (box[1] < 0) return;  // no active query in this chunk (uniform)
+  const int x0 = max(box[0] - 1, 0), x1 = min(box[1] + 1, g.dx - 1);
+  const int y0 = max(box[2] - 1, 0), y1 = min(box[3] + 1, g.dy - 1);
+  const int z0 = max(box[4] - 1, 0), z1 = min(box[5] + 1, g.dz - 1);
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1, nrows = ny * nz;
+  bool fits = nx <= kTileNx && nrows <= kTileRows;
+  // row table: global start and length of every (z,y) row's x-run, exclusive prefix -> LDS offsets
+  int cnt = 0;
+  if (fits && t < nrows) {
+    int row = ((z0 + t / ny) * g.dy + (y0 + t % ny)) * g.dx;
+    int gs = g.cell_start[row + x0];
+    cnt = g.cell_start[row + x1 + 1] - gs;
+    row_goff[t] = gs;
+  }
+  int incl = cnt;
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
+  int total = 0;
+  for (int w2 = 0; w2 < kBlock / 64; ++w2) total += wave_tot[w2];
+  if (fits && t < nrows) row_loff[t] = before + incl - cnt;
+  if (t == 0) row_loff[fits ? nrows : 0] = total;
+  fits = fits && total <= kTileCap;
+  if (!fits) {  // uniform: hand every active query of the chunk over
+    if (active) { m_to[s] = -1; hard[atomicAdd(hard_count, 1)] = s; }
+    return;
+  }
+  // per-row cell boundaries relative to the row start; loads issued in batches so that several
+  // are in flight per lane
+  {
+    const int ncs = nrows * (nx + 1);
+    for (int base = t; base < ncs; base += 8 * kBlock) {
+      int v[8], rr[8], kk2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int idx = min(base + u * kBlock, ncs - 1);
+        rr[u] = idx / (nx + 1); kk2[u] = idx - rr[u] * (nx + 1);
+        int row = ((z0 + rr[u] / ny) * g.dy + (y0 + rr[u] % ny)) * g.dx;
+        v[u] = g.cell_start[row + x0 + kk2[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (base + u * kBlock < ncs) cso[rr[u]][kk2[u]] = (unsigned short)(v[u] - row_goff[rr[u]]);
+    }
+  }
+  __syncthreads();
+  // stage the points: candidate c of the concatenated rows -> row by binary search over row_loff.
+  // total <= kTileCap = 8 * kBlock: every lane resolves its (up to) 8 addresses first, then issues
+  // the 8 loads back to back, then stores.
+  {
+    int addr[kTileCap / kBlock];
+#pragma unroll
+    for (int u = 0; u < kTileCap / kBlock; ++u) {
+      int c = t + u * kBlock;
+      addr[u] = -1;
+      if (c < total) {
+        int lo = 0, hi = nrows;  // last row with row_loff <= c
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (row_loff[mid] <= c) lo = mid; else hi = mid;
+        }
+        addr[u] = row_goff[lo] + (c - row_loff[lo]);
+      }
+    }
+    GridPoint pt[kTileCap / kBlock];
+#pragma unroll
+    for (int u = 0; u < kTileCap / kBlock; ++u) pt[u] = g.gp[max(addr[u], 0)];
+#pragma unroll
+    for (int u = 0; u < kTileCap / kBlock; ++u)
+      if (addr[u] >= 0) {
+        int c = t + u * kBlock;
+        px[c] = pt[u].x; py[c] = pt[u].y; pz[c] = pt[u].z; pcan[c] = pt[u].canon; porig[c] = pt[u].orig;
+      }
+  }
+  __syncthreads();
+  if (!active) return;
+  // ring search from LDS
+  Best b;
+  b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
+#define LDS_SCAN(R, XA, XB)                                                          \
+  {                                                                                  \
+    int base_ = row_loff[R];                                                         \
+    for (int j_ = base_ + cso[R][(XA) - x0], e_ = base_ + cso[R][(XB) + 1 - x0]; j_ < e_; ++j_) \
+      consider(b, dist2(yx, yy, yz, px[j_], py[j_], pz[j_]), porig[j_], pcan[j_]);   \
+  }
+  {
+    int r = (cz - z0) * ny + (cy - y0);
+    LDS_SCAN(r, cx, cx)
+  }
+  bool done = ring_settled(ring_bound(g, cx, cy, cz, 0, yx, yy, yz), g.tol, b.d);
+  if (!done) {
+    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z) {
       double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
       double dz2 = gz_ * gz_;
-      if (dz2 > bd) continue;
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        int y = cy - 1 + b;
-        if (y < 0 || y >= g.dy) continue;
+      if (dz2 > b.d) continue;
+      for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) {
         double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
         double dyz2 = dz2 + gy_ * gy_;
-        if (dyz2 > bd) continue;
-        if (a != 1 || b != 1) {  // shell row: the x-run cx-1..cx+1, narrowed by the best distance
+        if (dyz2 > b.d) continue;
+        int r = (z - z0) * ny + (y - y0);
+        if (z != cz || y != cy) {
           int xa = max(cx - 1, 0), xb = min(cx + 1, g.dx - 1);
-          if (bd < INFINITY) {
-            double rad = sqrt(bd - dyz2) + 2.0 * g.tol;
+          if (b.d < INFINITY) {
+            double rad = sqrt(b.d - dyz2) + 2.0 * g.tol;
             xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
             xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
           }
-          if (xa <= xb) LRR_SCAN(st[a][b][xa - (cx - 1)], st[a][b][xb + 1 - (cx - 1)])
-        } else {  // centre row: the two end cells
+          if (xa <= xb) LDS_SCAN(r, xa, xb)
+        } else {
           if (cx - 1 >= 0) {
             double gx_ = slab_gap(yx, g.lox + (cx - 1) * g.h, g.lox + cx * g.h, g.tol);
-            if (dyz2 + gx_ * gx_ <= bd) LRR_SCAN(st[1][1][0], st[1][1][1])
+            if (dyz2 + gx_ * gx_ <= b.d) LDS_SCAN(r, cx - 1, cx - 1)
           }
           if (cx + 1 <= g.dx - 1) {
             double gx_ = slab_gap(yx, g.lox + (cx + 1) * g.h, g.lox + (cx + 2) * g.h, g.tol);
-            if (dyz2 + gx_ * gx_ <= bd) LRR_SCAN(st[1][1][2], st[1][1][3])
+            if (dyz2 + gx_ * gx_ <= b.d) LDS_SCAN(r, cx + 1, cx + 1)
           }
         }
       }
     }
-    double lb = INFINITY;
-    if (cx - 1 > 0) lb = fmin(lb, yx - (g.lox + (cx - 1) * g.h));
-    if (cx + 1 < g.dx - 1) lb = fmin(lb, (g.lox + (cx + 2) * g.h) - yx);
-    if (cy - 1 > 0) lb = fmin(lb, yy - (g.loy + (cy - 1) * g.h));
-    if (cy + 1 < g.dy - 1) lb = fmin(lb, (g.loy + (cy + 2) * g.h) - yy);
-    if (cz - 1 > 0) lb = fmin(lb, yz - (g.loz + (cz - 1) * g.h));
-    if (cz + 1 < g.dz - 1) lb = fmin(lb, (g.loz + (cz + 2) * g.h) - yz);
-    if (lb == INFINITY) done = true;
-    else { lb -= g.tol; if (lb > 0.0 && bd < lb * lb) done = true; }
+    done = ring_settled(ring_bound(g, cx, cy, cz, 1, yx, yy, yz), g.tol, b.d);
   }
-#undef LRR_SCAN
-  best = (bi == 0x7fffffff) ? 0 : bi;
-  return done;
-}
-
-// K1, query order = match-list order (explicit orders, coarse levels, stand-alone queries)
-__global__ __launch_bounds__(kBlock) void k_match_grid(GridView g, QuerySrc qs, XfD xf, int n,
-                                                       int *m_from, int *m_to, double *w_out,
-                                                       int *overflow, int *overflow_count) {
-  int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  int p = query_index(qs, i);
-  const double *pr = qs.rec + (size_t)p * qs.stride;
-  double yx, yy, yz;
-  map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
-  if (m_from) m_from[i] = p;
-  if (w_out) w_out[i] = 1.0;
-  int bi;
-  if (grid_search_easy(g, yx, yy, yz, kEasyBudget, bi)) m_to[i] = bi;
+#undef LDS_SCAN
+  if (done) m_to[s] = (b.orig == 0x7fffffff) ? 0 : b.canon;
   else {
-    m_to[i] = -1;
-    overflow[atomicAdd(overflow_count, 1)] = i;
+    m_to[s] = -1;
+    hard[atomicAdd(hard_count, 1)] = s;
   }
 }
 
-// K1, spatially coherent form for the fine levels: thread s takes the s-th point of the
-// from-cloud in ITS grid order (coalesced loads; neighbouring lanes query neighbouring cells of
-// the target grid, so they share cache lines and ring counts) and writes the result into match
-// slot j = perm^-1(point), which keeps the match list identical to the direct form.
-__global__ __launch_bounds__(kBlock) void k_match_grid_coherent(GridView g, GridView gfrom, Keys keys,
-                                                                int half, int n_points, XfD xf,
-                                                                int *m_from, int *m_to, double *w_out,
-                                                                int *overflow, int *overflow_count) {
-  int s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= gfrom.n) return;
-  GridPoint src = gfrom.gp[s];
-  int p = (int)src.idx;
-  int j = subset_perm_inv(p, gfrom.n, half, keys);
-  if (j >= n_points) return;
-  double yx, yy, yz;
-  map_loc(xf, src.x, src.y, src.z, yx, yy, yz);
-  m_from[j] = p;
-  w_out[j] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-  int bi;
-  if (grid_search_easy(g, yx, yy, yz, kEasyBudget, bi)) m_to[j] = bi;
-  else {
-    m_to[j] = -1;
-    overflow[atomicAdd(overflow_count, 1)] = j;
-  }
-}
-
-// K1 phase 2: the queries phase 1 handed over (far from any target feature, or next to cells too
-// dense for one lane).  One WAVEFRONT per query.  For ring r the up to 2(2r+1)^2 cell runs (a
-// whole x-run for shell rows, the two end cells for interior rows) are taken 64 at a time: each
-// lane box-prunes one run and fetches its [start, end) range, a wave prefix sum turns the runs
-// into one candidate list, and the lanes stride over THAT list (binary search in LDS from
-// candidate number to run) — every lane busy whatever the point distribution.  Lanes are merged
-// by a lexicographic (distance, index) shuffle reduction; the stopping rule is grid_search's,
-// so the result is the same exact nearest neighbour.
-__global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QuerySrc qs, XfD xf, const int *hard,
+// K1 phase 2: the queries phase 1 handed over (far from any target feature, next to cells too
+// dense for one lane, or in a chunk whose box did not fit LDS).  One WAVEFRONT per query.  For
+// ring r the up to 2(2r+1)^2 cell runs (a whole x-run for shell rows, the two end cells for
+// interior rows) are taken 64 at a time: each lane box-prunes one run and fetches its
+// [start, end) range, a wave prefix sum turns the runs into one candidate list, and the lanes
+// stride over THAT list (binary search in LDS from candidate number to run) — every lane busy
+// whatever the point distribution.  Lanes are merged by a lexicographic (distance, index)
+// shuffle reduction; same stopping rule, so the result is the same exact nearest neighbour.
+__global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QSrc q, XfD xf, const int *hard,
                                                        const int *hard_count, int *m_to, int *overflow,
                                                        int *overflow_count) {
   __shared__ int seg_s[kBlock / 64][64], seg_pre[kBlock / 64][64];
@@ -527,22 +656,20 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QuerySrc qs, 
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
   const int cnt = *hard_count;
   for (int o = wave; o < cnt; o += nwaves) {
-    int i = hard[o];
-    int p = query_index(qs, i);
-    const double *pr = qs.rec + (size_t)p * qs.stride;
-    double yx, yy, yz;
-    map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
+    int s = hard[o];
+    double x, y_, z_, yx, yy, yz;
+    query_point(q, s, x, y_, z_);
+    map_loc(xf, x, y_, z_, yx, yy, yz);
     int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
     int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
     int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
-    double bd = INFINITY;   // wave-uniform best so far
-    int bi = 0x7fffffff;
+    Best b;  // wave-uniform best so far
+    b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
     bool done = false;
     for (int r = 0; r <= kRingMax && !done; ++r) {
       const int side = 2 * r + 1, nitems = 2 * side * side;
       for (int base = 0; base < nitems; base += 64) {
-        // one cell run per lane
-        int t = base + lane, s0 = 0, e0 = 0;
+        int t = base + lane, s0 = 0, e0 = 0;  // one cell run per lane
         if (t < nitems) {
           int rowi = t >> 1, which = t & 1;
           int z = cz - r + rowi / side, y = cy - r + rowi % side;
@@ -550,14 +677,14 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QuerySrc qs, 
             double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
             double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
             double dyz2 = gz_ * gz_ + gy_ * gy_;
-            if (dyz2 <= bd) {
+            if (dyz2 <= b.d) {
               int row = (z * g.dy + y) * g.dx;
               bool shell = (z - cz == r) || (cz - z == r) || (y - cy == r) || (cy - y == r);
               if (shell) {
                 if (which == 0) {
                   int xa = max(cx - r, 0), xb = min(cx + r, g.dx - 1);
-                  if (bd < INFINITY) {
-                    double rad = sqrt(bd - dyz2) + 2.0 * g.tol;
+                  if (b.d < INFINITY) {
+                    double rad = sqrt(b.d - dyz2) + 2.0 * g.tol;
                     xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
                     xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
                   }
@@ -567,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QuerySrc qs, 
                 int xc = which == 0 ? cx - r : cx + r;
                 if (xc >= 0 && xc <= g.dx - 1) {
                   double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
-                  if (dyz2 + gx_ * gx_ <= bd) { s0 = g.cell_start[row + xc]; e0 = g.cell_start[row + xc + 1]; }
+                  if (dyz2 + gx_ * gx_ <= b.d) { s0 = g.cell_start[row + xc]; e0 = g.cell_start[row + xc + 1]; }
                 }
               }
             }
@@ -584,8 +711,8 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QuerySrc qs, 
           seg_s[wv][lane] = s0;
           seg_pre[wv][lane] = incl - c0;
           __builtin_amdgcn_wave_barrier();
-          double ld = INFINITY;  // this lane's best in the chunk
-          int li = 0x7fffffff;
+          Best l;  // this lane's best in the chunk
+          l.d = INFINITY; l.orig = 0x7fffffff; l.canon = 0;
           for (int c = lane; c < total; c += 64) {
             int lo = 0, hi = 64;  // last run whose exclusive prefix is <= c
 #pragma unroll
@@ -594,101 +721,105 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QuerySrc qs, 
               if (seg_pre[wv][mid] <= c) lo = mid; else hi = mid;
             }
             GridPoint pt = g.gp[seg_s[wv][lo] + (c - seg_pre[wv][lo])];
-            double d = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
-            int oi = (int)pt.idx;
-            if (d < ld || (d == ld && oi < li)) { ld = d; li = oi; }
+            consider(l, dist2(yx, yy, yz, pt.x, pt.y, pt.z), pt.orig, pt.canon);
           }
           __builtin_amdgcn_wave_barrier();
-          // merge the lanes with the running best: smallest distance, ties to the lowest index
 #pragma unroll
           for (int off = 32; off > 0; off >>= 1) {
-            double d2 = __shfl_xor(ld, off, 64);
-            int i2 = __shfl_xor(li, off, 64);
-            if (d2 < ld || (d2 == ld && i2 < li)) { ld = d2; li = i2; }
+            double d2 = __shfl_xor(l.d, off, 64);
+            int o2 = __shfl_xor(l.orig, off, 64), c2 = __shfl_xor(l.canon, off, 64);
+            consider(l, d2, o2, c2);
           }
-          if (ld < bd || (ld == bd && li < bi)) { bd = ld; bi = li; }
+          consider(b, l.d, l.orig, l.canon);
         }
       }
-      double lb = INFINITY;
-      if (cx - r > 0) lb = fmin(lb, yx - (g.lox + (cx - r) * g.h));
-      if (cx + r < g.dx - 1) lb = fmin(lb, (g.lox + (cx + r + 1) * g.h) - yx);
-      if (cy - r > 0) lb = fmin(lb, yy - (g.loy + (cy - r) * g.h));
-      if (cy + r < g.dy - 1) lb = fmin(lb, (g.loy + (cy + r + 1) * g.h) - yy);
-      if (cz - r > 0) lb = fmin(lb, yz - (g.loz + (cz - r) * g.h));
-      if (cz + r < g.dz - 1) lb = fmin(lb, (g.loz + (cz + r + 1) * g.h) - yz);
-      if (lb == INFINITY) done = true;
-      else {
-        lb -= g.tol;
-        if (lb > 0.0 && bd < lb * lb) done = true;
-      }
+      done = ring_settled(ring_bound(g, cx, cy, cz, r, yx, yy, yz), g.tol, b.d);
     }
     if (lane == 0) {
-      if (done) m_to[i] = (bi == 0x7fffffff) ? 0 : bi;
-      else overflow[atomicAdd(overflow_count, 1)] = i;
+      if (done) m_to[s] = result_index(q, b);
+      else overflow[atomicAdd(overflow_count, 1)] = s;
     }
   }
 }
 
-// brute-force fallback for the (rare) queries the ring search did not settle: one block each
-__global__ __launch_bounds__(kBlock) void k_match_overflow(GridView g, QuerySrc qs, XfD xf,
-                                                           const int *overflow,
+// K1 phase 3: brute force for the (rare) queries still open after kRingMax rings: one block each
+__global__ __launch_bounds__(kBlock) void k_match_overflow(GridView g, QSrc q, XfD xf, const int *overflow,
                                                            const int *overflow_count, int *m_to) {
   __shared__ double sd[kBlock];
-  __shared__ int si[kBlock];
+  __shared__ int so[kBlock], sc[kBlock];
   int cnt = *overflow_count;
   for (int o = blockIdx.x; o < cnt; o += gridDim.x) {
-    int i = overflow[o];
-    int p = query_index(qs, i);
-    const double *pr = qs.rec + (size_t)p * qs.stride;
-    double yx, yy, yz;
-    map_loc(xf, pr[0], pr[1], pr[2], yx, yy, yz);
-    double bd = INFINITY;
-    int bi = 0x7fffffff;
+    int s = overflow[o];
+    double x, y_, z_, yx, yy, yz;
+    query_point(q, s, x, y_, z_);
+    map_loc(xf, x, y_, z_, yx, yy, yz);
+    Best b;
+    b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
     for (int j = threadIdx.x; j < g.n; j += kBlock) {
       GridPoint pt = g.gp[j];
-      double d = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
-      int oi = (int)pt.idx;
-      if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
+      consider(b, dist2(yx, yy, yz, pt.x, pt.y, pt.z), pt.orig, pt.canon);
     }
-    sd[threadIdx.x] = bd; si[threadIdx.x] = bi;
+    sd[threadIdx.x] = b.d; so[threadIdx.x] = b.orig; sc[threadIdx.x] = b.canon;
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) {
-        double d2 = sd[threadIdx.x + s]; int i2 = si[threadIdx.x + s];
-        if (d2 < sd[threadIdx.x] || (d2 == sd[threadIdx.x] && i2 < si[threadIdx.x])) { sd[threadIdx.x] = d2; si[threadIdx.x] = i2; }
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+      if ((int)threadIdx.x < st) {
+        Best a; a.d = sd[threadIdx.x]; a.orig = so[threadIdx.x]; a.canon = sc[threadIdx.x];
+        consider(a, sd[threadIdx.x + st], so[threadIdx.x + st], sc[threadIdx.x + st]);
+        sd[threadIdx.x] = a.d; so[threadIdx.x] = a.orig; sc[threadIdx.x] = a.canon;
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) m_to[i] = (si[0] == 0x7fffffff) ? 0 : si[0];
+    if (threadIdx.x == 0) { Best a; a.d = sd[0]; a.orig = so[0]; a.canon = sc[0]; m_to[s] = result_index(q, a); }
     __syncthreads();
   }
+}
+
+// slot assignment + active list for the all-vs-all matcher
+__global__ void k_slots_dense(const SrcPoint *src, Keys keys, int half, int nsrc, int n_points, int *slot,
+                              double *w, int *active, int *active_count) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc) return;
+  int j = subset_perm_inv((int)src[s].orig, nsrc, half, keys);
+  bool a = j < n_points;
+  slot[s] = a ? j : -1;
+  if (a) { w[s] = 1.0; active[atomicAdd(active_count, 1)] = s; }
+}
+__global__ void k_slots_sparse(const int *order, int use_keys, Keys keys, int half, int nsrc, const int *canon_of,
+                               int n, int *slot, double *w, int *active) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int p = order ? order[i] : (use_keys ? subset_perm(i, nsrc, half, keys) : i);
+  int s = canon_of[p];
+  slot[s] = i;
+  w[s] = 1.0;
+  active[i] = s;
 }
 
 // All-vs-all matcher: each block owns kBlock*Q queries (Q per thread, in registers) and streams
 // one chunk of the target cloud through LDS in tiles; every lane reads the same LDS address
 // (broadcast, conflict-free).  blockIdx.y splits the target cloud so that small query counts
-// still fill the chip; partial (d2, idx) pairs are merged lexicographically by k_brute_merge.
+// still fill the chip; partial results are merged lexicographically by k_brute_merge.
 constexpr int kBruteQ = 2;
 constexpr int kBruteTile = 1024;
 
-__global__ __launch_bounds__(kBlock) void k_match_brute(GridView g, QuerySrc qs, XfD xf, int n,
-                                                        int chunk, int *m_from, double *pd,
-                                                        int *pi) {
+__global__ __launch_bounds__(kBlock) void k_match_brute(GridView g, QSrc q, const int *active, XfD xf, int n,
+                                                        int chunk, double *pd, int *po, int *pc) {
   __shared__ double sx[kBruteTile], sy[kBruteTile], sz[kBruteTile];
-  __shared__ int sidx[kBruteTile];
-  double yx[kBruteQ], yy[kBruteQ], yz[kBruteQ], bd[kBruteQ];
-  int bi[kBruteQ], qi[kBruteQ];
+  __shared__ int sorig[kBruteTile], scan[kBruteTile];
+  double yx[kBruteQ], yy[kBruteQ], yz[kBruteQ];
+  Best b[kBruteQ];
+  int qi[kBruteQ];
 #pragma unroll
-  for (int q = 0; q < kBruteQ; ++q) {
-    int i = (blockIdx.x * kBruteQ + q) * kBlock + threadIdx.x;
-    qi[q] = i;
-    bd[q] = INFINITY; bi[q] = 0x7fffffff;
-    yx[q] = yy[q] = yz[q] = 0.0;
+  for (int u = 0; u < kBruteQ; ++u) {
+    int i = (blockIdx.x * kBruteQ + u) * kBlock + threadIdx.x;
+    qi[u] = i;
+    b[u].d = INFINITY; b[u].orig = 0x7fffffff; b[u].canon = 0;
+    yx[u] = yy[u] = yz[u] = 0.0;
     if (i < n) {
-      int p = query_index(qs, i);
-      const double *pr = qs.rec + (size_t)p * qs.stride;
-      map_loc(xf, pr[0], pr[1], pr[2], yx[q], yy[q], yz[q]);
-      if (m_from && blockIdx.y == 0) m_from[i] = p;
+      int s = active ? active[i] : i;
+      double x, y_, z_;
+      query_point(q, s, x, y_, z_);
+      map_loc(xf, x, y_, z_, yx[u], yy[u], yz[u]);
     }
   }
   int begin = blockIdx.y * chunk, end = min(begin + chunk, g.n);
@@ -697,75 +828,69 @@ __global__ __launch_bounds__(kBlock) void k_match_brute(GridView g, QuerySrc qs,
     __syncthreads();
     for (int j = threadIdx.x; j < tn; j += kBlock) {
       GridPoint pt = g.gp[base + j];
-      sx[j] = pt.x; sy[j] = pt.y; sz[j] = pt.z;
-      sidx[j] = (int)pt.idx;
+      sx[j] = pt.x; sy[j] = pt.y; sz[j] = pt.z; sorig[j] = pt.orig; scan[j] = pt.canon;
     }
     __syncthreads();
     for (int j = 0; j < tn; ++j) {
-      double px = sx[j], py = sy[j], pz = sz[j];
-      int oi = sidx[j];
+      double ptx = sx[j], pty = sy[j], ptz = sz[j];
+      int oi = sorig[j], ci = scan[j];
 #pragma unroll
-      for (int q = 0; q < kBruteQ; ++q) {
-        double d = dist2(yx[q], yy[q], yz[q], px, py, pz);
-        if (d < bd[q] || (d == bd[q] && oi < bi[q])) { bd[q] = d; bi[q] = oi; }
-      }
+      for (int u = 0; u < kBruteQ; ++u) consider(b[u], dist2(yx[u], yy[u], yz[u], ptx, pty, ptz), oi, ci);
     }
   }
 #pragma unroll
-  for (int q = 0; q < kBruteQ; ++q)
-    if (qi[q] < n) {
-      pd[(size_t)blockIdx.y * n + qi[q]] = bd[q];
-      pi[(size_t)blockIdx.y * n + qi[q]] = bi[q];
+  for (int u = 0; u < kBruteQ; ++u)
+    if (qi[u] < n) {
+      size_t o = (size_t)blockIdx.y * n + qi[u];
+      pd[o] = b[u].d; po[o] = b[u].orig; pc[o] = b[u].canon;
     }
 }
 
-__global__ void k_brute_merge(const double *pd, const int *pi, int n, int S, int *m_to, double *w_out) {
+__global__ void k_brute_merge(const double *pd, const int *po, const int *pc, int n, int S, QSrc q,
+                              const int *active, int *m_to) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (w_out) w_out[i] = 1.0;
-  double bd = pd[i];
-  int bi = pi[i];
-  for (int s = 1; s < S; ++s) {
-    double d = pd[(size_t)s * n + i];
-    int oi = pi[(size_t)s * n + i];
-    if (d < bd || (d == bd && oi < bi)) { bd = d; bi = oi; }
-  }
-  m_to[i] = (bi == 0x7fffffff) ? 0 : bi;
+  Best b;
+  b.d = pd[i]; b.orig = po[i]; b.canon = pc[i];
+  for (int s2 = 1; s2 < S; ++s2) consider(b, pd[(size_t)s2 * n + i], po[(size_t)s2 * n + i], pc[(size_t)s2 * n + i]);
+  m_to[active ? active[i] : i] = result_index(q, b);
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-match passes
+// per-match passes.  Arrays are indexed by the canonical source position s; slot[s] < 0 marks a
+// source feature that is not in the active subset.
 // ---------------------------------------------------------------------------------------------
 struct PairSrc {
   const double *from_rec, *to_rec;
-  const int *m_from, *m_to;
+  const int *slot, *m_to;
   const double *from_loc;  // pre-mapped copies or nullptr
+  int nsrc;
 };
 
-__device__ __forceinline__ void load_from(const PairSrc &ps, int i, double &p0, double &p1, double &p2) {
+__device__ __forceinline__ void load_from(const PairSrc &ps, int s, double &p0, double &p1, double &p2) {
   if (ps.from_loc) {
-    p0 = ps.from_loc[3 * (size_t)i]; p1 = ps.from_loc[3 * (size_t)i + 1]; p2 = ps.from_loc[3 * (size_t)i + 2];
+    p0 = ps.from_loc[3 * (size_t)s]; p1 = ps.from_loc[3 * (size_t)s + 1]; p2 = ps.from_loc[3 * (size_t)s + 2];
   } else {
-    const double *r = ps.from_rec + (size_t)ps.m_from[i] * kRecStride;
+    const double *r = ps.from_rec + (size_t)s * kRecStride;
     p0 = r[0]; p1 = r[1]; p2 = r[2];
   }
 }
 
 // rigid pre-map (cdcl .txx:467-482)
-__global__ void k_premap(PairSrc ps, XfD G, int n, double *out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ void k_premap(PairSrc ps, XfD G, double *out) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ps.nsrc || ps.slot[s] < 0) return;
   double p0, p1, p2, y0, y1, y2;
-  load_from(ps, i, p0, p1, p2);
+  load_from(ps, s, p0, p1, p2);
   map_loc(G, p0, p1, p2, y0, y1, y2);
-  out[3 * (size_t)i] = y0; out[3 * (size_t)i + 1] = y1; out[3 * (size_t)i + 2] = y2;
+  out[3 * (size_t)s] = y0; out[3 * (size_t)s + 1] = y1; out[3 * (size_t)s + 2] = y2;
 }
 
-__device__ __forceinline__ double pair_residual2(const PairSrc &ps, int i, const XfD &xf, const NormD &nm) {
+__device__ __forceinline__ double pair_residual2(const PairSrc &ps, int s, const XfD &xf, const NormD &nm) {
   double p0, p1, p2;
-  load_from(ps, i, p0, p1, p2);
+  load_from(ps, s, p0, p1, p2);
   p0 = (p0 - nm.cm[0]) / nm.rm; p1 = (p1 - nm.cm[1]) / nm.rm; p2 = (p2 - nm.cm[2]) / nm.rm;
-  const double *q = ps.to_rec + (size_t)ps.m_to[i] * kRecStride;
+  const double *q = ps.to_rec + (size_t)ps.m_to[s] * kRecStride;
   double q0 = (q[0] - nm.cf[0]) / nm.rf, q1 = (q[1] - nm.cf[1]) / nm.rf, q2 = (q[2] - nm.cf[2]) / nm.rf;
   double y0, y1, y2;
   map_loc(xf, p0, p1, p2, y0, y1, y2);
@@ -773,39 +898,39 @@ __device__ __forceinline__ double pair_residual2(const PairSrc &ps, int i, const
 }
 
 // K2 pass 1 (cdcl .txx:677-708; rrl .txx:594-617)
-__global__ __launch_bounds__(kBlock) void k_residual(PairSrc ps, XfD xf, NormD nm, int n,
-                                                     const double *w_prev, double *r2_out,
-                                                     double *dist_out, double *partials) {
+__global__ __launch_bounds__(kBlock) void k_residual(PairSrc ps, XfD xf, NormD nm, const double *w_prev,
+                                                     double *r2_out, double *dist_out, double *partials) {
   double acc[2] = {0.0, 0.0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    double r2 = pair_residual2(ps, i, xf, nm);
-    double wp = w_prev[i];
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+    if (ps.slot[s] < 0) { dist_out[s] = INFINITY; continue; }
+    double r2 = pair_residual2(ps, s, xf, nm);
+    double wp = w_prev[s];
     acc[0] += wp * r2;
     acc[1] += wp;
-    r2_out[i] = r2;
-    dist_out[i] = sqrt(r2);
+    r2_out[s] = r2;
+    dist_out[s] = sqrt(r2);
   }
   block_reduce_store<2>(acc, partials);
 }
 
 // K2 pass 2 (cdcl .txx:744-765, weight_BT cdcl_utils.h:142-152)
-__global__ void k_assign(const double *r2, double scale, int n, double *w) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__global__ void k_assign(const int *slot, const double *r2, double scale, int nsrc, double *w) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc || slot[s] < 0) return;
   double scale2 = scale * scale;
-  double u = r2[i] / scale2;
+  double u = r2[s] / scale2;
   double bt = 0.0;
   if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
-  w[i] = bt / scale2;
+  w[s] = bt / scale2;
 }
 
 // K4 (cdcl .txx:196-268)
-__global__ __launch_bounds__(kBlock) void k_errors(PairSrc ps, XfD xf, NormD nm, int n,
-                                                   const double *w, double *partials) {
+__global__ __launch_bounds__(kBlock) void k_errors(PairSrc ps, XfD xf, NormD nm, const double *w, double *partials) {
   double acc[3] = {0.0, 0.0, 0.0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    double r2 = pair_residual2(ps, i, xf, nm);
-    double wi = w[i];
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+    if (ps.slot[s] < 0) continue;
+    double r2 = pair_residual2(ps, s, xf, nm);
+    double wi = w[s];
     acc[0] += r2;
     acc[1] += sqrt(r2) * wi;
     acc[2] += wi;
@@ -814,19 +939,20 @@ __global__ __launch_bounds__(kBlock) void k_errors(PairSrc ps, XfD xf, NormD nm,
 }
 
 // K5 statistics (cdcl .txx:1175-1213)
-__global__ __launch_bounds__(kBlock) void k_from_sum(PairSrc ps, int n, double *partials) {
+__global__ __launch_bounds__(kBlock) void k_from_sum(PairSrc ps, double *partials) {
   double acc[3] = {0.0, 0.0, 0.0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+    if (ps.slot[s] < 0) continue;
     double p0, p1, p2;
-    load_from(ps, i, p0, p1, p2);
+    load_from(ps, s, p0, p1, p2);
     acc[0] += p0; acc[1] += p1; acc[2] += p2;
   }
   block_reduce_store<3>(acc, partials);
 }
 
-__global__ void k_mark(const int *m_to, int n, unsigned *flag) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flag[m_to[i]] = 1u;  // benign race: every writer stores 1
+__global__ void k_mark(const int *slot, const int *m_to, int nsrc, unsigned *flag) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nsrc && slot[s] >= 0) flag[m_to[s]] = 1u;  // benign race: every writer stores 1
 }
 
 __global__ __launch_bounds__(kBlock) void k_to_sum(const double *to_rec, const unsigned *flag, int nt,
@@ -841,14 +967,14 @@ __global__ __launch_bounds__(kBlock) void k_to_sum(const double *to_rec, const u
   block_reduce_store<4>(acc, partials);
 }
 
-__global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, int n, const double *to_rec,
-                                                  const unsigned *flag, int nt, double cm0, double cm1,
-                                                  double cm2, double cf0, double cf1, double cf2,
-                                                  double *partials) {
+__global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, const double *to_rec, const unsigned *flag, int nt,
+                                                  double cm0, double cm1, double cm2, double cf0, double cf1,
+                                                  double cf2, double *partials) {
   double acc[2] = {0.0, 0.0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+    if (ps.slot[s] < 0) continue;
     double p0, p1, p2;
-    load_from(ps, i, p0, p1, p2);
+    load_from(ps, s, p0, p1, p2);
     p0 -= cm0; p1 -= cm1; p2 -= cm2;
     acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
   }
@@ -862,54 +988,82 @@ __global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, int n, const doubl
   block_reduce_store<2>(acc, partials);
 }
 
-// weight_by_strength, first loop (cdcl .txx:832-851; rrl .txx:728-743).  reversed: the list is a
-// role-reversed clone list (the product is symmetric, only the weight buffer differs).
-__global__ __launch_bounds__(kBlock) void k_strength(PairSrc ps, int n, int float_product, double *w,
-                                                     double *key, double *partials) {
+__device__ __forceinline__ double strength_gain(const PairSrc &ps, int s, int float_product) {
+  double sp = ps.from_rec[(size_t)s * kRecStride + 9];
+  double sq = ps.to_rec[(size_t)ps.m_to[s] * kRecStride + 9];
+  double g = float_product ? (double)((float)sp * (float)sq) : sp * sq;
+  return g > 90000.0 ? 90000.0 : g;
+}
+
+// weight_by_strength, first loop (cdcl .txx:832-851; rrl .txx:728-743)
+__global__ __launch_bounds__(kBlock) void k_strength(PairSrc ps, int float_product, double *w, double *key,
+                                                     double *partials) {
   double acc[1] = {0.0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    double wi = w[i];
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
     double k = INFINITY;
-    if (wi != 0) {
-      double sp = ps.from_rec[(size_t)ps.m_from[i] * kRecStride + 9];
-      double sq = ps.to_rec[(size_t)ps.m_to[i] * kRecStride + 9];
-      double g = float_product ? (double)((float)sp * (float)sq) : sp * sq;
-      if (g > 90000.0) g = 90000.0;
-      w[i] = wi * g;
-      k = g;
-      acc[0] += 1.0;
+    if (ps.slot[s] >= 0) {
+      double wi = w[s];
+      if (wi != 0) {
+        double g = strength_gain(ps, s, float_product);
+        w[s] = wi * g;
+        k = g;
+        acc[0] += 1.0;
+      }
     }
-    key[i] = k;
+    key[s] = k;
   }
   block_reduce_store<1>(acc, partials);
 }
 
-// weight_spatially, first loop (cdcl .txx:977-990; rrl .txx:760-770).  use_from: the to_ of a
-// role-reversed clone is this direction's from_.
-__global__ void k_spatial(PairSrc ps, NormD nm, int n, int use_from, double *w, double *key) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// spatial weight 1 / (1 + 5 |q~|^2) of the normalised to_ location (cdcl .txx:984-985); use_from:
+// the to_ of a role-reversed clone is this direction's from_
+__device__ __forceinline__ double spatial_weight(const PairSrc &ps, int s, const NormD &nm, int use_from) {
   double q0, q1, q2;
   if (use_from) {
-    load_from(ps, i, q0, q1, q2);
+    load_from(ps, s, q0, q1, q2);
     q0 = (q0 - nm.cm[0]) / nm.rm; q1 = (q1 - nm.cm[1]) / nm.rm; q2 = (q2 - nm.cm[2]) / nm.rm;
   } else {
-    const double *q = ps.to_rec + (size_t)ps.m_to[i] * kRecStride;
+    const double *q = ps.to_rec + (size_t)ps.m_to[s] * kRecStride;
     q0 = (q[0] - nm.cf[0]) / nm.rf; q1 = (q[1] - nm.cf[1]) / nm.rf; q2 = (q[2] - nm.cf[2]) / nm.rf;
   }
   double d = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
-  double sw = 1.0 / (1.0 + 5.0 * d * d);
-  w[i] *= sw;
-  key[i] = sw;
+  return 1.0 / (1.0 + 5.0 * d * d);
 }
 
-__global__ void k_scale_w(double *w, int n, double f) {
+// weight_spatially, first loop (cdcl .txx:977-990; rrl .txx:760-770)
+__global__ void k_spatial(PairSrc ps, NormD nm, int use_from, double *w, double *key) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ps.nsrc) return;
+  if (ps.slot[s] < 0) { key[s] = INFINITY; return; }
+  double sw = spatial_weight(ps, s, nm, use_from);
+  w[s] *= sw;
+  key[s] = sw;
+}
+
+__global__ void k_scale_w(const int *slot, double *w, int nsrc, double f) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nsrc && slot[s] >= 0) w[s] *= f;
+}
+
+__global__ void k_copy_w(const double *src, double *dst, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) w[i] *= f;
+  if (i < n) dst[i] = src[i];
+}
+
+// matches_ in the reference's list order: (original from index, original to index, weight)
+__global__ void k_export(const int *slot, const int *m_to, const double *w, const int *from_orig,
+                         const int *to_orig, int nsrc, long long *out_from, long long *out_to, double *out_w) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc) return;
+  int j = slot[s];
+  if (j < 0) return;
+  out_from[j] = from_orig[s];
+  out_to[j] = to_orig[m_to[s]];
+  out_w[j] = w[s];
 }
 
 // K3 — normal equations.  Upper triangle + rhs per thread in registers, grid-stride over the
-// matches, fixed-order block reduction.  Per-pair products follow the reference's operation
+// sources, fixed-order block reduction.  Per-pair products follow the reference's operation
 // order (generic: (J^T P) J w, cdcl .txx:1061-1062; PREMUL: (J^T (P w)) J, rrl sym .txx:468-536)
 // so that only the ORDER of the sum differs from the CPU path.
 template <int DOF> struct Tri { static constexpr int N = DOF * (DOF + 1) / 2; };
@@ -969,13 +1123,13 @@ __device__ __forceinline__ void accumulate_pair(double *acc, double wi, double j
 }
 
 // loads one match in normalised coordinates and orients it (reversed: role-reversed term)
-__device__ __forceinline__ void load_oriented(const PairSrc &ps, int i, const NormD &nm, int reversed,
+__device__ __forceinline__ void load_oriented(const PairSrc &ps, int s, const NormD &nm, int reversed,
                                               double &jx, double &jy, double &jz, double &b0, double &b1,
                                               double &b2, double *P) {
   double p0, p1, p2;
-  load_from(ps, i, p0, p1, p2);
+  load_from(ps, s, p0, p1, p2);
   p0 = (p0 - nm.cm[0]) / nm.rm; p1 = (p1 - nm.cm[1]) / nm.rm; p2 = (p2 - nm.cm[2]) / nm.rm;
-  const double *qr = ps.to_rec + (size_t)ps.m_to[i] * kRecStride;
+  const double *qr = ps.to_rec + (size_t)ps.m_to[s] * kRecStride;
   double q0 = (qr[0] - nm.cf[0]) / nm.rf, q1 = (qr[1] - nm.cf[1]) / nm.rf, q2 = (qr[2] - nm.cf[2]) / nm.rf;
   if (!reversed) {
 #pragma unroll
@@ -983,7 +1137,7 @@ __device__ __forceinline__ void load_oriented(const PairSrc &ps, int i, const No
     jx = p0; jy = p1; jz = p2;
     b0 = q0; b1 = q1; b2 = q2;
   } else {
-    const double *pr = ps.from_rec + (size_t)ps.m_from[i] * kRecStride;
+    const double *pr = ps.from_rec + (size_t)s * kRecStride;
 #pragma unroll
     for (int k = 0; k < 6; ++k) P[k] = pr[3 + k];
     jx = q0; jy = q1; jz = q2;
@@ -992,32 +1146,71 @@ __device__ __forceinline__ void load_oriented(const PairSrc &ps, int i, const No
 }
 
 template <int DOF, bool PREMUL>
-__global__ __launch_bounds__(kBlock) void k_accumulate(PairSrc ps, NormD nm, int n, const double *w,
-                                                       double c0, double c1, double c2,
-                                                       int rigid_increment, int reversed,
+__global__ __launch_bounds__(kBlock) void k_accumulate(PairSrc ps, NormD nm, const double *w, double c0, double c1,
+                                                       double c2, int rigid_increment, int reversed,
                                                        double *partials) {
   constexpr int NT = Tri<DOF>::N;
   double acc[NT + DOF];
 #pragma unroll
   for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    double wi = w[i];
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+    if (ps.slot[s] < 0) continue;
+    double wi = w[s];
     if (PREMUL && wi < 1e-4) continue;
     double jx, jy, jz, b0, b1, b2, P[6];
-    load_oriented(ps, i, nm, reversed, jx, jy, jz, b0, b1, b2, P);
+    load_oriented(ps, s, nm, reversed, jx, jy, jz, b0, b1, b2, P);
     accumulate_pair<DOF, PREMUL>(acc, wi, jx, jy, jz, b0, b1, b2, P, c0, c1, c2, rigid_increment);
   }
   block_reduce_store<NT + DOF>(acc, partials);
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact order statistics: one 1024-thread block per job, 6-pass MSB radix select on the
-// (non-negative) double bit patterns with an LDS histogram; optional sum/count of smaller keys
-// (needed by the trimmed MUSE scale).  Stands in for std::nth_element / std::sort.
+// exact order statistics on the (non-negative) double bit patterns: 6-pass MSB radix select.
+// k_select: one 1024-thread block per job, LDS histogram, also sums the keys below the k-th
+// (needed by the trimmed MUSE scale; first estimate only).  k_sel_*: the same passes spread over
+// the chip for the per-iteration MAD scales.  Stand in for std::nth_element / std::sort.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long job_key(const SelJob &j, int i) {
   double v = i < j.n0 ? j.k0[i] : j.k1[i - j.n0];
   return (unsigned long long)__double_as_longlong(fabs(v));
+}
+
+// wave-aggregated LDS histogram update: keys of similar magnitude share their leading digits, so
+// one lane adds the whole group (two rounds), the stragglers use their own LDS atomic
+__device__ __forceinline__ void hist_add(int *hist, bool act, int dgt) {
+  int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    unsigned long long m = __ballot(act);
+    if (m == 0ull) break;
+    int leader = __ffsll((long long)m) - 1;
+    int d0 = __shfl(dgt, leader, 64);
+    unsigned long long same = __ballot(act && dgt == d0);
+    if (lane == leader) atomicAdd(&hist[d0], (int)__popcll(same));
+    if (dgt == d0) act = false;
+  }
+  if (act) atomicAdd(&hist[dgt], 1);
+}
+
+// every thread owns bins 2t, 2t+1 of a 2048-bin histogram: finds the bin holding rank k
+__device__ __forceinline__ void pick_bin(int h0, int h1, long long k, int *wave_tot, int *sel_bin, int *sel_before) {
+  int s = h0 + h1, incl = s;
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
+  int excl = before + incl - s;
+  if (s > 0 && k >= excl && k < excl + s) {
+    if (k < excl + h0) { *sel_bin = 2 * threadIdx.x; *sel_before = excl; }
+    else { *sel_bin = 2 * threadIdx.x + 1; *sel_before = excl + h0; }
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
@@ -1029,18 +1222,6 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
   SelJob job = jobs[blockIdx.x];
   int n = job.n0 + job.n1;
   long long k = job.k, m = job.m_fixed;
-  if (job.cnt) {  // uniform branch: the whole block sums the partial counts in a fixed order
-    double c = 0.0;
-    for (int b = job.cnt_a0 + (int)threadIdx.x; b < job.cnt_a1; b += kSelThreads) c += job.cnt[b];
-    for (int b = job.cnt_b0 + (int)threadIdx.x; b < job.cnt_b1; b += kSelThreads) c += job.cnt[b];
-    c = wave_sum(c);
-    if ((threadIdx.x & 63) == 0) red_c[threadIdx.x >> 6] = c;
-    __syncthreads();
-    double tot = 0.0;
-    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += red_c[w2];
-    __syncthreads();
-    m = (long long)tot;
-  }
   if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
   if (n <= 0 || k < 0 || k >= n) {
     if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m; }
@@ -1062,41 +1243,10 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
         act = (key & mask) == prefix;
         dgt = (int)((key >> shift) & (unsigned long long)(bins - 1));
       }
-      // keys of similar magnitude share their leading digits: let one lane add the whole group
-      // (two rounds), the stragglers use their own LDS atomic
-      int lane = threadIdx.x & 63;
-#pragma unroll
-      for (int round = 0; round < 2; ++round) {
-        unsigned long long m = __ballot(act);
-        if (m == 0ull) break;
-        int leader = __ffsll((long long)m) - 1;
-        int d0 = __shfl(dgt, leader, 64);
-        unsigned long long same = __ballot(act && dgt == d0);
-        if (lane == leader) atomicAdd(&hist[d0], (int)__popcll(same));
-        if (dgt == d0) act = false;
-      }
-      if (act) atomicAdd(&hist[dgt], 1);
+      hist_add(hist, act, dgt);
     }
     __syncthreads();
-    // each thread owns 2 bins; block-wide exclusive scan of the pair sums
-    int h0 = hist[2 * threadIdx.x], h1 = hist[2 * threadIdx.x + 1];
-    int s = h0 + h1, incl = s;
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    int before = 0;
-    for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
-    int excl = before + incl - s;
-    if (s > 0 && k >= excl && k < excl + s) {
-      if (k < excl + h0) { sel_bin = 2 * threadIdx.x; sel_before = excl; }
-      else { sel_bin = 2 * threadIdx.x + 1; sel_before = excl + h0; }
-    }
-    __syncthreads();
+    pick_bin(hist[2 * threadIdx.x], hist[2 * threadIdx.x + 1], k, wave_tot, &sel_bin, &sel_before);
     prefix |= (unsigned long long)sel_bin << shift;
     mask |= (unsigned long long)(bins - 1) << shift;
     k -= sel_before;
@@ -1118,6 +1268,69 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
   }
 }
 
+__global__ __launch_bounds__(kBlock) void k_sel_init(const SelJob *jobs, SelState *st, int *hist) {
+  SelJob job = jobs[blockIdx.x];
+  long long m = job.m_fixed;
+  if (job.cnt) {
+    double tot = block_total(job.cnt, job.cnt_a0, job.cnt_a1, 1, 0) + block_total(job.cnt, job.cnt_b0, job.cnt_b1, 1, 0);
+    m = (long long)tot;
+  }
+  long long k = job.k;
+  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
+  if (k >= (long long)job.n0 + job.n1) k = -1;
+  for (int b = threadIdx.x; b < 2048; b += kBlock) hist[blockIdx.x * 2048 + b] = 0;
+  if (threadIdx.x == 0) { SelState s0; s0.prefix = 0; s0.mask = 0; s0.k = k; s0.m = m; st[blockIdx.x] = s0; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sel_hist(const SelJob *jobs, const SelState *st, int *hist, int shift, int bins) {
+  __shared__ int lh[2048];
+  SelJob job = jobs[blockIdx.y];
+  SelState s0 = st[blockIdx.y];
+  if (s0.k < 0) return;
+  for (int b = threadIdx.x; b < 2048; b += kBlock) lh[b] = 0;
+  __syncthreads();
+  int n = job.n0 + job.n1;
+  int per = (n + gridDim.x - 1) / gridDim.x;
+  int lo = blockIdx.x * per, hi = min(lo + per, n);
+  for (int base = lo; base < hi; base += kBlock) {
+    int i = base + threadIdx.x;
+    bool act = false;
+    int dgt = 0;
+    if (i < hi) {
+      unsigned long long key = job_key(job, i);
+      act = (key & s0.mask) == s0.prefix;
+      dgt = (int)((key >> shift) & (unsigned long long)(bins - 1));
+    }
+    hist_add(lh, act, dgt);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += kBlock) {
+    int v = lh[b];
+    if (v) atomicAdd(&hist[blockIdx.y * 2048 + b], v);  // integer: order-independent
+  }
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_sel_pick(const SelJob *jobs, SelState *st, int *hist, int shift, int bins, int last) {
+  __shared__ int wave_tot[kSelThreads / 64];
+  __shared__ int sel_bin, sel_before;
+  SelJob job = jobs[blockIdx.x];
+  SelState s0 = st[blockIdx.x];
+  int *h = hist + blockIdx.x * 2048;
+  if (s0.k < 0) {
+    if (last && threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
+    return;
+  }
+  pick_bin(h[2 * threadIdx.x], h[2 * threadIdx.x + 1], s0.k, wave_tot, &sel_bin, &sel_before);
+  h[2 * threadIdx.x] = 0; h[2 * threadIdx.x + 1] = 0;  // ready for the next pass
+  if (threadIdx.x == 0) {
+    s0.prefix |= (unsigned long long)sel_bin << shift;
+    s0.mask |= (unsigned long long)(bins - 1) << shift;
+    s0.k -= sel_before;
+    st[blockIdx.x] = s0;
+    if (last) { job.out[0] = __longlong_as_double((long long)s0.prefix); job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused symmetric estimate: six kernels, no host round trip in between.  Scalars (scales,
 // normalisation statistics, MAD factors) are re-derived in each consumer kernel's prologue from
@@ -1125,7 +1338,7 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
 // ---------------------------------------------------------------------------------------------
 struct DirArgs {
   PairSrc ps;
-  int n;
+  int n;               // active matches
   double *w, *wc, *r2, *key_s, *key_g;
   unsigned *flag;
   int float_product;
@@ -1134,21 +1347,6 @@ struct DirArgs {
 // scalar block layout (doubles) inside the fused output buffer
 enum { SC_CM = 0, SC_RM = 3, SC_CF = 4, SC_RF = 7, SC_ND = 8, SC_SIGF = 9, SC_SIGB = 10, SC_SIZE = 16,
        SEL_OFF = 16, SEL_SIZE = 16, FIN_OFF = 32, FUSED_OUT = 32 + kMaxRed };
-
-// sum of column k over rows [r0, r1) of a row-major partials table; same value in every thread
-__device__ __forceinline__ double block_total(const double *P, int r0, int r1, int K, int k) {
-  __shared__ double sh[kBlock / 64];
-  double s = 0.0;
-  for (int b = r0 + (int)threadIdx.x; b < r1; b += kBlock) s += P[(size_t)b * K + k];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  double tot = sh[0];
-#pragma unroll
-  for (int w2 = 1; w2 < kBlock / 64; ++w2) tot += sh[w2];
-  __syncthreads();
-  return tot;
-}
 
 // F1: residuals of both lists (un-normalised coordinates: rrl sym .txx:701-705), sums for the
 // RMS scale, centroid sums and distinct-target marks of the forward list
@@ -1159,18 +1357,19 @@ __global__ __launch_bounds__(kBlock) void k_f_residual(DirArgs F, DirArgs B, int
   const XfD &xf = isF ? xfF : xfB;
   const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = lb * kBlock + threadIdx.x; i < D.n; i += nb * kBlock) {
-    double r2 = pair_residual2(D.ps, i, xf, ident);
-    double wp = D.w[i];
+  for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
+    if (D.ps.slot[s] < 0) { D.key_s[s] = INFINITY; continue; }
+    double r2 = pair_residual2(D.ps, s, xf, ident);
+    double wp = D.w[s];
     acc[0] += wp * r2;
     acc[1] += wp;
-    D.r2[i] = r2;
-    D.key_s[i] = sqrt(r2);
+    D.r2[s] = r2;
+    D.key_s[s] = sqrt(r2);
     if (isF && want_stats) {
       double p0, p1, p2;
-      load_from(D.ps, i, p0, p1, p2);
+      load_from(D.ps, s, p0, p1, p2);
       acc[2] += p0; acc[3] += p1; acc[4] += p2;
-      D.flag[D.ps.m_to[i]] = 1u;
+      D.flag[D.ps.m_to[s]] = 1u;
     }
   }
   block_reduce_store<5>(acc, P1);
@@ -1189,9 +1388,10 @@ __global__ __launch_bounds__(kBlock) void k_f_radii(DirArgs F, int nbF, const do
     SC[SC_ND] = nd;
   }
   double acc[2] = {0.0, 0.0};
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < F.n; i += gridDim.x * kBlock) {
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+    if (F.ps.slot[s] < 0) continue;
     double p0, p1, p2;
-    load_from(F.ps, i, p0, p1, p2);
+    load_from(F.ps, s, p0, p1, p2);
     p0 -= cm[0]; p1 -= cm[1]; p2 -= cm[2];
     acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
   }
@@ -1261,33 +1461,22 @@ __global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int 
   double *wdst = clone ? D.wc : D.w;
   const double scale2 = scale * scale;
   double acc[1] = {0.0};
-  for (int i = lb * kBlock + threadIdx.x; i < D.n; i += nb * kBlock) {
-    double u = D.r2[i] / scale2, bt = 0.0;
+  for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
+    if (D.ps.slot[s] < 0) { D.key_g[s] = INFINITY; D.key_s[s] = INFINITY; continue; }
+    double u = D.r2[s] / scale2, bt = 0.0;
     if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
     double wi = bt / scale2;
-    if (clone) D.w[i] = wi;  // the backward list itself keeps its Beaton-Tukey weights (cdcl sym .txx:665)
+    if (clone) D.w[s] = wi;  // the backward list itself keeps its Beaton-Tukey weights (cdcl sym .txx:665)
     double key = INFINITY;
     if (strength && wi != 0) {
-      double sp = D.ps.from_rec[(size_t)D.ps.m_from[i] * kRecStride + 9];
-      double sq = D.ps.to_rec[(size_t)D.ps.m_to[i] * kRecStride + 9];
-      double g = D.float_product ? (double)((float)sp * (float)sq) : sp * sq;
-      if (g > 90000.0) g = 90000.0;
+      double g = strength_gain(D.ps, s, D.float_product);
       wi = wi * g;
       key = g;
       acc[0] += 1.0;
     }
-    D.key_g[i] = key;
-    double q0, q1, q2;
-    if (clone) {  // the clone's to_ is this list's from_
-      load_from(D.ps, i, q0, q1, q2);
-      q0 = (q0 - nm.cm[0]) / nm.rm; q1 = (q1 - nm.cm[1]) / nm.rm; q2 = (q2 - nm.cm[2]) / nm.rm;
-    } else {
-      const double *q = D.ps.to_rec + (size_t)D.ps.m_to[i] * kRecStride;
-      q0 = (q[0] - nm.cf[0]) / nm.rf; q1 = (q[1] - nm.cf[1]) / nm.rf; q2 = (q[2] - nm.cf[2]) / nm.rf;
-    }
-    double d = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
-    D.key_s[i] = 1.0 / (1.0 + 5.0 * d * d);
-    wdst[i] = wi;
+    D.key_g[s] = key;
+    D.key_s[s] = spatial_weight(D.ps, s, nm, clone ? 1 : 0);
+    wdst[s] = wi;
   }
   block_reduce_store<1>(acc, P4);
 }
@@ -1318,133 +1507,19 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
   double acc[NT + DOF];
 #pragma unroll
   for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
-  for (int i = lb * kBlock + threadIdx.x; i < D.n; i += nb * kBlock) {
-    double wi = wbuf[i];
+  for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
+    if (D.ps.slot[s] < 0) continue;
+    double wi = wbuf[s];
     if (strength) wi = wi * fg;
-    wi = wi * D.key_s[i];
+    wi = wi * D.key_s[s];
     wi = wi * fs;
-    wbuf[i] = wi;
+    wbuf[s] = wi;
     if (PREMUL && wi < 1e-4) continue;
     double jx, jy, jz, b0, b1, b2, P[6];
-    load_oriented(D.ps, i, nm, isF ? 0 : 1, jx, jy, jz, b0, b1, b2, P);
+    load_oriented(D.ps, s, nm, isF ? 0 : 1, jx, jy, jz, b0, b1, b2, P);
     accumulate_pair<DOF, PREMUL>(acc, wi, jx, jy, jz, b0, b1, b2, P, c0, c1, c2, rigid_increment);
   }
   block_reduce_store<NT + DOF>(acc, P6);
-}
-
-// ---------------------------------------------------------------------------------------------
-// the same 6-pass MSB radix select spread over the chip: per pass one histogram kernel (many
-// blocks per job, LDS-private histograms flushed with integer atomics: order-independent, so
-// still deterministic) and one pick kernel (one block per job scans the 2048 bins, narrows the
-// prefix and clears the histogram).  Used for the MAD scales, where only the k-th value is needed.
-// ---------------------------------------------------------------------------------------------
-constexpr int kSelHistBlocks = 64;   // blocks per job and pass
-
-__global__ __launch_bounds__(kBlock) void k_sel_init(const SelJob *jobs, SelState *st, int *hist) {
-  SelJob job = jobs[blockIdx.x];
-  long long m = job.m_fixed;
-  if (job.cnt) {
-    double tot = block_total(job.cnt, job.cnt_a0, job.cnt_a1, 1, 0) + block_total(job.cnt, job.cnt_b0, job.cnt_b1, 1, 0);
-    m = (long long)tot;
-  }
-  long long k = job.k;
-  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
-  if (k >= (long long)job.n0 + job.n1) k = -1;
-  for (int b = threadIdx.x; b < 2048; b += kBlock) hist[blockIdx.x * 2048 + b] = 0;
-  if (threadIdx.x == 0) { SelState s0; s0.prefix = 0; s0.mask = 0; s0.k = k; s0.m = m; st[blockIdx.x] = s0; }
-}
-
-__global__ __launch_bounds__(kBlock) void k_sel_hist(const SelJob *jobs, const SelState *st, int *hist, int shift, int bins) {
-  __shared__ int lh[2048];
-  SelJob job = jobs[blockIdx.y];
-  SelState s0 = st[blockIdx.y];
-  if (s0.k < 0) return;
-  for (int b = threadIdx.x; b < 2048; b += kBlock) lh[b] = 0;
-  __syncthreads();
-  int n = job.n0 + job.n1;
-  int per = (n + gridDim.x - 1) / gridDim.x;
-  int lo = blockIdx.x * per, hi = min(lo + per, n);
-  int lane = threadIdx.x & 63;
-  for (int base = lo; base < hi; base += kBlock) {
-    int i = base + threadIdx.x;
-    bool act = false;
-    int dgt = 0;
-    if (i < hi) {
-      unsigned long long key = job_key(job, i);
-      act = (key & s0.mask) == s0.prefix;
-      dgt = (int)((key >> shift) & (unsigned long long)(bins - 1));
-    }
-#pragma unroll
-    for (int round = 0; round < 2; ++round) {
-      unsigned long long mm = __ballot(act);
-      if (mm == 0ull) break;
-      int leader = __ffsll((long long)mm) - 1;
-      int d0 = __shfl(dgt, leader, 64);
-      unsigned long long same = __ballot(act && dgt == d0);
-      if (lane == leader) atomicAdd(&lh[d0], (int)__popcll(same));
-      if (dgt == d0) act = false;
-    }
-    if (act) atomicAdd(&lh[dgt], 1);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < bins; b += kBlock) {
-    int v = lh[b];
-    if (v) atomicAdd(&hist[blockIdx.y * 2048 + b], v);
-  }
-}
-
-__global__ __launch_bounds__(kSelThreads) void k_sel_pick(const SelJob *jobs, SelState *st, int *hist, int shift, int bins, int last) {
-  __shared__ int wave_tot[kSelThreads / 64];
-  __shared__ int sel_bin, sel_before;
-  SelJob job = jobs[blockIdx.x];
-  SelState s0 = st[blockIdx.x];
-  int *h = hist + blockIdx.x * 2048;
-  if (s0.k < 0) {
-    if (last && threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
-    return;
-  }
-  int h0 = h[2 * threadIdx.x], h1 = h[2 * threadIdx.x + 1];
-  int s = h0 + h1, incl = s;
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) wave_tot[wv] = incl;
-  __syncthreads();
-  int before = 0;
-  for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
-  int excl = before + incl - s;
-  long long k = s0.k;
-  if (s > 0 && k >= excl && k < excl + s) {
-    if (k < excl + h0) { sel_bin = 2 * threadIdx.x; sel_before = excl; }
-    else { sel_bin = 2 * threadIdx.x + 1; sel_before = excl + h0; }
-  }
-  __syncthreads();
-  h[2 * threadIdx.x] = 0; h[2 * threadIdx.x + 1] = 0;  // ready for the next pass
-  if (threadIdx.x == 0) {
-    s0.prefix |= (unsigned long long)sel_bin << shift;
-    s0.mask |= (unsigned long long)(bins - 1) << shift;
-    s0.k = k - sel_before;
-    st[blockIdx.x] = s0;
-    if (last) { job.out[0] = __longlong_as_double((long long)s0.prefix); job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
-  }
-}
-
-__global__ void k_copy_w(const double *src, double *dst, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i];
-}
-
-__global__ void k_fill(double *dst, int n, double v) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = v;
-}
-
-__global__ void k_widen_idx(const int *src, int n, long long *dst) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1495,8 +1570,9 @@ GridView view_of(const lrr_icp_cloud *c) {
 PairSrc pairs_of(const lrr_icp_dir *d) {
   PairSrc ps;
   ps.from_rec = d->from->rec; ps.to_rec = d->to->rec;
-  ps.m_from = d->m_from; ps.m_to = d->m_to;
+  ps.slot = d->slot; ps.m_to = d->m_to;
   ps.from_loc = d->from_is_copy ? d->from_loc : nullptr;
+  ps.nsrc = (int)d->from->n;
   return ps;
 }
 
@@ -1546,26 +1622,48 @@ int run_select(lrr_icp_ctx *ctx, std::vector<SelJob> &jobs, double *host_out, bo
   return LRR_ICP_OK;
 }
 
+SelJob make_job(const double *k0, int n0, const double *k1, int n1, long long k, long long m) {
+  SelJob j{};
+  j.k0 = k0; j.n0 = n0; j.k1 = k1; j.n1 = n1; j.k = k; j.out = nullptr;
+  j.cnt = nullptr; j.cnt_a0 = j.cnt_a1 = j.cnt_b0 = j.cnt_b1 = 0; j.m_fixed = m;
+  return j;
+}
+
 // rrel_util_median_abs_dev_scale, dof = 1 (cdcl .txx:520-536): k-th of m values, 0 if m <= 1
 inline long long mad_rank(long long m) { return (m - 1) / 2 + 1; }
 inline double mad_from_kth(long long m, double kth) { return 1.4826 * (1 + 5.0 / (double)(m - 1)) * kth; }
 
-int ensure_dir_capacity(lrr_icp_dir *d, int64_t n) {
+int ensure_dir_capacity(lrr_icp_dir *d) {
   lrr_icp_ctx *ctx = d->ctx;
-  if (n <= d->cap) return LRR_ICP_OK;
-  int64_t cap = std::max<int64_t>(n, 1024);
-  void *ptrs[] = {d->m_from, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc};
+  int64_t need = std::max<int64_t>(d->from->n, 1);
+  if (need <= d->cap) return LRR_ICP_OK;
+  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  d->slot = d->m_to = nullptr; d->w = d->wc = d->r2 = d->key_g = d->key_s = d->from_loc = nullptr;
   d->cap = 0;
-  HIPCHK(ctx, hipMalloc(&d->m_from, sizeof(int) * cap));
-  HIPCHK(ctx, hipMalloc(&d->m_to, sizeof(int) * cap));
-  HIPCHK(ctx, hipMalloc(&d->w, sizeof(double) * cap));
-  HIPCHK(ctx, hipMalloc(&d->wc, sizeof(double) * cap));
-  HIPCHK(ctx, hipMalloc(&d->r2, sizeof(double) * cap));
-  HIPCHK(ctx, hipMalloc(&d->key_g, sizeof(double) * cap));
-  HIPCHK(ctx, hipMalloc(&d->key_s, sizeof(double) * cap));
-  HIPCHK(ctx, hipMalloc(&d->from_loc, sizeof(double) * 3 * cap));
-  d->cap = cap;
+  HIPCHK(ctx, hipMalloc(&d->slot, sizeof(int) * need));
+  HIPCHK(ctx, hipMalloc(&d->m_to, sizeof(int) * need));
+  HIPCHK(ctx, hipMalloc(&d->w, sizeof(double) * need));
+  HIPCHK(ctx, hipMalloc(&d->wc, sizeof(double) * need));
+  HIPCHK(ctx, hipMalloc(&d->r2, sizeof(double) * need));
+  HIPCHK(ctx, hipMalloc(&d->key_g, sizeof(double) * need));
+  HIPCHK(ctx, hipMalloc(&d->key_s, sizeof(double) * need));
+  HIPCHK(ctx, hipMalloc(&d->from_loc, sizeof(double) * 3 * need));
+  d->cap = need;
+  return LRR_ICP_OK;
+}
+
+int ensure_lists(lrr_icp_ctx *ctx, size_t need) {
+  if (need <= ctx->list_cap) return LRR_ICP_OK;
+  if (ctx->d_hard) (void)hipFree(ctx->d_hard);
+  if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+  if (ctx->d_active) (void)hipFree(ctx->d_active);
+  ctx->d_hard = ctx->d_overflow = ctx->d_active = nullptr;
+  ctx->list_cap = 0;
+  HIPCHK(ctx, hipMalloc(&ctx->d_hard, sizeof(int) * need));
+  HIPCHK(ctx, hipMalloc(&ctx->d_overflow, sizeof(int) * need));
+  HIPCHK(ctx, hipMalloc(&ctx->d_active, sizeof(int) * need));
+  ctx->list_cap = need;
   return LRR_ICP_OK;
 }
 
@@ -1580,72 +1678,56 @@ unsigned host_fmix32(unsigned h) {
   return h;
 }
 
-// launch the exact NN search of n queries against `to`; results in m_to (and m_from when given)
-int launch_match(lrr_icp_ctx *ctx, lrr_icp_cloud *to, const lrr_icp_cloud *from_cloud, const QuerySrc &qs,
-                 const XfD &xf, int n, int method, int *m_from, int *m_to, double *w_out) {
-  if (n <= 0) return LRR_ICP_OK;
-  if (to->n <= 0) {
-    HIPCHK(ctx, hipMemsetAsync(m_to, 0xff, sizeof(int) * n, ctx->stream));
-    return LRR_ICP_OK;
-  }
-  GridView g = view_of(to);
-  bool prof = ctx->prof && ctx->pe_used + 2 <= (int)ctx->pe.size();
-  if (prof) HIPCHK(ctx, hipEventRecord(ctx->pe[ctx->pe_used], ctx->stream));
-  if (method == LRR_ICP_NN_BRUTE) {
-    int bx = (n + kBlock * kBruteQ - 1) / (kBlock * kBruteQ);
-    int S = std::max(1, std::min(64, 1024 / bx));
-    int max_chunks = (int)((to->n + kBruteTile - 1) / kBruteTile);
-    S = std::min(S, std::max(1, max_chunks));
-    int chunk = (int)((to->n + S - 1) / S);
-    chunk = ((chunk + kBruteTile - 1) / kBruteTile) * kBruteTile;
-    S = (int)((to->n + chunk - 1) / chunk);
-    size_t need = (size_t)S * (size_t)n;
-    if (need > ctx->brute_cap) {
-      if (ctx->d_bd) (void)hipFree(ctx->d_bd);
-      if (ctx->d_bi) (void)hipFree(ctx->d_bi);
-      ctx->brute_cap = 0;
-      HIPCHK(ctx, hipMalloc(&ctx->d_bd, sizeof(double) * need));
-      HIPCHK(ctx, hipMalloc(&ctx->d_bi, sizeof(int) * need));
-      ctx->brute_cap = need;
-    }
-    hipLaunchKernelGGL(k_match_brute, dim3(bx, S), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, chunk, m_from, ctx->d_bd, ctx->d_bi);
-    HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_bd, ctx->d_bi, n, S, m_to, w_out);
-    HIPCHK(ctx, hipGetLastError());
-  } else {
-    if ((size_t)n > ctx->overflow_cap) {
-      if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
-      if (ctx->d_hard) (void)hipFree(ctx->d_hard);
-      ctx->overflow_cap = 0;
-      HIPCHK(ctx, hipMalloc(&ctx->d_overflow, sizeof(int) * (size_t)n));
-      HIPCHK(ctx, hipMalloc(&ctx->d_hard, sizeof(int) * (size_t)n));
-      ctx->overflow_cap = (size_t)n;
-    }
-    int *hard_count = ctx->d_overflow_count, *over_count = ctx->d_overflow_count + 1;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_overflow_count, 0, 2 * sizeof(int), ctx->stream));
-    // phase 1: rings 0..kRingEasy, one thread per query; unsettled queries -> hard list
-    if (from_cloud && qs.use_keys && !qs.order && m_from && w_out && (int64_t)n * 4 >= from_cloud->n) {
-      GridView gf = view_of(from_cloud);
-      hipLaunchKernelGGL(k_match_grid_coherent, dim3(blocks_for(from_cloud->n)), dim3(kBlock), 0, ctx->stream, g, gf, qs.keys, qs.half, n, xf, m_from, m_to, w_out, ctx->d_hard, hard_count);
-    } else {
-      hipLaunchKernelGGL(k_match_grid, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, g, qs, xf, n, m_from, m_to, w_out, ctx->d_hard, hard_count);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    // phase 2: one wavefront per hard query; phase 3: brute force for what is still open.
-    // Both read their list length on the device and fall through when it is 0.
-    int hard_blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)n + 3) / 4));
-    hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, ctx->stream, g, qs, xf, ctx->d_hard, hard_count, m_to, ctx->d_overflow, over_count);
-    HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, ctx->stream, g, qs, xf, ctx->d_overflow, over_count, m_to);
-    HIPCHK(ctx, hipGetLastError());
-  }
-  if (prof) {
-    HIPCHK(ctx, hipEventRecord(ctx->pe[ctx->pe_used + 1], ctx->stream));
-    ctx->pe_used += 2;
-  }
-  ctx->match_launches += 1;
+// phases 2 and 3 of the grid search; both read their list length on the device and fall through
+// when it is 0
+int launch_hard_phases(lrr_icp_ctx *ctx, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to) {
+  int *hard_count = ctx->d_counts, *over_count = ctx->d_counts + 1;
+  int hard_blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)n + 3) / 4));
+  hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, ctx->stream, g, q, xf, ctx->d_hard, hard_count, m_to, ctx->d_overflow, over_count);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, ctx->stream, g, q, xf, ctx->d_overflow, over_count, m_to);
+  HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
+
+int launch_brute(lrr_icp_ctx *ctx, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const int *active,
+                 const XfD &xf, int n, int *m_to) {
+  int bx = (n + kBlock * kBruteQ - 1) / (kBlock * kBruteQ);
+  int S = std::max(1, std::min(64, 1024 / bx));
+  int max_chunks = (int)((to->n + kBruteTile - 1) / kBruteTile);
+  S = std::min(S, std::max(1, max_chunks));
+  int chunk = (int)((to->n + S - 1) / S);
+  chunk = ((chunk + kBruteTile - 1) / kBruteTile) * kBruteTile;
+  S = (int)((to->n + chunk - 1) / chunk);
+  size_t need = (size_t)S * (size_t)n;
+  if (need > ctx->brute_cap) {
+    if (ctx->d_bd) (void)hipFree(ctx->d_bd);
+    if (ctx->d_bi) (void)hipFree(ctx->d_bi);
+    ctx->d_bd = nullptr; ctx->d_bi = nullptr;
+    ctx->brute_cap = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_bd, sizeof(double) * need));
+    HIPCHK(ctx, hipMalloc(&ctx->d_bi, sizeof(int) * 2 * need));
+    ctx->brute_cap = need;
+  }
+  int *po = ctx->d_bi, *pc = ctx->d_bi + need;
+  hipLaunchKernelGGL(k_match_brute, dim3(bx, S), dim3(kBlock), 0, ctx->stream, g, q, active, xf, n, chunk, ctx->d_bd, po, pc);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_bd, po, pc, n, S, q, active, m_to);
+  HIPCHK(ctx, hipGetLastError());
+  return LRR_ICP_OK;
+}
+
+struct ProfScope {  // HIP events around one K1 submission (all phases)
+  lrr_icp_ctx *ctx;
+  bool on;
+  explicit ProfScope(lrr_icp_ctx *c) : ctx(c), on(c->prof && c->pe_used + 2 <= (int)c->pe.size()) {
+    if (on) (void)hipEventRecord(ctx->pe[ctx->pe_used], ctx->stream);
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(ctx->pe[ctx->pe_used + 1], ctx->stream); ctx->pe_used += 2; }
+    ctx->match_launches += 1;
+  }
+};
 
 int resolve_profile(lrr_icp_ctx *ctx) {
   if (ctx->pe_used == 0) return LRR_ICP_OK;
@@ -1657,6 +1739,16 @@ int resolve_profile(lrr_icp_ctx *ctx) {
   }
   ctx->pe_used = 0;
   return LRR_ICP_OK;
+}
+
+DirArgs dir_args(lrr_icp_dir *d) {
+  DirArgs a;
+  a.ps = pairs_of(d);
+  a.n = (int)d->n;
+  a.w = d->w; a.wc = d->wc; a.r2 = d->r2; a.key_s = d->key_s; a.key_g = d->key_g;
+  a.flag = d->flag;
+  a.float_product = d->from->float_strength;
+  return a;
 }
 
 }  // namespace
@@ -1685,11 +1777,11 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
-  if ((e = hipMalloc(&ctx->d_overflow_count, 2 * sizeof(int))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_counts, 4 * sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selstate, sizeof(SelState) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selhist, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256)) != hipSuccess) return bail(e);
   *out = ctx;
   return LRR_ICP_OK;
 }
@@ -1701,20 +1793,11 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   for (hipEvent_t ev : ctx->pe) (void)hipEventDestroy(ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
-  if (ctx->d_final) (void)hipFree(ctx->d_final);
+  void *dev[] = {ctx->d_partials, ctx->d_final, ctx->d_jobs, ctx->d_bd, ctx->d_bi, ctx->d_hard, ctx->d_overflow,
+                 ctx->d_active, ctx->d_counts, ctx->d_order, ctx->d_fused, ctx->d_selstate, ctx->d_selhist};
+  for (void *p : dev) if (p) (void)hipFree(p);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
-  if (ctx->d_jobs) (void)hipFree(ctx->d_jobs);
   if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
-  if (ctx->d_bd) (void)hipFree(ctx->d_bd);
-  if (ctx->d_bi) (void)hipFree(ctx->d_bi);
-  if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
-  if (ctx->d_hard) (void)hipFree(ctx->d_hard);
-  if (ctx->d_overflow_count) (void)hipFree(ctx->d_overflow_count);
-  if (ctx->d_order) (void)hipFree(ctx->d_order);
-  if (ctx->d_fused) (void)hipFree(ctx->d_fused);
-  if (ctx->d_selstate) (void)hipFree(ctx->d_selstate);
-  if (ctx->d_selhist) (void)hipFree(ctx->d_selhist);
   if (ctx->h_fused) (void)hipHostFree(ctx->h_fused);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1765,26 +1848,22 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
   if (!ctx || !out || n < 0 || n > 0x3fffffff || (n > 0 && (!loc || !proj))) return fail(ctx, LRR_ICP_ERR_ARG, "cloud_create: bad argument");
   *out = nullptr;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  // records; the error projector must be symmetric (nn^T, I - tt^T, I: features/itkFeatureImageFilter.txx:1053-1072)
-  std::vector<double> rec((size_t)std::max<int64_t>(n, 1) * kRecStride);
+  // the error projector must be symmetric (nn^T, I - tt^T, I: features/itkFeatureImageFilter.txx:1053-1072)
   for (int64_t i = 0; i < n; ++i) {
     const double *P = proj + 9 * i;
     if (P[1] != P[3] || P[2] != P[6] || P[5] != P[7]) return fail(ctx, LRR_ICP_ERR_ARG, "cloud_create: error_projector_ must be symmetric");
-    double *r = &rec[(size_t)i * kRecStride];
-    r[0] = loc[3 * i]; r[1] = loc[3 * i + 1]; r[2] = loc[3 * i + 2];
-    r[3] = P[0]; r[4] = P[1]; r[5] = P[2]; r[6] = P[4]; r[7] = P[5]; r[8] = P[8];
-    double s = strength ? strength[i] : 0.0;
-    r[9] = float_strength ? (double)(float)s : s;
+    for (int d = 0; d < 3; ++d)
+      if (!std::isfinite(loc[3 * i + d])) return fail(ctx, LRR_ICP_ERR_ARG, "cloud_create: non-finite location");
   }
   lrr_icp_cloud *c = new (std::nothrow) lrr_icp_cloud;
   if (!c) return fail(ctx, LRR_ICP_ERR_HIP, "out of host memory");
   c->ctx = ctx; c->n = n; c->float_strength = float_strength;
-  // uniform grid, ~2 points per cell; counting sort by cell id
+  // uniform grid, ~0.5 points per cell on average (features sit on surfaces: occupied cells hold
+  // far more); replaces the kd-tree / Voronoi volume of the reference
   double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   for (int64_t i = 0; i < n; ++i)
     for (int d = 0; d < 3; ++d) {
       double v = loc[3 * i + d];
-      if (!std::isfinite(v)) { delete c; return fail(ctx, LRR_ICP_ERR_ARG, "cloud_create: non-finite location"); }
       if (i == 0 || v < lo[d]) lo[d] = v;
       if (i == 0 || v > hi[d]) hi[d] = v;
     }
@@ -1798,7 +1877,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
   if (n > 0 && maxext > 0.0) {
     double vol = 1.0;
     for (int d = 0; d < 3; ++d) vol *= std::max(ext[d], maxext * 1e-3);
-    double ppc = 0.5;  // target points per cell (surfaces make occupied cells far denser)
+    double ppc = 0.5;  // target points per cell
     if (const char *e = std::getenv("LRR_ICP_GRID_PPC")) { double v = std::atof(e); if (v > 0.0) ppc = v; }
     h = std::cbrt(vol / std::max<double>(1.0, (double)n / ppc));
     h = std::max(h, maxext / 512.0);
@@ -1809,7 +1888,10 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
   c->h = h; c->inv_h = 1.0 / h;
   for (int d = 0; d < 3; ++d) { c->lo[d] = lo[d]; c->dim[d] = dim[d]; }
   c->tol = 1e-9 * (maxabs + maxext + h);
-  std::vector<int> cell((size_t)std::max<int64_t>(n, 1)), start((size_t)ncell + 1, 0);
+  const size_t m = (size_t)std::max<int64_t>(n, 1);
+  std::vector<int> cell(m), start((size_t)ncell + 1, 0);
+  std::vector<unsigned long long> key(m);  // (tile, cell): the canonical order
+  const int tdx = (dim[0] + kTile - 1) / kTile, tdy = (dim[1] + kTile - 1) / kTile;
   for (int64_t i = 0; i < n; ++i) {
     int cc[3];
     for (int d = 0; d < 3; ++d) {
@@ -1819,23 +1901,53 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
     int id = (cc[2] * dim[1] + cc[1]) * dim[0] + cc[0];
     cell[(size_t)i] = id;
     start[(size_t)id + 1]++;
+    unsigned long long tile = (unsigned long long)(((cc[2] / kTile) * tdy + cc[1] / kTile) * tdx + cc[0] / kTile);
+    key[(size_t)i] = (tile << 32) | (unsigned)id;
   }
   for (int64_t k = 0; k < ncell; ++k) start[(size_t)k + 1] += start[(size_t)k];
+  std::vector<int> orig_of(m, 0), canon_of(m, 0);
+  for (int64_t i = 0; i < n; ++i) orig_of[(size_t)i] = (int)i;
+  std::sort(orig_of.begin(), orig_of.begin() + n, [&](int a, int b) { return key[(size_t)a] != key[(size_t)b] ? key[(size_t)a] < key[(size_t)b] : a < b; });
+  for (int64_t s = 0; s < n; ++s) canon_of[(size_t)orig_of[(size_t)s]] = (int)s;
+  std::vector<double> rec(m * kRecStride, 0.0);
+  std::vector<SrcPoint> src(m);
+  std::vector<Chunk> chunks;
+  for (int64_t s = 0; s < n; ++s) {
+    int i = orig_of[(size_t)s];
+    const double *P = proj + 9 * (int64_t)i;
+    double *r = &rec[(size_t)s * kRecStride];
+    r[0] = loc[3 * (int64_t)i]; r[1] = loc[3 * (int64_t)i + 1]; r[2] = loc[3 * (int64_t)i + 2];
+    r[3] = P[0]; r[4] = P[1]; r[5] = P[2]; r[6] = P[4]; r[7] = P[5]; r[8] = P[8];
+    double st = strength ? strength[i] : 0.0;
+    r[9] = float_strength ? (double)(float)st : st;
+    src[(size_t)s] = SrcPoint{r[0], r[1], r[2], (long long)i};
+    unsigned long long tile = key[(size_t)i] >> 32;
+    if (chunks.empty() || chunks.back().count == kBlock || (key[(size_t)orig_of[(size_t)chunks.back().start]] >> 32) != tile)
+      chunks.push_back(Chunk{(int)s, 0});
+    chunks.back().count++;
+  }
   std::vector<int> cursor(start.begin(), start.end() - 1);
-  std::vector<GridPoint> gp((size_t)std::max<int64_t>(n, 1));
+  std::vector<GridPoint> gp(m);
   for (int64_t i = 0; i < n; ++i) {  // ascending i: original order kept inside a cell
     int pos = cursor[(size_t)cell[(size_t)i]]++;
-    gp[(size_t)pos] = GridPoint{loc[3 * i], loc[3 * i + 1], loc[3 * i + 2], (long long)i};
+    gp[(size_t)pos] = GridPoint{loc[3 * i], loc[3 * i + 1], loc[3 * i + 2], canon_of[(size_t)i], (int)i};
   }
+  c->nchunks = (int)chunks.size();
+  if (chunks.empty()) chunks.push_back(Chunk{0, 0});
   auto cleanup = [&](int code, const std::string &msg) { lrr_icp_cloud_destroy(c); return fail(ctx, code, msg); };
-  size_t m = (size_t)std::max<int64_t>(n, 1);
-  if (hipMalloc(&c->rec, sizeof(double) * m * kRecStride) != hipSuccess ||
+  if (hipMalloc(&c->rec, sizeof(double) * m * kRecStride) != hipSuccess || hipMalloc(&c->src, sizeof(SrcPoint) * m) != hipSuccess ||
+      hipMalloc(&c->orig_of, sizeof(int) * m) != hipSuccess || hipMalloc(&c->canon_of, sizeof(int) * m) != hipSuccess ||
       hipMalloc(&c->gp, sizeof(GridPoint) * m) != hipSuccess ||
-      hipMalloc(&c->cell_start, sizeof(int) * ((size_t)ncell + 1)) != hipSuccess)
+      hipMalloc(&c->cell_start, sizeof(int) * ((size_t)ncell + 1)) != hipSuccess ||
+      hipMalloc(&c->chunks, sizeof(Chunk) * chunks.size()) != hipSuccess)
     return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
   if (hipMemcpy(c->rec, rec.data(), sizeof(double) * m * kRecStride, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->src, src.data(), sizeof(SrcPoint) * m, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->orig_of, orig_of.data(), sizeof(int) * m, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->canon_of, canon_of.data(), sizeof(int) * m, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->gp, gp.data(), sizeof(GridPoint) * m, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), hipMemcpyHostToDevice) != hipSuccess)
+      hipMemcpy(c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->chunks, chunks.data(), sizeof(Chunk) * chunks.size(), hipMemcpyHostToDevice) != hipSuccess)
     return cleanup(LRR_ICP_ERR_HIP, "cloud_create: upload failed");
   *out = c;
   return LRR_ICP_OK;
@@ -1844,7 +1956,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
 void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
-  void *ptrs[] = {c->rec, c->gp, c->cell_start};
+  void *ptrs[] = {c->rec, c->src, c->orig_of, c->canon_of, c->gp, c->cell_start, c->chunks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
@@ -1860,6 +1972,9 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
   HIPCHK(ctx, hipSetDevice(ctx->device));
   d->flag_cap = std::max<int64_t>(to->n, 1);
   if (hipMalloc(&d->flag, sizeof(unsigned) * d->flag_cap) != hipSuccess) { delete d; return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: hipMalloc failed"); }
+  int rc = ensure_dir_capacity(d);
+  if (rc) { lrr_icp_dir_destroy(d); return rc; }
+  if (hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, ctx->stream) != hipSuccess) { lrr_icp_dir_destroy(d); return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: memset failed"); }
   *out = d;
   return LRR_ICP_OK;
 }
@@ -1867,16 +1982,22 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
 void lrr_icp_dir_destroy(lrr_icp_dir *d) {
   if (!d) return;
   if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
-  void *ptrs[] = {d->m_from, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->flag};
+  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete d;
 }
 
 int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
   if (!d || !from) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   d->from = from;
   d->n = 0;
   d->from_is_copy = 0;
+  int rc = ensure_dir_capacity(d);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, ctx->stream));
   return LRR_ICP_OK;
 }
 
@@ -1913,43 +2034,73 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
                   int64_t n_points, int method) {
   if (!d || !xf || n_points < 0) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = d->ctx;
-  if (n_points > d->from->n) return fail(ctx, LRR_ICP_ERR_ARG, "match: n_points exceeds the from-cloud");
+  const int64_t N = d->from->n;
+  if (n_points > N) return fail(ctx, LRR_ICP_ERR_ARG, "match: n_points exceeds the from-cloud");
   if (!keys && !order && n_points > 0) return fail(ctx, LRR_ICP_ERR_ARG, "match: need keys or an explicit order");
   if (n_points > 0 && d->to->n <= 0) return fail(ctx, LRR_ICP_ERR_ARG, "match: empty to-cloud");
   for (int k = 0; k < 9; ++k) if (!std::isfinite(xf->A[k])) return fail(ctx, LRR_ICP_ERR_ARG, "match: non-finite transform");
   for (int k = 0; k < 3; ++k) if (!std::isfinite(xf->t[k]) || !std::isfinite(xf->c[k])) return fail(ctx, LRR_ICP_ERR_ARG, "match: non-finite transform");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = ensure_dir_capacity(d, n_points);
+  int rc = ensure_dir_capacity(d);
   if (rc) return rc;
   d->from_is_copy = 0;
   d->n = n_points;
-  if (n_points == 0) return LRR_ICP_OK;
-  QuerySrc qs;
-  qs.rec = d->from->rec; qs.stride = kRecStride; qs.order = nullptr; qs.use_keys = 0;
-  qs.nsrc = (int)d->from->n; qs.half = perm_half(d->from->n);
-  std::memset(&qs.keys, 0, sizeof qs.keys);
+  hipStream_t st = ctx->stream;
+  if (n_points == 0) {
+    HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
+    return LRR_ICP_OK;
+  }
+  if ((rc = ensure_lists(ctx, (size_t)N))) return rc;
+  Keys kk;
+  std::memset(&kk, 0, sizeof kk);
+  if (keys) for (int r = 0; r < 4; ++r) kk.k[r] = keys[r];
+  const int half = perm_half(N);
+  const int *d_order = nullptr;
   if (order) {
     if ((size_t)n_points > ctx->order_cap) {
       if (ctx->d_order) (void)hipFree(ctx->d_order);
-      ctx->order_cap = 0;
+      ctx->d_order = nullptr; ctx->order_cap = 0;
       HIPCHK(ctx, hipMalloc(&ctx->d_order, sizeof(int) * (size_t)n_points));
       ctx->order_cap = (size_t)n_points;
     }
     std::vector<int> o32((size_t)n_points);
+    std::vector<unsigned char> seen((size_t)N, 0);
     for (int64_t i = 0; i < n_points; ++i) {
-      if (order[i] < 0 || order[i] >= d->from->n) return fail(ctx, LRR_ICP_ERR_ARG, "match: order index out of range");
+      if (order[i] < 0 || order[i] >= N) return fail(ctx, LRR_ICP_ERR_ARG, "match: order index out of range");
+      if (seen[(size_t)order[i]]) return fail(ctx, LRR_ICP_ERR_ARG, "match: order holds an index twice");
+      seen[(size_t)order[i]] = 1;
       o32[(size_t)i] = (int)order[i];
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_order, o32.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // o32 is pageable and dies at scope exit
-    qs.order = ctx->d_order;
-  } else {
-    qs.use_keys = 1;
-    for (int r = 0; r < 4; ++r) qs.keys.k[r] = keys[r];
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_order, o32.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));  // o32 is pageable and dies at scope exit
+    d_order = ctx->d_order;
   }
   if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
-  // the match kernels also set every weight to 1.0 (cdcl .txx:645)
-  return launch_match(ctx, d->to, d->from, qs, to_dev(xf), (int)n_points, method, d->m_from, d->m_to, d->w);
+  GridView g = view_of(d->to);
+  QSrc q;
+  q.src = d->from->src; q.raw = nullptr; q.want_orig = 0;
+  XfD x = to_dev(xf);
+  const bool dense = !order && n_points * 4 >= N;  // fine levels: every source feature is looked at
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, 4 * sizeof(int), st));
+  ProfScope prof(ctx);
+  if (method == LRR_ICP_NN_BRUTE) {
+    if (dense) {
+      hipLaunchKernelGGL(k_slots_dense, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->from->src, kk, half, (int)N, (int)n_points, d->slot, d->w, ctx->d_active, ctx->d_counts + 2);
+    } else {
+      HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
+      hipLaunchKernelGGL(k_slots_sparse, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, (int)n_points, d->slot, d->w, ctx->d_active);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return launch_brute(ctx, d->to, g, q, ctx->d_active, x, (int)n_points, d->m_to);
+  }
+  if (dense) {
+    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts);
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
+    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, g, q, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, x, (int)n_points, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return launch_hard_phases(ctx, g, q, x, (int)n_points, d->m_to);
 }
 
 int lrr_icp_premap(lrr_icp_dir *d, const lrr_icp_xform *G) {
@@ -1959,7 +2110,7 @@ int lrr_icp_premap(lrr_icp_dir *d, const lrr_icp_xform *G) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   PairSrc ps = pairs_of(d);
   // in place is safe: each thread reads its own 3 doubles before writing them
-  hipLaunchKernelGGL(k_premap, dim3(blocks_for(d->n)), dim3(kBlock), 0, ctx->stream, ps, to_dev(G), (int)d->n, d->from_loc);
+  hipLaunchKernelGGL(k_premap, dim3(blocks_for(ps.nsrc)), dim3(kBlock), 0, ctx->stream, ps, to_dev(G), d->from_loc);
   HIPCHK(ctx, hipGetLastError());
   d->from_is_copy = 1;
   return LRR_ICP_OK;
@@ -1972,8 +2123,9 @@ int lrr_icp_residual_pass(lrr_icp_dir *d, const lrr_icp_xform *xf, const lrr_icp
   if (W) *W = 0.0;
   if (d->n == 0) return LRR_ICP_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int nb = grid_for(d->n);
-  hipLaunchKernelGGL(k_residual, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(d), to_dev(xf), to_dev(norm), (int)d->n, d->w, d->r2, d->key_s, ctx->d_partials);
+  PairSrc ps = pairs_of(d);
+  int nb = grid_for(ps.nsrc);
+  hipLaunchKernelGGL(k_residual, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, to_dev(xf), to_dev(norm), d->w, d->r2, d->key_s, ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   double out[2];
   int rc = finish_reduce(ctx, nb, 2, out);
@@ -2031,8 +2183,8 @@ int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
     if (Qk / sd < 3.0) continue;  // min_exp_kth_to_stddev_ratio
     double div = (double)(n + 1) * std::sqrt(2.0 / M_PI) * (1.0 - std::exp(-Qk * Qk / 2.0));
     cands.push_back({k, Qk, sd, div});
-    SelJob j{}; j.k0 = d->key_s; j.n0 = (int)n; j.k1 = nullptr; j.n1 = 0; j.k = k - 1; j.out = nullptr; j.cnt = nullptr; j.m_fixed = n;
-    jobs.push_back(j);
+    // keys of inactive sources are +inf and sort last
+    jobs.push_back(make_job(d->key_s, (int)d->from->n, nullptr, 0, k - 1, n));
   }
   std::vector<double> res(4 * jobs.size() + 4);
   int rc = run_select(ctx, jobs, res.data(), true);
@@ -2056,7 +2208,8 @@ int lrr_icp_assign_weights(lrr_icp_dir *d, double sigma) {
   lrr_icp_ctx *ctx = d->ctx;
   if (d->n == 0) return LRR_ICP_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_assign, dim3(blocks_for(d->n)), dim3(kBlock), 0, ctx->stream, d->r2, sigma, (int)d->n, d->w);
+  int nsrc = (int)d->from->n;
+  hipLaunchKernelGGL(k_assign, dim3(blocks_for(nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->r2, sigma, nsrc, d->w);
   HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
@@ -2068,17 +2221,15 @@ int lrr_icp_normalize_stats(lrr_icp_dir *d, lrr_icp_norm *out) {
   int64_t n = d->n, nt = d->to->n;
   PairSrc ps = pairs_of(d);
   double r[4];
-  int nb = grid_for(n);
-  hipLaunchKernelGGL(k_from_sum, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, (int)n, ctx->d_partials);
+  int nb = grid_for(ps.nsrc);
+  hipLaunchKernelGGL(k_from_sum, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   int rc = finish_reduce(ctx, nb, 3, r);
   if (rc) return rc;
   for (int k = 0; k < 3; ++k) out->cm[k] = r[k] / (double)n;
   HIPCHK(ctx, hipMemsetAsync(d->flag, 0, sizeof(unsigned) * d->flag_cap, ctx->stream));
-  if (n > 0) {
-    hipLaunchKernelGGL(k_mark, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, d->m_to, (int)n, d->flag);
-    HIPCHK(ctx, hipGetLastError());
-  }
+  hipLaunchKernelGGL(k_mark, dim3(blocks_for(ps.nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->m_to, ps.nsrc, d->flag);
+  HIPCHK(ctx, hipGetLastError());
   int nbt = grid_for(nt);
   hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kBlock), 0, ctx->stream, d->to->rec, d->flag, (int)nt, ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
@@ -2087,7 +2238,7 @@ int lrr_icp_normalize_stats(lrr_icp_dir *d, lrr_icp_norm *out) {
   double nd = r[3];
   for (int k = 0; k < 3; ++k) out->cf[k] = r[k] / nd;
   int nb2 = std::max(nb, nbt);
-  hipLaunchKernelGGL(k_radii, dim3(nb2), dim3(kBlock), 0, ctx->stream, ps, (int)n, d->to->rec, d->flag, (int)nt,
+  hipLaunchKernelGGL(k_radii, dim3(nb2), dim3(kBlock), 0, ctx->stream, ps, d->to->rec, d->flag, (int)nt,
                      out->cm[0], out->cm[1], out->cm[2], out->cf[0], out->cf[1], out->cf[2], ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   rc = finish_reduce(ctx, nb2, 2, r);
@@ -2102,7 +2253,8 @@ int lrr_icp_clone_weights(lrr_icp_dir *d) {
   lrr_icp_ctx *ctx = d->ctx;
   if (d->n == 0) return LRR_ICP_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_copy_w, dim3(blocks_for(d->n)), dim3(kBlock), 0, ctx->stream, d->w, d->wc, (int)d->n);
+  int nsrc = (int)d->from->n;
+  hipLaunchKernelGGL(k_copy_w, dim3(blocks_for(nsrc)), dim3(kBlock), 0, ctx->stream, d->w, d->wc, nsrc);
   HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
@@ -2113,34 +2265,32 @@ int lrr_icp_weight_by_strength(lrr_icp_dir *a, lrr_icp_dir *b, double *grad_scal
   HIPCHK(ctx, hipSetDevice(ctx->device));
   double cnt_a = 0.0, cnt_b = 0.0;
   int rc;
+  const int na = (int)a->from->n, nbsrc = b ? (int)b->from->n : 0;
   if (a->n > 0) {
-    int nb = grid_for(a->n);
-    hipLaunchKernelGGL(k_strength, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(a), (int)a->n, a->from->float_strength, a->w, a->key_g, ctx->d_partials);
+    int nb = grid_for(na);
+    hipLaunchKernelGGL(k_strength, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(a), a->from->float_strength, a->w, a->key_g, ctx->d_partials);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = finish_reduce(ctx, nb, 1, &cnt_a))) return rc;
   }
   if (b && b->n > 0) {
-    int nb = grid_for(b->n);
-    hipLaunchKernelGGL(k_strength, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(b), (int)b->n, b->from->float_strength, b->wc, b->key_g, ctx->d_partials);
+    int nb = grid_for(nbsrc);
+    hipLaunchKernelGGL(k_strength, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(b), b->from->float_strength, b->wc, b->key_g, ctx->d_partials);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = finish_reduce(ctx, nb, 1, &cnt_b))) return rc;
   }
   long long m = (long long)(cnt_a + cnt_b);
   double gs = 0.0;
   if (m > 1) {
-    // masked entries carry +inf keys and sort last, so rank k among the m finite keys is rank k overall
-    std::vector<SelJob> jobs(1);
-    jobs[0] = SelJob{};
-    jobs[0].k0 = a->key_g; jobs[0].n0 = (int)a->n;
-    jobs[0].k1 = b ? b->key_g : nullptr; jobs[0].n1 = b ? (int)b->n : 0;
-    jobs[0].k = mad_rank(m); jobs[0].out = nullptr; jobs[0].cnt = nullptr; jobs[0].m_fixed = m;
+    // masked / inactive entries carry +inf keys and sort last, so rank k among the m finite keys is rank k overall
+    std::vector<SelJob> jobs(1, make_job(a->n > 0 ? a->key_g : nullptr, a->n > 0 ? na : 0,
+                                         (b && b->n > 0) ? b->key_g : nullptr, (b && b->n > 0) ? nbsrc : 0, mad_rank(m), m));
     double res[4];
     if ((rc = run_select(ctx, jobs, res))) return rc;
     gs = mad_from_kth(m, res[0]);
   }
   double f = 1.0 / gs;
-  if (a->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, a->w, (int)a->n, f); HIPCHK(ctx, hipGetLastError()); }
-  if (b && b->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(b->n)), dim3(kBlock), 0, ctx->stream, b->wc, (int)b->n, f); HIPCHK(ctx, hipGetLastError()); }
+  if (a->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(na)), dim3(kBlock), 0, ctx->stream, a->slot, a->w, na, f); HIPCHK(ctx, hipGetLastError()); }
+  if (b && b->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(nbsrc)), dim3(kBlock), 0, ctx->stream, b->slot, b->wc, nbsrc, f); HIPCHK(ctx, hipGetLastError()); }
   if (grad_scale) *grad_scale = gs;
   return LRR_ICP_OK;
 }
@@ -2149,30 +2299,28 @@ int lrr_icp_weight_spatially(lrr_icp_dir *a, const lrr_icp_norm *norm_a, lrr_icp
   if (!a) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = a->ctx;
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int na = (int)a->from->n, nbsrc = b ? (int)b->from->n : 0;
   if (a->n > 0) {
-    hipLaunchKernelGGL(k_spatial, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, pairs_of(a), to_dev(norm_a), (int)a->n, 0, a->w, a->key_s);
+    hipLaunchKernelGGL(k_spatial, dim3(blocks_for(na)), dim3(kBlock), 0, ctx->stream, pairs_of(a), to_dev(norm_a), 0, a->w, a->key_s);
     HIPCHK(ctx, hipGetLastError());
   }
   if (b && b->n > 0) {
-    hipLaunchKernelGGL(k_spatial, dim3(blocks_for(b->n)), dim3(kBlock), 0, ctx->stream, pairs_of(b), to_dev(norm_b), (int)b->n, 1, b->wc, b->key_s);
+    hipLaunchKernelGGL(k_spatial, dim3(blocks_for(nbsrc)), dim3(kBlock), 0, ctx->stream, pairs_of(b), to_dev(norm_b), 1, b->wc, b->key_s);
     HIPCHK(ctx, hipGetLastError());
   }
   long long m = (long long)a->n + (b ? (long long)b->n : 0);
   double ss = 0.0;
   int rc;
   if (m > 1) {
-    std::vector<SelJob> jobs(1);
-    jobs[0] = SelJob{};
-    jobs[0].k0 = a->key_s; jobs[0].n0 = (int)a->n;
-    jobs[0].k1 = b ? b->key_s : nullptr; jobs[0].n1 = b ? (int)b->n : 0;
-    jobs[0].k = mad_rank(m); jobs[0].out = nullptr; jobs[0].cnt = nullptr; jobs[0].m_fixed = m;
+    std::vector<SelJob> jobs(1, make_job(a->n > 0 ? a->key_s : nullptr, a->n > 0 ? na : 0,
+                                         (b && b->n > 0) ? b->key_s : nullptr, (b && b->n > 0) ? nbsrc : 0, mad_rank(m), m));
     double res[4];
     if ((rc = run_select(ctx, jobs, res))) return rc;
     ss = mad_from_kth(m, res[0]);
   }
   double f = 1.0 / ss;
-  if (a->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(a->n)), dim3(kBlock), 0, ctx->stream, a->w, (int)a->n, f); HIPCHK(ctx, hipGetLastError()); }
-  if (b && b->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(b->n)), dim3(kBlock), 0, ctx->stream, b->wc, (int)b->n, f); HIPCHK(ctx, hipGetLastError()); }
+  if (a->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(na)), dim3(kBlock), 0, ctx->stream, a->slot, a->w, na, f); HIPCHK(ctx, hipGetLastError()); }
+  if (b && b->n > 0) { hipLaunchKernelGGL(k_scale_w, dim3(blocks_for(nbsrc)), dim3(kBlock), 0, ctx->stream, b->slot, b->wc, nbsrc, f); HIPCHK(ctx, hipGetLastError()); }
   if (spatial_scale) *spatial_scale = ss;
   return LRR_ICP_OK;
 }
@@ -2185,17 +2333,17 @@ int lrr_icp_accumulate(lrr_icp_dir *d, int dof, const double jac_centre[3], cons
   std::memset(Atb, 0, sizeof(double) * dof);
   if (d->n == 0) return LRR_ICP_OK;
   int nt = dof * (dof + 1) / 2, K = nt + dof;
-  // 90 fp64 accumulators per thread at dof 12: fewer, longer blocks
-  int nb = (int)std::min<int64_t>(std::max<int64_t>(1, (d->n + kBlock - 1) / kBlock), 512);
   PairSrc ps = pairs_of(d);
+  // 90 fp64 accumulators per thread at dof 12: fewer, longer blocks
+  int nb = (int)std::min<int64_t>(std::max<int64_t>(1, ((int64_t)ps.nsrc + kBlock - 1) / kBlock), 256);
   NormD nm = to_dev(norm);
   const double *w = (flags & LRR_ICP_ACC_CLONE_W) ? d->wc : d->w;
   int rigid = (flags & LRR_ICP_ACC_RIGID_INCREMENT) ? 1 : 0, rev = (flags & LRR_ICP_ACC_REVERSED) ? 1 : 0;
   bool premul = (flags & LRR_ICP_ACC_PREMUL_SKIP) != 0;
-  if (dof == 12 && premul) hipLaunchKernelGGL((k_accumulate<12, true>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, (int)d->n, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
-  else if (dof == 12) hipLaunchKernelGGL((k_accumulate<12, false>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, (int)d->n, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
-  else if (premul) hipLaunchKernelGGL((k_accumulate<6, true>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, (int)d->n, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
-  else hipLaunchKernelGGL((k_accumulate<6, false>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, (int)d->n, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
+  if (dof == 12 && premul) hipLaunchKernelGGL((k_accumulate<12, true>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
+  else if (dof == 12) hipLaunchKernelGGL((k_accumulate<12, false>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
+  else if (premul) hipLaunchKernelGGL((k_accumulate<6, true>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
+  else hipLaunchKernelGGL((k_accumulate<6, false>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, nm, w, jac_centre[0], jac_centre[1], jac_centre[2], rigid, rev, ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   double r[kMaxRed];
   int rc = finish_reduce(ctx, nb, K, r);
@@ -2213,8 +2361,9 @@ int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, doub
   double r[3] = {0.0, 0.0, 0.0};
   if (d->n > 0) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    int nb = grid_for(d->n);
-    hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kBlock), 0, ctx->stream, pairs_of(d), to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), (int)d->n, d->w, ctx->d_partials);
+    PairSrc ps = pairs_of(d);
+    int nb = grid_for(ps.nsrc);
+    hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, ctx->d_partials);
     HIPCHK(ctx, hipGetLastError());
     int rc = finish_reduce(ctx, nb, 3, r);
     if (rc) return rc;
@@ -2223,16 +2372,6 @@ int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, doub
   if (sum_wr) *sum_wr = r[1];
   if (sum_w) *sum_w = r[2];
   return LRR_ICP_OK;
-}
-
-static DirArgs dir_args(lrr_icp_dir *d) {
-  DirArgs a;
-  a.ps = pairs_of(d);
-  a.n = (int)d->n;
-  a.w = d->w; a.wc = d->wc; a.r2 = d->r2; a.key_s = d->key_s; a.key_g = d->key_g;
-  a.flag = d->flag;
-  a.float_product = d->from->float_strength;
-  return a;
 }
 
 int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xform *xfF, const lrr_icp_xform *xfB,
@@ -2247,7 +2386,8 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   double *P4 = ctx->d_fused + kFusedP4, *P6 = ctx->d_fused + kFusedP6, *OUT = ctx->d_fused + kFusedOut;
   double *SC = OUT, *SEL = OUT + SEL_OFF, *FIN = OUT + FIN_OFF;
   DirArgs aF = dir_args(F), aB = dir_args(B);
-  int nbF = grid_for(F->n), nbB = grid_for(B->n), nt = (int)F->to->n, nbT = grid_for(nt);
+  const int nsF = aF.ps.nsrc, nsB = aB.ps.nsrc;
+  int nbF = grid_for(nsF), nbB = grid_for(nsB), nt = (int)F->to->n, nbT = grid_for(nt);
   int nb3 = std::max(nbF, nbT);
   NormD ident = to_dev((const lrr_icp_norm *)nullptr);
   // F1
@@ -2272,21 +2412,20 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   // order statistics: ranks of the strength jobs come from the device-side counts
   SelJob *hj = ctx->h_jobs;
   int nj = 0;
-  auto job = [&](const double *k0, int n0, const double *k1, int n1, bool counted, int a0, int a1, int b0, int b1) {
-    SelJob j{};
-    j.k0 = k0; j.n0 = n0; j.k1 = k1; j.n1 = n1; j.k = -1; j.out = SEL + 4 * nj;
+  auto job = [&](const double *k0, int n0, const double *k1, int n1, long long m, bool counted, int a0, int a1, int b0, int b1) {
+    SelJob j = make_job(k0, n0, k1, n1, -1, m);
+    j.out = SEL + 4 * nj;
     j.cnt = counted ? P4 : nullptr; j.cnt_a0 = a0; j.cnt_a1 = a1; j.cnt_b0 = b0; j.cnt_b1 = b1;
-    j.m_fixed = (long long)n0 + n1;
     hj[nj++] = j;
   };
   if (o->rrl) {
-    job(F->key_g, aF.n, nullptr, 0, true, 0, nbF, 0, 0);
-    job(B->key_g, aB.n, nullptr, 0, true, nbF, nbF + nbB, 0, 0);
-    job(F->key_s, aF.n, nullptr, 0, false, 0, 0, 0, 0);
-    job(B->key_s, aB.n, nullptr, 0, false, 0, 0, 0, 0);
+    job(F->key_g, nsF, nullptr, 0, 0, true, 0, nbF, 0, 0);
+    job(B->key_g, nsB, nullptr, 0, 0, true, nbF, nbF + nbB, 0, 0);
+    job(F->key_s, nsF, nullptr, 0, F->n, false, 0, 0, 0, 0);
+    job(B->key_s, nsB, nullptr, 0, B->n, false, 0, 0, 0, 0);
   } else {
-    job(F->key_g, aF.n, B->key_g, aB.n, true, 0, nbF, nbF, nbF + nbB);
-    job(F->key_s, aF.n, B->key_s, aB.n, false, 0, 0, 0, 0);
+    job(F->key_g, nsF, B->key_g, nsB, 0, true, 0, nbF, nbF, nbF + nbB);
+    job(F->key_s, nsF, B->key_s, nsB, F->n + B->n, false, 0, 0, 0, 0);
   }
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, hj, sizeof(SelJob) * nj, hipMemcpyHostToDevice, st));
   { int rc = launch_select_kth(ctx, nj); if (rc) return rc; }
@@ -2323,37 +2462,56 @@ int lrr_icp_get_matches(lrr_icp_dir *d, int64_t *from_idx, int64_t *to_idx, doub
   int64_t n = d->n;
   if (n == 0) return LRR_ICP_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<int> tmp((size_t)n);
-  if (from_idx) {
-    HIPCHK(ctx, hipMemcpy(tmp.data(), d->m_from, sizeof(int) * n, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; ++i) from_idx[i] = tmp[(size_t)i];
+  long long *df = nullptr, *dt = nullptr;
+  double *dw = nullptr;
+  int rc = LRR_ICP_OK;
+  if (hipMalloc(&df, sizeof(long long) * n) != hipSuccess || hipMalloc(&dt, sizeof(long long) * n) != hipSuccess ||
+      hipMalloc(&dw, sizeof(double) * n) != hipSuccess)
+    rc = fail(ctx, LRR_ICP_ERR_HIP, "get_matches: hipMalloc failed");
+  if (!rc) {
+    int nsrc = (int)d->from->n;
+    hipLaunchKernelGGL(k_export, dim3(blocks_for(nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->m_to, d->w, d->from->orig_of, d->to->orig_of, nsrc, df, dt, dw);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "get_matches: export failed");
   }
-  if (to_idx) {
-    HIPCHK(ctx, hipMemcpy(tmp.data(), d->m_to, sizeof(int) * n, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < n; ++i) to_idx[i] = tmp[(size_t)i];
-  }
-  if (w) HIPCHK(ctx, hipMemcpy(w, d->w, sizeof(double) * n, hipMemcpyDeviceToHost));
-  return LRR_ICP_OK;
+  static_assert(sizeof(long long) == sizeof(int64_t), "int64 layout");
+  if (!rc && from_idx && hipMemcpy(from_idx, df, sizeof(int64_t) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "get_matches: download failed");
+  if (!rc && to_idx && hipMemcpy(to_idx, dt, sizeof(int64_t) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "get_matches: download failed");
+  if (!rc && w && hipMemcpy(w, dw, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "get_matches: download failed");
+  if (df) (void)hipFree(df);
+  if (dt) (void)hipFree(dt);
+  if (dw) (void)hipFree(dw);
+  return rc;
 }
 
 int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int method, int64_t *idx) {
-  if (!cloud || nq < 0 || (nq > 0 && (!query || !idx))) return LRR_ICP_ERR_ARG;
+  if (!cloud || nq < 0 || nq > 0x3fffffff || (nq > 0 && (!query || !idx))) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = cloud->ctx;
   if (nq == 0) return LRR_ICP_OK;
+  if (cloud->n <= 0) { for (int64_t i = 0; i < nq; ++i) idx[i] = -1; return LRR_ICP_OK; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_lists(ctx, (size_t)nq);
+  if (rc) return rc;
   double *dq = nullptr;
   int *dto = nullptr;
   HIPCHK(ctx, hipMalloc(&dq, sizeof(double) * 3 * nq));
   if (hipMalloc(&dto, sizeof(int) * nq) != hipSuccess) { (void)hipFree(dq); return fail(ctx, LRR_ICP_ERR_HIP, "nearest: hipMalloc failed"); }
-  int rc = LRR_ICP_OK;
   if (hipMemcpy(dq, query, sizeof(double) * 3 * nq, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: upload failed");
+  if (!rc && hipMemsetAsync(ctx->d_counts, 0, 4 * sizeof(int), ctx->stream) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: memset failed");
   if (!rc) {
-    QuerySrc qs;
-    qs.rec = dq; qs.stride = 3; qs.order = nullptr; qs.use_keys = 0; qs.nsrc = (int)nq; qs.half = 1;
-    std::memset(&qs.keys, 0, sizeof qs.keys);
+    GridView g = view_of(cloud);
+    QSrc q;
+    q.src = nullptr; q.raw = dq; q.want_orig = 1;
+    Keys kk;
+    std::memset(&kk, 0, sizeof kk);
+    XfD x = identity_xf();
     if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
-    rc = launch_match(ctx, cloud, nullptr, qs, identity_xf(), (int)nq, method, nullptr, dto, nullptr);
+    ProfScope prof(ctx);
+    if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, cloud, g, q, nullptr, x, (int)nq, dto);
+    else {
+      hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, ctx->d_hard, ctx->d_counts);
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: launch failed");
+      if (!rc) rc = launch_hard_phases(ctx, g, q, x, (int)nq, dto);
+    }
   }
   std::vector<int> tmp((size_t)nq);
   if (!rc && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(tmp.data(), dto, sizeof(int) * nq, hipMemcpyDeviceToHost) != hipSuccess))
