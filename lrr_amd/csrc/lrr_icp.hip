@@ -50,6 +50,7 @@ constexpr int kTile = 8;             // canonical order: tiles of kTile^3 grid c
 constexpr int kScanUnroll = 8;       // candidate loads in flight per lane in the global-memory grid search
 constexpr int kEasyBudget = 48;      // candidate points a lane may scan in the thread-per-query global search
 constexpr int kRingMax = 8;          // rings walked by the wave-per-query phase before the brute-force fallback
+constexpr int kTileBudget = 96;      // candidates a lane may scan from LDS before handing its query over
 constexpr int kTileCap = 2048;       // target points a block may stage in LDS (64 KB) ...
 constexpr int kTileRows = 256;       // ... spread over at most this many (z,y) rows of the target grid
 constexpr int kTileNx = 20;          // ... of at most this many cells each
@@ -445,24 +446,28 @@ __global__ __launch_bounds__(kBlock) void k_match_direct(GridView g, QSrc q, con
   map_loc(xf, x, y, z, yx, yy, yz);
   Best b;
   if (grid_search_easy(g, yx, yy, yz, kEasyBudget, b)) m_to[s] = result_index(q, b);
-  else {
-    m_to[s] = -1;
-    hard[atomicAdd(hard_count, 1)] = s;
-  }
+  else hard[atomicAdd(hard_count, 1)] = s;  // m_to[s] keeps the previous match (cloud queries)
 }
 
 // K1, dense form (fine levels): one block per chunk of <= 256 consecutive canonical source
 // features, all from one 8x8x8-cell tile of the SOURCE grid, so their mapped positions fall into
-// a small box of the TARGET grid.  The block stages that box (+1 cell all round) in LDS with
-// coalesced row-run copies, then every lane searches rings 0..1 from LDS: the divergent,
-// dependent accesses of the ring search cost LDS latency instead of a memory round trip each.
-// slot[s] = perm^-1(original index) keeps the match LIST identical to the direct form.
-// Blocks whose box does not fit (degenerate transforms) and queries ring 1 does not settle go to
-// the wave-per-query kernel.
+// a small box of the TARGET grid.  The block stages that box in LDS with coalesced row-run
+// copies, then every lane searches from LDS: the divergent, dependent accesses of the search cost
+// LDS latency instead of a memory round trip each.
+//
+// Search region of a lane.  m_to[s] still holds the source's match of the PREVIOUS iteration (any
+// target feature is a valid upper bound; under ICP's small updates it is nearly the new nearest
+// neighbour): with it, the nearest neighbour lies in the ball of that radius around the query,
+// so the lane scans exactly the cells meeting that ball (box-pruned by the running best) and
+// needs no stopping test.  Without a previous match it scans ring 0, then ring 1, with the usual
+// interior-face test.  slot[s] = perm^-1(original index) keeps the match LIST identical to the
+// direct form.  Lanes whose region is wide, chunks whose box does not fit, unsettled and
+// over-budget queries go to the wave-per-query kernel.
 __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoint *src, const Chunk *chunks,
                                                        Keys keys, int half, int nsrc, int n_points, XfD xf,
-                                                       int *slot, int *m_to, double *w, int *hard,
-                                                       int *hard_count) {
+                                                       const double *to_rec, const int *to_orig_of, int *slot,
+                                                       int *m_to, double *w, int *hard, int *hard_count,
+                                                       int budget) {
   __shared__ double px[kTileCap], py[kTileCap], pz[kTileCap];
   __shared__ int pcan[kTileCap], porig[kTileCap];
   __shared__ int row_goff[kTileRows], row_loff[kTileRows + 1];
@@ -470,15 +475,19 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
   __shared__ int box[6], wave_tot[kBlock / 64];
   const Chunk ck = chunks[blockIdx.x];
   const int t = threadIdx.x, s = ck.start + t;
-  bool active = false;
+  bool active = false, has_prev = false, to_hard = false;
   double yx = 0, yy = 0, yz = 0;
   int cx = 0, cy = 0, cz = 0;
+  int ra[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, rb[3] = {-1, -1, -1};  // this lane's cell region
+  Best b;
+  b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
   if (t == 0) { box[0] = box[2] = box[4] = 0x7fffffff; box[1] = box[3] = box[5] = -1; }
   __syncthreads();
   if (t < ck.count) {
     SrcPoint sp = src[s];
     int j = subset_perm_inv((int)sp.orig, nsrc, half, keys);
     active = j < n_points;
+    int prev = m_to[s];
     slot[s] = active ? j : -1;
     if (active) {
       w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
@@ -486,11 +495,32 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
       cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
       cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
       cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
+      double rad = g.h;  // no previous match: rings 0..1
+      if (prev >= 0) {
+        const double *q = to_rec + (size_t)prev * kRecStride;
+        b.d = dist2(yx, yy, yz, q[0], q[1], q[2]);
+        b.orig = to_orig_of[prev];
+        b.canon = prev;
+        has_prev = true;
+        rad = sqrt(b.d) + 2.0 * g.tol;
+      }
+      if (rad > 2.0 * g.h) to_hard = true;  // wide region (outlier): better served by a whole wavefront
+      else if (has_prev) {
+        ra[0] = clampi((int)floor((yx - rad - g.lox) * g.inv_h), 0, g.dx - 1); rb[0] = clampi((int)floor((yx + rad - g.lox) * g.inv_h), 0, g.dx - 1);
+        ra[1] = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1); rb[1] = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
+        ra[2] = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1); rb[2] = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
+      } else {
+        ra[0] = max(cx - 1, 0); rb[0] = min(cx + 1, g.dx - 1);
+        ra[1] = max(cy - 1, 0); rb[1] = min(cy + 1, g.dy - 1);
+        ra[2] = max(cz - 1, 0); rb[2] = min(cz + 1, g.dz - 1);
+      }
     }
   }
-  {  // bounding box of the active queries' cells: wave min/max by shuffles, one LDS atomic per wave
-    int lo3[3] = {active ? cx : 0x7fffffff, active ? cy : 0x7fffffff, active ? cz : 0x7fffffff};
-    int hi3[3] = {active ? cx : -1, active ? cy : -1, active ? cz : -1};
+  const bool searching = active && !to_hard;
+  {  // bounding box of the searching lanes' regions: wave min/max by shuffles, one LDS atomic per wave
+    int lo3[3], hi3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo3[k] = searching ? ra[k] : 0x7fffffff; hi3[k] = searching ? rb[k] : -1; }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
@@ -503,10 +533,9 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
       for (int k = 0; k < 3; ++k) { atomicMin(&box[2 * k], lo3[k]); atomicMax(&box[2 * k + 1], hi3[k]); }
   }
   __syncthreads();
-  if (box[1] < 0) return;  // no active query in this chunk (uniform)
-  const int x0 = max(box[0] - 1, 0), x1 = min(box[1] + 1, g.dx - 1);
-  const int y0 = max(box[2] - 1, 0), y1 = min(box[3] + 1, g.dy - 1);
-  const int z0 = max(box[4] - 1, 0), z1 = min(box[5] + 1, g.dz - 1);
+  if (active && to_hard) hard[atomicAdd(hard_count, 1)] = s;  // m_to[s] keeps the previous match: a bound for phase 2
+  if (box[1] < 0) return;  // no searching lane in this chunk (uniform)
+  const int x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3], z0 = box[4], z1 = box[5];
   const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1, nrows = ny * nz;
   bool fits = nx <= kTileNx && nrows <= kTileRows;
   // row table: global start and length of every (z,y) row's x-run, exclusive prefix -> LDS offsets
@@ -533,8 +562,8 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
   if (fits && t < nrows) row_loff[t] = before + incl - cnt;
   if (t == 0) row_loff[fits ? nrows : 0] = total;
   fits = fits && total <= kTileCap;
-  if (!fits) {  // uniform: hand every active query of the chunk over
-    if (active) { m_to[s] = -1; hard[atomicAdd(hard_count, 1)] = s; }
+  if (!fits) {  // uniform: hand every searching query of the chunk over
+    if (searching) hard[atomicAdd(hard_count, 1)] = s;
     return;
   }
   // per-row cell boundaries relative to the row start; loads issued in batches so that several
@@ -585,72 +614,110 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
       }
   }
   __syncthreads();
-  if (!active) return;
-  // ring search from LDS
-  Best b;
-  b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
+  if (!searching) return;
+  // search from LDS; 4 candidates are read before any is compared (LDS latency paid once per 4)
+  bool over_budget = false;
 #define LDS_SCAN(R, XA, XB)                                                          \
   {                                                                                  \
     int base_ = row_loff[R];                                                         \
-    for (int j_ = base_ + cso[R][(XA) - x0], e_ = base_ + cso[R][(XB) + 1 - x0]; j_ < e_; ++j_) \
-      consider(b, dist2(yx, yy, yz, px[j_], py[j_], pz[j_]), porig[j_], pcan[j_]);   \
+    int j_ = base_ + cso[R][(XA) - x0], e_ = base_ + cso[R][(XB) + 1 - x0];         \
+    budget -= e_ - j_;                                                               \
+    if (budget < 0) { over_budget = true; j_ = e_; }                                 \
+    for (; j_ < e_; j_ += 4) {                                                       \
+      double qx_[4], qy_[4], qz_[4];                                                 \
+      int qo_[4], qc_[4];                                                            \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                             \
+        int k_ = min(j_ + u_, e_ - 1);                                               \
+        qx_[u_] = px[k_]; qy_[u_] = py[k_]; qz_[u_] = pz[k_]; qo_[u_] = porig[k_]; qc_[u_] = pcan[k_]; \
+      }                                                                              \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)                               \
+        if (j_ + u_ < e_) consider(b, dist2(yx, yy, yz, qx_[u_], qy_[u_], qz_[u_]), qo_[u_], qc_[u_]); \
+    }                                                                                \
   }
-  {
-    int r = (cz - z0) * ny + (cy - y0);
-    LDS_SCAN(r, cx, cx)
-  }
-  bool done = ring_settled(ring_bound(g, cx, cy, cz, 0, yx, yy, yz), g.tol, b.d);
+  // the query's own cell first: it usually holds the answer and tightens the pruning radius
+  LDS_SCAN((cz - z0) * ny + (cy - y0), cx, cx)
+  bool done = false;
+  if (!has_prev) done = ring_settled(ring_bound(g, cx, cy, cz, 0, yx, yy, yz), g.tol, b.d);
   if (!done) {
-    for (int z = max(cz - 1, 0); z <= min(cz + 1, g.dz - 1); ++z) {
+    for (int z = ra[2]; z <= rb[2]; ++z) {
       double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
       double dz2 = gz_ * gz_;
       if (dz2 > b.d) continue;
-      for (int y = max(cy - 1, 0); y <= min(cy + 1, g.dy - 1); ++y) {
+      for (int y = ra[1]; y <= rb[1]; ++y) {
         double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
         double dyz2 = dz2 + gy_ * gy_;
         if (dyz2 > b.d) continue;
         int r = (z - z0) * ny + (y - y0);
-        if (z != cz || y != cy) {
-          int xa = max(cx - 1, 0), xb = min(cx + 1, g.dx - 1);
-          if (b.d < INFINITY) {
-            double rad = sqrt(b.d - dyz2) + 2.0 * g.tol;
-            xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
-            xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
-          }
-          if (xa <= xb) LDS_SCAN(r, xa, xb)
-        } else {
-          if (cx - 1 >= 0) {
-            double gx_ = slab_gap(yx, g.lox + (cx - 1) * g.h, g.lox + cx * g.h, g.tol);
-            if (dyz2 + gx_ * gx_ <= b.d) LDS_SCAN(r, cx - 1, cx - 1)
-          }
-          if (cx + 1 <= g.dx - 1) {
-            double gx_ = slab_gap(yx, g.lox + (cx + 1) * g.h, g.lox + (cx + 2) * g.h, g.tol);
-            if (dyz2 + gx_ * gx_ <= b.d) LDS_SCAN(r, cx + 1, cx + 1)
-          }
+        // x-run of the region narrowed by the best distance; the own cell is skipped
+        int xa = ra[0], xb = rb[0];
+        if (b.d < INFINITY) {
+          double rad = sqrt(b.d - dyz2) + 2.0 * g.tol;
+          xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
+          xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
         }
+        if (z == cz && y == cy) {
+          if (xa <= cx - 1) LDS_SCAN(r, xa, cx - 1)
+          if (cx + 1 <= xb) LDS_SCAN(r, cx + 1, xb)
+        } else if (xa <= xb) LDS_SCAN(r, xa, xb)
       }
     }
-    done = ring_settled(ring_bound(g, cx, cy, cz, 1, yx, yy, yz), g.tol, b.d);
+    // with a previous match the scanned ball provably holds the nearest neighbour
+    done = !over_budget && (has_prev || ring_settled(ring_bound(g, cx, cy, cz, 1, yx, yy, yz), g.tol, b.d));
   }
 #undef LDS_SCAN
   if (done) m_to[s] = (b.orig == 0x7fffffff) ? 0 : b.canon;
-  else {
-    m_to[s] = -1;
-    hard[atomicAdd(hard_count, 1)] = s;
-  }
+  else hard[atomicAdd(hard_count, 1)] = s;
 }
 
 // K1 phase 2: the queries phase 1 handed over (far from any target feature, next to cells too
-// dense for one lane, or in a chunk whose box did not fit LDS).  One WAVEFRONT per query.  For
-// ring r the up to 2(2r+1)^2 cell runs (a whole x-run for shell rows, the two end cells for
-// interior rows) are taken 64 at a time: each lane box-prunes one run and fetches its
-// [start, end) range, a wave prefix sum turns the runs into one candidate list, and the lanes
-// stride over THAT list (binary search in LDS from candidate number to run) — every lane busy
-// whatever the point distribution.  Lanes are merged by a lexicographic (distance, index)
-// shuffle reduction; same stopping rule, so the result is the same exact nearest neighbour.
+// dense for one lane, without a previous match, or in a chunk whose box did not fit LDS).  One
+// WAVEFRONT per query.  Cell runs (an x-run of one (z,y) row) are taken 64 at a time: each lane
+// box-prunes one run and fetches its [start, end) range, a wave prefix sum turns the runs into one
+// candidate list, and the lanes stride over THAT list (binary search in LDS from candidate number
+// to run) — every lane busy whatever the point distribution; lanes are merged by a
+// lexicographic (distance, index) shuffle reduction.  With a previous match (use_prev) the runs
+// are the rows of the ball of that radius and the result is final; otherwise ring r = 0, 1, ...
+// with the interior-face stopping rule.  Same exact nearest neighbour either way.
+__device__ __forceinline__ void wave_scan_runs(const GridView &g, int (*seg_s)[64], int (*seg_pre)[64], int wv,
+                                               int lane, int s0, int e0, double yx, double yy, double yz,
+                                               Best &b) {
+  int c0 = e0 - s0, incl = c0;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  int total = __shfl(incl, 63, 64);
+  if (total <= 0) return;
+  seg_s[wv][lane] = s0;
+  seg_pre[wv][lane] = incl - c0;
+  __builtin_amdgcn_wave_barrier();
+  Best l;  // this lane's best in the chunk
+  l.d = INFINITY; l.orig = 0x7fffffff; l.canon = 0;
+  for (int c = lane; c < total; c += 64) {
+    int lo = 0, hi = 64;  // last run whose exclusive prefix is <= c
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+      int mid = (lo + hi) >> 1;
+      if (seg_pre[wv][mid] <= c) lo = mid; else hi = mid;
+    }
+    GridPoint pt = g.gp[seg_s[wv][lo] + (c - seg_pre[wv][lo])];
+    consider(l, dist2(yx, yy, yz, pt.x, pt.y, pt.z), pt.orig, pt.canon);
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double d2 = __shfl_xor(l.d, off, 64);
+    int o2 = __shfl_xor(l.orig, off, 64), c2 = __shfl_xor(l.canon, off, 64);
+    consider(l, d2, o2, c2);
+  }
+  consider(b, l.d, l.orig, l.canon);
+}
+
 __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QSrc q, XfD xf, const int *hard,
-                                                       const int *hard_count, int *m_to, int *overflow,
-                                                       int *overflow_count) {
+                                                       const int *hard_count, int use_prev,
+                                                       const double *to_rec, const int *to_orig_of, int *m_to,
+                                                       int *overflow, int *overflow_count) {
   __shared__ int seg_s[kBlock / 64][64], seg_pre[kBlock / 64][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
@@ -666,6 +733,37 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QSrc q, XfD x
     Best b;  // wave-uniform best so far
     b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
     bool done = false;
+    int prev = use_prev ? m_to[s] : -1;
+    if (prev >= 0) {
+      const double *pq = to_rec + (size_t)prev * kRecStride;
+      b.d = dist2(yx, yy, yz, pq[0], pq[1], pq[2]);
+      b.orig = to_orig_of[prev];
+      b.canon = prev;
+      double rad = sqrt(b.d) + 2.0 * g.tol;
+      int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
+      int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
+      int nyb = yb - ya + 1, nitems = (zb - za + 1) * nyb;
+      if (nitems <= 64 * 64) {  // the rows of the ball; otherwise fall back to the ring search
+        for (int base = 0; base < nitems; base += 64) {
+          int t = base + lane, s0 = 0, e0 = 0;
+          if (t < nitems) {
+            int z = za + t / nyb, y = ya + t % nyb;
+            double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
+            double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
+            double dyz2 = gz_ * gz_ + gy_ * gy_;
+            if (dyz2 <= b.d) {
+              double rx = sqrt(b.d - dyz2) + 2.0 * g.tol;
+              int xa = clampi((int)floor((yx - rx - g.lox) * g.inv_h), 0, g.dx - 1);
+              int xb = clampi((int)floor((yx + rx - g.lox) * g.inv_h), 0, g.dx - 1);
+              int row = (z * g.dy + y) * g.dx;
+              s0 = g.cell_start[row + xa]; e0 = g.cell_start[row + xb + 1];
+            }
+          }
+          wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b);
+        }
+        done = true;
+      }
+    }
     for (int r = 0; r <= kRingMax && !done; ++r) {
       const int side = 2 * r + 1, nitems = 2 * side * side;
       for (int base = 0; base < nitems; base += 64) {
@@ -700,38 +798,7 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QSrc q, XfD x
             }
           }
         }
-        int c0 = e0 - s0, incl = c0;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          int v = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += v;
-        }
-        int total = __shfl(incl, 63, 64);
-        if (total > 0) {
-          seg_s[wv][lane] = s0;
-          seg_pre[wv][lane] = incl - c0;
-          __builtin_amdgcn_wave_barrier();
-          Best l;  // this lane's best in the chunk
-          l.d = INFINITY; l.orig = 0x7fffffff; l.canon = 0;
-          for (int c = lane; c < total; c += 64) {
-            int lo = 0, hi = 64;  // last run whose exclusive prefix is <= c
-#pragma unroll
-            for (int step = 0; step < 6; ++step) {
-              int mid = (lo + hi) >> 1;
-              if (seg_pre[wv][mid] <= c) lo = mid; else hi = mid;
-            }
-            GridPoint pt = g.gp[seg_s[wv][lo] + (c - seg_pre[wv][lo])];
-            consider(l, dist2(yx, yy, yz, pt.x, pt.y, pt.z), pt.orig, pt.canon);
-          }
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) {
-            double d2 = __shfl_xor(l.d, off, 64);
-            int o2 = __shfl_xor(l.orig, off, 64), c2 = __shfl_xor(l.canon, off, 64);
-            consider(l, d2, o2, c2);
-          }
-          consider(b, l.d, l.orig, l.canon);
-        }
+        wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b);
       }
       done = ring_settled(ring_bound(g, cx, cy, cz, r, yx, yy, yz), g.tol, b.d);
     }
@@ -1680,10 +1747,10 @@ unsigned host_fmix32(unsigned h) {
 
 // phases 2 and 3 of the grid search; both read their list length on the device and fall through
 // when it is 0
-int launch_hard_phases(lrr_icp_ctx *ctx, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to) {
+int launch_hard_phases(lrr_icp_ctx *ctx, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to) {
   int *hard_count = ctx->d_counts, *over_count = ctx->d_counts + 1;
   int hard_blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)n + 3) / 4));
-  hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, ctx->stream, g, q, xf, ctx->d_hard, hard_count, m_to, ctx->d_overflow, over_count);
+  hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, ctx->stream, g, q, xf, ctx->d_hard, hard_count, q.src ? 1 : 0, to->rec, to->orig_of, m_to, ctx->d_overflow, over_count);
   HIPCHK(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, ctx->stream, g, q, xf, ctx->d_overflow, over_count, m_to);
   HIPCHK(ctx, hipGetLastError());
@@ -1974,7 +2041,8 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
   if (hipMalloc(&d->flag, sizeof(unsigned) * d->flag_cap) != hipSuccess) { delete d; return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: hipMalloc failed"); }
   int rc = ensure_dir_capacity(d);
   if (rc) { lrr_icp_dir_destroy(d); return rc; }
-  if (hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, ctx->stream) != hipSuccess) { lrr_icp_dir_destroy(d); return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: memset failed"); }
+  if (hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(d->m_to, 0xff, sizeof(int) * d->cap, ctx->stream) != hipSuccess) { lrr_icp_dir_destroy(d); return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: memset failed"); }
   *out = d;
   return LRR_ICP_OK;
 }
@@ -1998,6 +2066,7 @@ int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
   int rc = ensure_dir_capacity(d);
   if (rc) return rc;
   HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d->m_to, 0xff, sizeof(int) * d->cap, ctx->stream));
   return LRR_ICP_OK;
 }
 
@@ -2094,13 +2163,13 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
     return launch_brute(ctx, d->to, g, q, ctx->d_active, x, (int)n_points, d->m_to);
   }
   if (dense) {
-    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts);
+    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts, std::getenv("LRR_ICP_TILE_BUDGET") ? std::atoi(std::getenv("LRR_ICP_TILE_BUDGET")) : kTileBudget);
   } else {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
     hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, g, q, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, x, (int)n_points, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  return launch_hard_phases(ctx, g, q, x, (int)n_points, d->m_to);
+  return launch_hard_phases(ctx, d->to, g, q, x, (int)n_points, d->m_to);
 }
 
 int lrr_icp_premap(lrr_icp_dir *d, const lrr_icp_xform *G) {
@@ -2510,7 +2579,7 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
     else {
       hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, ctx->d_hard, ctx->d_counts);
       if (hipGetLastError() != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: launch failed");
-      if (!rc) rc = launch_hard_phases(ctx, g, q, x, (int)nq, dto);
+      if (!rc) rc = launch_hard_phases(ctx, cloud, g, q, x, (int)nq, dto);
     }
   }
   std::vector<int> tmp((size_t)nq);
