@@ -50,7 +50,7 @@ constexpr int kTile = 8;             // canonical order: tiles of kTile^3 grid c
 constexpr int kScanUnroll = 8;       // candidate loads in flight per lane in the global-memory grid search
 constexpr int kEasyBudget = 48;      // candidate points a lane may scan in the thread-per-query global search
 constexpr int kRingMax = 8;          // rings walked by the wave-per-query phase before the brute-force fallback
-constexpr int kTileBudget = 96;      // candidates a lane may scan from LDS before handing its query over
+constexpr int kTileBudget = 48;      // candidates a lane may scan from LDS before handing its query over
 constexpr int kTileCap = 2048;       // target points a block may stage in LDS (64 KB) ...
 constexpr int kTileRows = 256;       // ... spread over at most this many (z,y) rows of the target grid
 constexpr int kTileNx = 20;          // ... of at most this many cells each
@@ -2163,7 +2163,7 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
     return launch_brute(ctx, d->to, g, q, ctx->d_active, x, (int)n_points, d->m_to);
   }
   if (dense) {
-    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts, std::getenv("LRR_ICP_TILE_BUDGET") ? std::atoi(std::getenv("LRR_ICP_TILE_BUDGET")) : kTileBudget);
+    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts, kTileBudget);
   } else {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
     hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, g, q, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, x, (int)n_points, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts);
