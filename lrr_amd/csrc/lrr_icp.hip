@@ -43,7 +43,7 @@
 namespace {
 
 constexpr int kBlock = 256;          // 4 wavefronts of 64
-constexpr int kMaxBlocks = 512;      // reduction grids: 2 blocks / CU on 256 CUs
+constexpr int kMaxBlocks = 2048;     // reduction grids: 8 blocks / CU on 256 CUs (one dependent gather chain per thread)
 constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 for dof 12)
 constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
 constexpr int kTile = 8;             // canonical order: tiles of kTile^3 grid cells
@@ -58,10 +58,12 @@ constexpr int kSelThreads = 1024;
 constexpr int kMaxSelJobs = 32;
 constexpr int kProfEvents = 4096;
 constexpr int kSelHistBlocks = 64;   // blocks per job and pass of the multi-block radix select
-// fused scratch: P1 (2*512 x 5), P2 (512 x 4), P3 (512 x 2), P4 (2*512 x 1), P6 (2*512 x 96), output block
-constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * 512 * 5, kFusedP3 = kFusedP2 + 512 * 4,
-              kFusedP4 = kFusedP3 + 512 * 2, kFusedP6 = kFusedP4 + 2 * 512, kFusedOut = kFusedP6 + 2 * 512 * 96,
-              kFusedDoubles = kFusedOut + 256;
+// fused scratch: P1 (2*kMaxBlocks x 5), P2 (kMaxBlocks x 4), P3 (kMaxBlocks x 2), P4 (2*kMaxBlocks x 1),
+// P6 (2*256 x 96), output block
+constexpr int kAccBlocks = 256;      // accumulate grid per direction (90 fp64 accumulators per thread: 2 waves/SIMD)
+constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * kMaxBlocks * 5, kFusedP3 = kFusedP2 + kMaxBlocks * 4,
+              kFusedP4 = kFusedP3 + kMaxBlocks * 2, kFusedP6 = kFusedP4 + 2 * kMaxBlocks,
+              kFusedOut = kFusedP6 + 2 * kAccBlocks * 96, kFusedDoubles = kFusedOut + 256;
 
 // one candidate of the search grid: 32 B = two 16-B loads
 struct GridPoint { double x, y, z; int canon, orig; };
@@ -468,8 +470,7 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
                                                        const double *to_rec, const int *to_orig_of, int *slot,
                                                        int *m_to, double *w, int *hard, int *hard_count,
                                                        int budget) {
-  __shared__ double px[kTileCap], py[kTileCap], pz[kTileCap];
-  __shared__ int pcan[kTileCap], porig[kTileCap];
+  __shared__ GridPoint lp[kTileCap];  // staged candidates, AoS: one candidate = two 16-B LDS reads
   __shared__ int row_goff[kTileRows], row_loff[kTileRows + 1];
   __shared__ unsigned short cso[kTileRows][kTileNx + 1];
   __shared__ int box[6], wave_tot[kBlock / 64];
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
     for (int u = 0; u < kTileCap / kBlock; ++u)
       if (addr[u] >= 0) {
         int c = t + u * kBlock;
-        px[c] = pt[u].x; py[c] = pt[u].y; pz[c] = pt[u].z; pcan[c] = pt[u].canon; porig[c] = pt[u].orig;
+        lp[c] = pt[u];
       }
   }
   __syncthreads();
@@ -624,14 +625,10 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
     budget -= e_ - j_;                                                               \
     if (budget < 0) { over_budget = true; j_ = e_; }                                 \
     for (; j_ < e_; j_ += 4) {                                                       \
-      double qx_[4], qy_[4], qz_[4];                                                 \
-      int qo_[4], qc_[4];                                                            \
-      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                             \
-        int k_ = min(j_ + u_, e_ - 1);                                               \
-        qx_[u_] = px[k_]; qy_[u_] = py[k_]; qz_[u_] = pz[k_]; qo_[u_] = porig[k_]; qc_[u_] = pcan[k_]; \
-      }                                                                              \
+      GridPoint c_[4];                                                               \
+      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) c_[u_] = lp[min(j_ + u_, e_ - 1)]; \
       _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)                               \
-        if (j_ + u_ < e_) consider(b, dist2(yx, yy, yz, qx_[u_], qy_[u_], qz_[u_]), qo_[u_], qc_[u_]); \
+        if (j_ + u_ < e_) consider(b, dist2(yx, yy, yz, c_[u_].x, c_[u_].y, c_[u_].z), c_[u_].orig, c_[u_].canon); \
     }                                                                                \
   }
   // the query's own cell first: it usually holds the answer and tightens the pruning radius
@@ -2499,7 +2496,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, hj, sizeof(SelJob) * nj, hipMemcpyHostToDevice, st));
   { int rc = launch_select_kth(ctx, nj); if (rc) return rc; }
   // F6 + final reduction
-  int nbAF = std::min(nbF, 256), nbAB = std::min(nbB, 256);
+  int nbAF = std::min(nbF, kAccBlocks), nbAB = std::min(nbB, kAccBlocks);
   const double *c = o->jac_centre;
   const int nt2 = o->dof * (o->dof + 1) / 2, K = nt2 + o->dof;
   if (o->dof == 12 && o->rrl) hipLaunchKernelGGL((k_f_accumulate<12, true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
