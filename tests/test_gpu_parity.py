@@ -242,3 +242,27 @@ def test_full_size_properties_200k(E):
     Ti = synth.Transform(A, t, c).inverse()
     assert rel(Ab, Ti.A) < 1e-10 and rel(tb, Ti.t) < 1e-10  # backward = inverse(forward)
     e.close()
+
+
+def test_locations_driver_against_oracle(E, ob):
+    """config 5 driver (lrr_amd/locations.py): every location's final transform and iteration
+    count equal the oracle's run of the same location"""
+    from lrr_amd import locations, multi_gpu
+    pair = synth.make_pair(40000, 40000, 20247, kind="affine")
+    rois = synth.query_rois(pair, 4, 20247, half=50.0)
+    inits = [synth.perturbed(pair.planted, 100 + i) for i in range(len(rois))]
+    rows, pairs = locations.register_locations(pair, rois, inits, seed=19)
+    assert rows.shape == (4, multi_gpu.RESULT_WIDTH) and pairs > 0
+    c = None
+    for i, (_, _, mi, fi) in enumerate(rois):
+        m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[i]
+        if c is None:
+            c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                                   moving_inside=m_in, fixed_inside=f_in, seed=19)
+        else:
+            c.set_features(m_in, f_in)
+            c.set_transform(T0.A, T0.t, T0.c)
+        conv, its = c.run(locations.MAX_ITERATIONS)
+        A, t, cc, _ = c.get_transform()
+        assert int(rows[i, 19]) == i and bool(rows[i, 0]) == conv and int(rows[i, 1]) == its
+        assert rel(rows[i, 2:11].reshape(3, 3), A) < 1e-6 and rel(rows[i, 11:14], t) < 1e-6
