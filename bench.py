@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--workload", choices=["c3", "locations"], default="c3",
                     help="c3: the BASELINE metric (default); locations: config 5, independent query locations sharded over the ranks")
     ap.add_argument("--locations", type=int, default=256)
+    ap.add_argument("--workers", type=int, default=4, help="host threads (device contexts) per rank in the locations workload")
     return ap.parse_args()
 
 
@@ -98,7 +99,8 @@ def bench_locations(args, rank, local_rank, world):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rows, pairs = locations.register_locations(pair, rois, inits, rank, world, gather_device=dev)
+    rows, pairs = locations.register_locations(pair, rois, inits, rank, world, gather_device=dev,
+                                               workers=args.workers, device_index=local_rank)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -115,7 +117,7 @@ def bench_locations(args, rank, local_rank, world):
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{len(rois)} query locations (50 mm ROIs) x {args.n}-feature volume pair, "
                                    "symmetric ICP to convergence per location (<= 70 iterations)",
-                       "parallelism": f"{world} rank(s), static blocks of locations, one all_gather"},
+                       "parallelism": f"{world} rank(s) x {args.workers} host thread(s), static blocks of locations, one all_gather"},
             "locations_per_s": len(rois) / dt, "converged": int(rows[:, 0].sum()),
             "mean_iterations": float(rows[:, 1].mean()), "roofline": None, "cpu_baseline": None}))
     if world > 1:

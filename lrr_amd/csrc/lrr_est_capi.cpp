@@ -112,9 +112,10 @@ struct est_base {
   virtual void inject_initial_scale(double f, double b) = 0;
   virtual void set_subset_order(int dir, const int64_t *order, int64_t n) = 0;
   virtual void set_nn_method(int m) = 0;
+  virtual void set_subset_seed(uint64_t seed) = 0;
   virtual void find_closest_euclidean() = 0;
   virtual bool one_iteration(unsigned it) = 0;
-  virtual bool run(unsigned max_it, unsigned *done) = 0;
+  virtual bool run(unsigned max_it, unsigned *done, int64_t *pairs) = 0;
   virtual void estimate_LS(bool) = 0;
   virtual void estimate_LS_backward(bool) = 0;
   virtual void get_transform(int dir, double *A, double *t, double *c, double *covar) = 0;
@@ -157,14 +158,15 @@ struct fwd_impl : est_base {
   void inject_initial_scale(double f, double) override { e->inject_initial_scale(f); }
   void set_subset_order(int, const int64_t *order, int64_t n) override { e->set_subset_order(std::vector<int64_t>(order, order + n)); }
   void set_nn_method(int m) override { e->set_nn_method(m); }
+  void set_subset_seed(uint64_t seed) override { e->set_subset_seed(seed); }
   void find_closest_euclidean() override { e->find_closest_euclidean(); }
   bool one_iteration(unsigned it) override { return e->one_iteration(0, 0, it); }
-  bool run(unsigned max_it, unsigned *done) override {
+  bool run(unsigned max_it, unsigned *done, int64_t *pairs) override {
     // run() of the reference hard-codes 30 iterations (cdcl .txx:419)
     bool conv = false;
     unsigned it = 0;
     e->initialize();
-    while (!conv && it < max_it) { conv = e->one_iteration(0, 0, it); ++it; }
+    while (!conv && it < max_it) { conv = e->one_iteration(0, 0, it); ++it; if (pairs) *pairs += e->number_points(); }
     if (done) *done = it;
     return conv;
   }
@@ -208,13 +210,18 @@ struct sym_impl : est_base {
   void inject_initial_scale(double f, double b) override { e->inject_initial_scale(f, b); }
   void set_subset_order(int dir, const int64_t *order, int64_t n) override { d(dir).set_subset_order(std::vector<int64_t>(order, order + n)); }
   void set_nn_method(int m) override { e->set_nn_method(m); }
+  void set_subset_seed(uint64_t seed) override { e->set_subset_seed(seed); }
   void find_closest_euclidean() override { e->find_closest_euclidean(); }
   bool one_iteration(unsigned it) override { return e->one_iteration(0, 0, it); }
-  bool run(unsigned max_it, unsigned *done) override {
+  bool run(unsigned max_it, unsigned *done, int64_t *pairs) override {
     // the caller's loop (rrl/itkLocationRegistration.cxx:2418): the class's own run() is a stub
     bool conv = false;
     unsigned it = 0;
-    while (!conv && it < max_it) { conv = e->one_iteration(0, 0, it); ++it; }
+    while (!conv && it < max_it) {
+      if (pairs) *pairs += e->forward().number_points() + e->backward().number_points();
+      conv = e->one_iteration(0, 0, it);
+      ++it;
+    }
     if (done) *done = it;
     return conv;
   }
@@ -316,7 +323,10 @@ int lrr_est_set_subset_order(lrr_est *e, int dir, const int64_t *order, int64_t 
 int lrr_est_set_nn_method(lrr_est *e, int m) { return guard([&] { E(e)->set_nn_method(m); }); }
 int lrr_est_find_closest_euclidean(lrr_est *e) { return guard([&] { E(e)->find_closest_euclidean(); }); }
 int lrr_est_one_iteration(lrr_est *e, unsigned it, int *converged) { return guard([&] { bool c = E(e)->one_iteration(it); if (converged) *converged = c ? 1 : 0; }); }
-int lrr_est_run(lrr_est *e, unsigned max_it, unsigned *done, int *converged) { return guard([&] { bool c = E(e)->run(max_it, done); if (converged) *converged = c ? 1 : 0; }); }
+int lrr_est_run(lrr_est *e, unsigned max_it, unsigned *done, int *converged) { return guard([&] { bool c = E(e)->run(max_it, done, nullptr); if (converged) *converged = c ? 1 : 0; }); }
+// same loop, also counting the matched pairs formed (sum over iterations of the active subset sizes)
+int lrr_est_run_counted(lrr_est *e, unsigned max_it, unsigned *done, int *converged, int64_t *pairs) { return guard([&] { if (pairs) *pairs = 0; bool c = E(e)->run(max_it, done, pairs); if (converged) *converged = c ? 1 : 0; }); }
+int lrr_est_set_subset_seed(lrr_est *e, uint64_t seed) { return guard([&] { E(e)->set_subset_seed(seed); }); }
 int lrr_est_estimate_LS(lrr_est *e, int p) { return guard([&] { E(e)->estimate_LS(p != 0); }); }
 int lrr_est_estimate_LS_backward(lrr_est *e, int p) { return guard([&] { E(e)->estimate_LS_backward(p != 0); }); }
 int lrr_est_get_transform(lrr_est *e, int dir, double *A, double *t, double *c, double *covar) { return guard([&] { E(e)->get_transform(dir, A, t, c, covar); }); }

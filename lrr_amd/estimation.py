@@ -109,6 +109,8 @@ def est_lib() -> C.CDLL:
         L.lrr_est_find_closest_euclidean.argtypes = [C.c_void_p]
         L.lrr_est_one_iteration.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
         L.lrr_est_run.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+        L.lrr_est_run_counted.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_int), _ip]
+        L.lrr_est_set_subset_seed.argtypes = [C.c_void_p, C.c_uint64]
         L.lrr_est_estimate_LS.argtypes = [C.c_void_p, C.c_int]
         L.lrr_est_estimate_LS_backward.argtypes = [C.c_void_p, C.c_int]
         L.lrr_est_get_transform.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
@@ -295,6 +297,15 @@ class Estimator:
         n, conv = C.c_uint(0), C.c_int(0)
         self._ck(est_lib().lrr_est_run(self._h, max_iterations, C.byref(n), C.byref(conv)))
         return bool(conv.value), int(n.value)
+
+    def run_counted(self, max_iterations=70):
+        """run() + the number of matched pairs formed over its iterations"""
+        n, conv, pairs = C.c_uint(0), C.c_int(0), C.c_int64(0)
+        self._ck(est_lib().lrr_est_run_counted(self._h, max_iterations, C.byref(n), C.byref(conv), C.byref(pairs)))
+        return bool(conv.value), int(n.value), int(pairs.value)
+
+    def set_subset_seed(self, seed):
+        self._ck(est_lib().lrr_est_set_subset_seed(self._h, int(seed)))
 
     def estimate_LS(self, estimate_parameters=True):
         self._ck(est_lib().lrr_est_estimate_LS(self._h, int(estimate_parameters)))

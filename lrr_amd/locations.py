@@ -17,14 +17,15 @@ from . import multi_gpu, synth
 MAX_ITERATIONS = 70  # rrl/itkLocationRegistration.cxx:2413-2418
 
 
-def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1,
-                       seed: int = 7, gather_device=None):
-    """rois: list of (centre_fixed, centre_moving, moving_idx, fixed_idx) (synth.query_rois);
-    inits: list of synth.Transform, the initial transform of every location.
-    Returns (rows of multi_gpu.RESULT_WIDTH for ALL locations, matched pairs processed by this rank)."""
+def location_seed(seed: int, index: int) -> int:
+    return (int(seed) * 1000003 + int(index) * 7919 + 1) & 0xFFFFFFFFFFFFFFFF
+
+
+def _run_block(pair, rois, inits, indices, seed):
+    """One estimator object re-used over `indices` (a host thread = one device context)."""
     est = None
     rows, pairs = [], 0
-    for i in multi_gpu.shard(len(rois), rank, world):
+    for i in indices:
         _, _, mi, fi = rois[i]
         m_in, f_in = pair.moving.subset(mi), pair.fixed.subset(fi)
         T0 = inits[i]
@@ -34,14 +35,43 @@ def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world
         else:
             est.set_features(m_in, f_in)
             est.set_transform(T0.A, T0.t, T0.c)
-        converged, it = False, 0
-        while not converged and it < MAX_ITERATIONS:
-            converged = est.one_iteration(it)
-            pairs += est.number_points(0) + est.number_points(1)
-            it += 1
+        # the subset permutations of a location depend only on (seed, location): results do not
+        # depend on which rank / thread / estimator object handles it
+        est.set_subset_seed(location_seed(seed, i))
+        converged, it, p = est.run_counted(MAX_ITERATIONS)  # the caller's loop, in C++ (no GIL held)
+        pairs += p
         A, t, c, _ = est.get_transform()
         rows.append(multi_gpu.pack_result(i, converged, it, A, t, c, est.weighted_error(), est.RMS_error()))
     if est is not None:
         est.close()
+    return rows, pairs
+
+
+def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1,
+                       seed: int = 7, gather_device=None, workers: int = 1, device_index=None):
+    """rois: list of (centre_fixed, centre_moving, moving_idx, fixed_idx) (synth.query_rois);
+    inits: list of synth.Transform, the initial transform of every location.
+    workers > 1: the rank's block is dealt round-robin to that many host threads, each with its own
+    device context and estimator (a single small problem leaves the GPU mostly idle: the iterations
+    of a 1-3k-feature ROI are kernel-boundary bound), so their streams overlap.  Every location is
+    estimated by exactly one estimator started from its own initial transform: results do not
+    depend on `workers`.
+    Returns (rows of multi_gpu.RESULT_WIDTH for ALL locations, matched pairs processed by this rank)."""
+    mine = list(multi_gpu.shard(len(rois), rank, world))
+    if workers <= 1 or len(mine) <= 1:
+        rows, pairs = _run_block(pair, rois, inits, mine, seed)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def work(k):
+            if device_index is not None:
+                E.set_device(device_index)  # contexts are per host thread
+            return _run_block(pair, rois, inits, mine[k::workers], seed)
+
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            parts = list(pool.map(work, range(workers)))
+        rows = [r for p in parts for r in p[0]]
+        rows.sort(key=lambda r: r[19])
+        pairs = sum(p[1] for p in parts)
     local = np.stack(rows) if rows else np.zeros((0, multi_gpu.RESULT_WIDTH))
     return multi_gpu.gather_results(local, len(rois), device=gather_device), pairs

@@ -253,16 +253,15 @@ def test_locations_driver_against_oracle(E, ob):
     inits = [synth.perturbed(pair.planted, 100 + i) for i in range(len(rois))]
     rows, pairs = locations.register_locations(pair, rois, inits, seed=19)
     assert rows.shape == (4, multi_gpu.RESULT_WIDTH) and pairs > 0
-    c = None
     for i, (_, _, mi, fi) in enumerate(rois):
         m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[i]
-        if c is None:
-            c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
-                                   moving_inside=m_in, fixed_inside=f_in, seed=19)
-        else:
-            c.set_features(m_in, f_in)
-            c.set_transform(T0.A, T0.t, T0.c)
+        # every location has its own subset seed, so a fresh oracle estimator per location is equivalent
+        c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                               moving_inside=m_in, fixed_inside=f_in, seed=locations.location_seed(19, i))
         conv, its = c.run(locations.MAX_ITERATIONS)
         A, t, cc, _ = c.get_transform()
         assert int(rows[i, 19]) == i and bool(rows[i, 0]) == conv and int(rows[i, 1]) == its
         assert rel(rows[i, 2:11].reshape(3, 3), A) < 1e-6 and rel(rows[i, 11:14], t) < 1e-6
+    # the partition over threads / ranks does not change any location's result
+    rows2, _ = locations.register_locations(pair, rois, inits, seed=19, workers=3, device_index=0)
+    assert np.array_equal(rows, rows2)
