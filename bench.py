@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--nn", choices=["grid", "brute"], default="grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on fewer GPUs)")
     ap.add_argument("--workload", choices=["c3", "locations"], default="c3",
                     help="c3: the BASELINE metric (default); locations: config 5, independent query locations sharded over the ranks")
     ap.add_argument("--locations", type=int, default=256)
@@ -93,7 +95,7 @@ def bench_locations(args, rank, local_rank, world):
     pair = synth.make_pair(args.n, args.n, 20245, kind="affine")  # same volumes on every rank
     rois = synth.query_rois(pair, args.locations, 20245, half=25.0)
     inits = [synth.perturbed(pair.planted, 1000 + i) for i in range(len(rois))]
-    dev = torch.device("cuda", local_rank) if world > 1 else None
+    dev = (torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")) if world > 1 else None
     locations.register_locations(pair, rois[: max(1, world)], inits, 0, 1)  # warm-up: libraries, kernels
     if world > 1:
         dist.barrier()
@@ -105,7 +107,7 @@ def bench_locations(args, rank, local_rank, world):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt, float(pairs)], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=dev if dev is not None else "cuda")
     if world > 1:
         dist.all_reduce(tt[0:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(tt[1:2], op=dist.ReduceOp.SUM)
@@ -134,9 +136,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ICP hot path has no CPU fallback")
+    local_rank = local_rank % torch.cuda.device_count()  # rehearsals run several ranks on one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from lrr_amd import estimation as E
     from lrr_amd import multi_gpu, synth
@@ -185,10 +191,11 @@ def main():
     A, t, c, _ = est.get_transform()
     row = multi_gpu.pack_result(rank, True, it, A, t, c, est.weighted_error(), est.RMS_error())
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cdev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        rows = multi_gpu.gather_results(row[None], world, device=torch.device("cuda", local_rank))
+        rows = multi_gpu.gather_results(row[None], world, device=cdev)
     else:
         rows = row[None]
 
@@ -218,7 +225,7 @@ def main():
                        "nn": args.nn, "schedule_iterations_before_timing": schedule_iters,
                        "parallelism": f"{world} independent problem(s), one per GPU; one all_gather of the final transforms"},
             "roofline": {"bound": "hbm",
-                         "kernel": ("K1 find_closest_euclidean = k_match_grid_coherent + k_match_hard + k_match_overflow"
+                         "kernel": ("K1 find_closest_euclidean = k_match_tile + k_match_hard + k_match_overflow"
                                     if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),

@@ -121,6 +121,8 @@ struct lrr_icp_cloud {
   int *canon_of = nullptr;      // original -> canonical index
   GridPoint *gp = nullptr;      // n, sorted by grid cell (raster z,y,x): the search structure
   int *cell_start = nullptr;    // ncell + 1
+  int *fine_start = nullptr;    // ncell * fine + 1: every cell cut into `fine` slices along x (ball search)
+  int fine = 1;
   Chunk *chunks = nullptr; int nchunks = 0;
   double lo[3] = {0, 0, 0}, h = 1.0, inv_h = 1.0, tol = 0.0;
   int dim[3] = {1, 1, 1};
@@ -131,6 +133,7 @@ struct lrr_icp_dir {
   lrr_icp_cloud *from = nullptr, *to = nullptr;
   int64_t cap = 0;   // allocated length of the per-source arrays (>= from->n)
   int64_t n = 0;     // active matches
+  int64_t prev_n = -1;  // subset size of the last grid match on this source cloud (-1: none): m_to is a valid bound for those
   int *slot = nullptr;   // list position of source s, -1 when s is not in the active subset
   int *m_to = nullptr;   // canonical target index
   double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
@@ -164,8 +167,9 @@ struct Keys { unsigned k[4]; };
 struct GridView {
   const GridPoint *gp;   // points sorted by grid cell
   const int *cell_start;
+  const int *fine_start;  // cells cut into `fine` x-slices; points of a cell are sorted by slice
   double lox, loy, loz, h, inv_h, tol;
-  int dx, dy, dz, n;
+  int dx, dy, dz, n, fine;
 };
 
 __device__ __forceinline__ void map_loc(const XfD &T, double x0, double x1, double x2, double &y0,
@@ -664,6 +668,104 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
 #undef LDS_SCAN
   if (done) m_to[s] = (b.orig == 0x7fffffff) ? 0 : b.canon;
   else hard[atomicAdd(hard_count, 1)] = s;
+}
+
+// K1, dense form with previous matches (later iterations of a level): one THREAD per canonical
+// source feature, searching global memory.  m_to[s] holds the match of the previous iteration
+// (any target feature is a valid upper bound; under ICP's small updates it is nearly the new
+// nearest neighbour): the nearest neighbour lies in the ball of that radius around the mapped
+// feature, so the lane needs no stopping test.  It walks the (z,y) rows of cells meeting the
+// ball — rows are h x h wide, so there are few — and in each row takes the x-run of the ball at
+// the resolution of the x-SLICES (h / fine): few candidates per row.  All slice bounds of up to
+// kBallRows rows are fetched in one round trip, then the candidates of the concatenated runs
+// kScanUnroll loads at a time.  Four dependent memory levels per query (source + previous index,
+// previous point, slice bounds, candidates) with every query of the launch resident at once.
+// Lanes without a previous match, with a ball wider than kBallCells cells or more than `budget`
+// candidates go to the wave-per-query kernel.
+constexpr int kBallRows = 9;        // (z,y) rows whose cell bounds a lane fetches in one round trip
+constexpr int kBallBudget = 64;     // candidates a lane may scan before handing its query over
+constexpr double kBallCells = 2.0;  // widest ball (in cells) the thread-per-query search takes
+__global__ __launch_bounds__(kBlock) void k_match_ball(GridView g, const SrcPoint *src, Keys keys, int half,
+                                                       int nsrc, int n_points, XfD xf, const double *to_rec,
+                                                       const int *to_orig_of, int *slot, const int *m_prev, int *m_to, double *w,
+                                                       int *hard, int *hard_count, int budget, double max_rad) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= nsrc) return;
+  const SrcPoint sp = src[s];
+  const int prev = m_prev[s];
+  const int j = subset_perm_inv((int)sp.orig, nsrc, half, keys);
+  const bool active = j < n_points;
+  slot[s] = active ? j : -1;
+  if (!active) return;
+  w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+  if (prev < 0) { hard[atomicAdd(hard_count, 1)] = s; return; }
+  double yx, yy, yz;
+  map_loc(xf, sp.x, sp.y, sp.z, yx, yy, yz);
+  Best b;
+  {
+    const double *q = to_rec + (size_t)prev * kRecStride;
+    b.d = dist2(yx, yy, yz, q[0], q[1], q[2]);
+    b.orig = to_orig_of[prev];
+    b.canon = prev;
+  }
+  const double rad = sqrt(b.d) + 2.0 * g.tol;
+  if (!(rad <= max_rad)) { hard[atomicAdd(hard_count, 1)] = s; return; }  // outlier: a whole wavefront serves it better
+  const double inv_hx = g.inv_h * g.fine;
+  const int fdx = g.dx * g.fine;  // x-slices per row
+  const int xa0 = clampi((int)floor((yx - rad - g.lox) * inv_hx), 0, fdx - 1), xb0 = clampi((int)floor((yx + rad - g.lox) * inv_hx), 0, fdx - 1);
+  const int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
+  const int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
+  const int nyr = yb - ya + 1, nrows = nyr * (zb - za + 1);
+  int yi = ya, zi = za;  // (z,y) of row r0: advanced without integer division
+  for (int r0 = 0; r0 < nrows; r0 += kBallRows) {
+    int rs[kBallRows], re[kBallRows];
+#pragma unroll
+    for (int u = 0; u < kBallRows; ++u) {
+      rs[u] = 0; re[u] = 0;
+      if (r0 + u < nrows) {
+        const double gz_ = slab_gap(yz, g.loz + zi * g.h, g.loz + (zi + 1) * g.h, g.tol);
+        const double gy_ = slab_gap(yy, g.loy + yi * g.h, g.loy + (yi + 1) * g.h, g.tol);
+        const double dyz2 = gz_ * gz_ + gy_ * gy_;
+        if (dyz2 <= b.d) {  // strictly farther rows cannot hold a better or an equal candidate
+          // half-width of the ball in this row, rounded UP (single-precision root, 1 ulp, plus margin)
+          const double rx = (double)(__builtin_amdgcn_sqrtf((float)(b.d - dyz2)) * 1.000002f) + 2.0 * g.tol;
+          const int xa = max(xa0, (int)floor((yx - rx - g.lox) * inv_hx)), xb = min(xb0, (int)floor((yx + rx - g.lox) * inv_hx));
+          if (xa <= xb) {
+            const int row = (zi * g.dy + yi) * fdx;
+            rs[u] = g.fine_start[row + xa];
+            re[u] = g.fine_start[row + xb + 1];
+          }
+        }
+        if (++yi > yb) { yi = ya; ++zi; }
+      }
+    }
+    // candidate c of the concatenated runs sits at c + off[u], off[u] = rs[u] - pre[u], for the last
+    // run u with pre[u] <= c: a telescoping sum of compare-selects, no register indexing
+    int pre[kBallRows], dl[kBallRows], total = 0;
+#pragma unroll
+    for (int u = 0; u < kBallRows; ++u) {
+      pre[u] = total;
+      dl[u] = (rs[u] - total) - (u ? rs[u - 1] - pre[u - 1] : 0);
+      total += re[u] - rs[u];
+    }
+    budget -= total;
+    if (budget < 0) { hard[atomicAdd(hard_count, 1)] = s; return; }  // m_to[s] keeps the previous match
+    for (int c0 = 0; c0 < total; c0 += kScanUnroll) {
+      GridPoint pt[kScanUnroll];
+#pragma unroll
+      for (int v = 0; v < kScanUnroll; ++v) {
+        const int c = min(c0 + v, total - 1);
+        int addr = c + dl[0];
+#pragma unroll
+        for (int u = 1; u < kBallRows; ++u) addr += c >= pre[u] ? dl[u] : 0;
+        pt[v] = g.gp[addr];
+      }
+#pragma unroll
+      for (int v = 0; v < kScanUnroll; ++v)
+        if (c0 + v < total) consider(b, dist2(yx, yy, yz, pt[v].x, pt[v].y, pt[v].z), pt[v].orig, pt[v].canon);
+    }
+  }
+  m_to[s] = b.canon;
 }
 
 // K1 phase 2: the queries phase 1 handed over (far from any target feature, next to cells too
@@ -1623,7 +1725,7 @@ XfD identity_xf() {
 
 GridView view_of(const lrr_icp_cloud *c) {
   GridView g;
-  g.gp = c->gp; g.cell_start = c->cell_start;
+  g.gp = c->gp; g.cell_start = c->cell_start; g.fine_start = c->fine_start; g.fine = c->fine;
   g.lox = c->lo[0]; g.loy = c->lo[1]; g.loz = c->lo[2];
   g.h = c->h; g.inv_h = c->inv_h; g.tol = c->tol;
   g.dx = c->dim[0]; g.dy = c->dim[1]; g.dz = c->dim[2];
@@ -1953,7 +2055,13 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
   for (int d = 0; d < 3; ++d) { c->lo[d] = lo[d]; c->dim[d] = dim[d]; }
   c->tol = 1e-9 * (maxabs + maxext + h);
   const size_t m = (size_t)std::max<int64_t>(n, 1);
-  std::vector<int> cell(m), start((size_t)ncell + 1, 0);
+  // x-slices per cell: rows stay h x h wide in (y,z) (few rows per ball) while the x-run of a ball
+  // is cut at h/fine resolution (few candidates per row)
+  int fine = 8;
+  if (const char *e = std::getenv("LRR_ICP_GRID_FINE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) { fine = 1; while (fine * 2 <= v) fine *= 2; } }
+  while (fine > 1 && ncell * fine > (int64_t)1 << 25) fine >>= 1;
+  c->fine = fine;
+  std::vector<int> cell(m), slice(m), start((size_t)ncell + 1, 0), fstart((size_t)ncell * fine + 1, 0);
   std::vector<unsigned long long> key(m);  // (tile, cell): the canonical order
   const int tdx = (dim[0] + kTile - 1) / kTile, tdy = (dim[1] + kTile - 1) / kTile;
   for (int64_t i = 0; i < n; ++i) {
@@ -1965,10 +2073,16 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
     int id = (cc[2] * dim[1] + cc[1]) * dim[0] + cc[0];
     cell[(size_t)i] = id;
     start[(size_t)id + 1]++;
+    // floor(fine * a) / fine == floor(a) for a power of two: the slice lies inside the point's cell; the clamp covers the grid boundary
+    int xf = (int)std::floor((loc[3 * i] - lo[0]) * (c->inv_h * fine));  // same expression as the kernels (fine is a power of two: exact)
+    xf = std::min(std::max(xf, cc[0] * fine), cc[0] * fine + fine - 1);
+    slice[(size_t)i] = id * fine + (xf - cc[0] * fine);
+    fstart[(size_t)slice[(size_t)i] + 1]++;
     unsigned long long tile = (unsigned long long)(((cc[2] / kTile) * tdy + cc[1] / kTile) * tdx + cc[0] / kTile);
     key[(size_t)i] = (tile << 32) | (unsigned)id;
   }
   for (int64_t k = 0; k < ncell; ++k) start[(size_t)k + 1] += start[(size_t)k];
+  for (int64_t k = 0; k < ncell * fine; ++k) fstart[(size_t)k + 1] += fstart[(size_t)k];
   std::vector<int> orig_of(m, 0), canon_of(m, 0);
   for (int64_t i = 0; i < n; ++i) orig_of[(size_t)i] = (int)i;
   std::sort(orig_of.begin(), orig_of.begin() + n, [&](int a, int b) { return key[(size_t)a] != key[(size_t)b] ? key[(size_t)a] < key[(size_t)b] : a < b; });
@@ -1990,10 +2104,10 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
       chunks.push_back(Chunk{(int)s, 0});
     chunks.back().count++;
   }
-  std::vector<int> cursor(start.begin(), start.end() - 1);
+  std::vector<int> cursor(fstart.begin(), fstart.end() - 1);
   std::vector<GridPoint> gp(m);
-  for (int64_t i = 0; i < n; ++i) {  // ascending i: original order kept inside a cell
-    int pos = cursor[(size_t)cell[(size_t)i]]++;
+  for (int64_t i = 0; i < n; ++i) {  // ascending i: original order kept inside a slice
+    int pos = cursor[(size_t)slice[(size_t)i]]++;
     gp[(size_t)pos] = GridPoint{loc[3 * i], loc[3 * i + 1], loc[3 * i + 2], canon_of[(size_t)i], (int)i};
   }
   c->nchunks = (int)chunks.size();
@@ -2003,6 +2117,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
       hipMalloc(&c->orig_of, sizeof(int) * m) != hipSuccess || hipMalloc(&c->canon_of, sizeof(int) * m) != hipSuccess ||
       hipMalloc(&c->gp, sizeof(GridPoint) * m) != hipSuccess ||
       hipMalloc(&c->cell_start, sizeof(int) * ((size_t)ncell + 1)) != hipSuccess ||
+      hipMalloc(&c->fine_start, sizeof(int) * fstart.size()) != hipSuccess ||
       hipMalloc(&c->chunks, sizeof(Chunk) * chunks.size()) != hipSuccess)
     return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
   if (hipMemcpy(c->rec, rec.data(), sizeof(double) * m * kRecStride, hipMemcpyHostToDevice) != hipSuccess ||
@@ -2011,6 +2126,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
       hipMemcpy(c->canon_of, canon_of.data(), sizeof(int) * m, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->gp, gp.data(), sizeof(GridPoint) * m, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->fine_start, fstart.data(), sizeof(int) * fstart.size(), hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(c->chunks, chunks.data(), sizeof(Chunk) * chunks.size(), hipMemcpyHostToDevice) != hipSuccess)
     return cleanup(LRR_ICP_ERR_HIP, "cloud_create: upload failed");
   *out = c;
@@ -2020,7 +2136,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
 void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
-  void *ptrs[] = {c->rec, c->src, c->orig_of, c->canon_of, c->gp, c->cell_start, c->chunks};
+  void *ptrs[] = {c->rec, c->src, c->orig_of, c->canon_of, c->gp, c->cell_start, c->fine_start, c->chunks};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
@@ -2059,6 +2175,7 @@ int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   d->from = from;
   d->n = 0;
+  d->prev_n = -1;
   d->from_is_copy = 0;
   int rc = ensure_dir_capacity(d);
   if (rc) return rc;
@@ -2159,7 +2276,12 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
     HIPCHK(ctx, hipGetLastError());
     return launch_brute(ctx, d->to, g, q, ctx->d_active, x, (int)n_points, d->m_to);
   }
-  if (dense) {
+  // a level's later iterations: every active source carries its previous match -> ball search
+  const bool steady = dense && d->prev_n == n_points;
+  d->prev_n = dense ? n_points : -1;
+  if (steady) {
+    hipLaunchKernelGGL(k_match_ball, dim3(blocks_for(N)), dim3(kBlock), 0, st, g, d->from->src, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->m_to, d->w, ctx->d_hard, ctx->d_counts, kBallBudget, kBallCells * g.h);
+  } else if (dense) {
     hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts, kTileBudget);
   } else {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));

@@ -74,4 +74,6 @@ def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world
         rows.sort(key=lambda r: r[19])
         pairs = sum(p[1] for p in parts)
     local = np.stack(rows) if rows else np.zeros((0, multi_gpu.RESULT_WIDTH))
+    if world == 1:  # also a single-rank call made inside a multi-rank job (bench warm-up): no collective
+        return local, pairs
     return multi_gpu.gather_results(local, len(rois), device=gather_device), pairs
