@@ -57,7 +57,9 @@ constexpr int kTileNx = 20;          // ... of at most this many cells each
 constexpr int kSelThreads = 1024;
 constexpr int kMaxSelJobs = 32;
 constexpr int kProfEvents = 4096;
-constexpr int kSelHistBlocks = 64;   // blocks per job and pass of the multi-block radix select
+constexpr int kSelCap = 8192;        // keys of one window bin the final block can select from in LDS
+constexpr int kSelStates = 16;      // remembered results (window centres)
+constexpr int kSelHistBlocks = 128;  // blocks per job of the chip-wide select kernels (<= kSelPre keys per thread up to 262k keys)
 // fused scratch: P1 (2*kMaxBlocks x 5), P2 (kMaxBlocks x 4), P3 (kMaxBlocks x 2), P4 (2*kMaxBlocks x 1),
 // P6 (2*256 x 96), output block
 constexpr int kAccBlocks = 256;      // accumulate grid per direction (90 fp64 accumulators per thread: 2 waves/SIMD)
@@ -70,7 +72,7 @@ struct GridPoint { double x, y, z; int canon, orig; };
 // one source feature in canonical order
 struct SrcPoint { double x, y, z; long long orig; };
 struct Chunk { int start, count; };  // <= kBlock consecutive canonical features of ONE tile
-struct SelState { unsigned long long prefix, mask; long long k, m; };  // radix-select progress of one job
+struct SelState { int bin, count; long long k, k_in_bin, m; };  // window bin holding rank k of one job
 
 struct SelJob {
   const double *k0; int n0;
@@ -80,6 +82,7 @@ struct SelJob {
   const double *cnt;               // per-block partial counts (1 double per row) or nullptr
   int cnt_a0, cnt_a1, cnt_b0, cnt_b1;  // two row ranges whose sum is m
   long long m_fixed;               // m when cnt == nullptr
+  int state;                       // slot of the previous result that centres the window (< 0: none)
 };
 
 }  // namespace
@@ -95,7 +98,10 @@ struct lrr_icp_ctx {
   SelJob *d_jobs = nullptr;
   SelJob *h_jobs = nullptr;
   SelState *d_selstate = nullptr;
-  int *d_selhist = nullptr;      // kMaxSelJobs x 2048
+  int *d_selhist = nullptr;      // kMaxSelJobs x 2048, zero between selections
+  double *d_selprev = nullptr;   // kSelStates previous results
+  unsigned long long *d_selcoll = nullptr;  // kMaxSelJobs x kSelCap gathered keys
+  int *d_selcursor = nullptr;    // kMaxSelJobs, zero between selections
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
   double *h_fused = nullptr;
   // K1 scratch
@@ -1331,10 +1337,17 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(PairSrc ps, NormD nm, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact order statistics on the (non-negative) double bit patterns: 6-pass MSB radix select.
-// k_select: one 1024-thread block per job, LDS histogram, also sums the keys below the k-th
-// (needed by the trimmed MUSE scale; first estimate only).  k_sel_*: the same passes spread over
-// the chip for the per-iteration MAD scales.  Stand in for std::nth_element / std::sort.
+// exact order statistics on the (non-negative) double bit patterns; stand in for
+// std::nth_element / std::sort.
+// k_select: one 1024-thread block per job, 6-pass MSB radix select with an LDS histogram; also
+// sums the keys below the k-th (needed by the trimmed MUSE scale; first estimate only).
+// k_selw_*: the per-iteration MAD scales in three launches.  The keys' bit patterns are binned in
+// a 2048-bin WINDOW around the job's previous result (the scales move little between ICP
+// iterations): 128 bins per binade, 8 binades either side, everything outside in the two end
+// bins.  hist: chip-wide histogram of the window.  collect: every block re-derives the bin holding
+// rank k and the keys of that bin are gathered (a few hundred).  final: one block per job selects
+// the exact k-th among them in LDS.  If the rank falls into an end bin or the bin is too full for
+// LDS, the final block runs the full radix select over all keys instead — slow, still exact.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long job_key(const SelJob &j, int i) {
   double v = i < j.n0 ? j.k0[i] : j.k1[i - j.n0];
@@ -1358,14 +1371,20 @@ __device__ __forceinline__ void hist_add(int *hist, bool act, int dgt) {
   if (act) atomicAdd(&hist[dgt], 1);
 }
 
-// every thread owns bins 2t, 2t+1 of a 2048-bin histogram: finds the bin holding rank k
-__device__ __forceinline__ void pick_bin(int h0, int h1, long long k, int *wave_tot, int *sel_bin, int *sel_before) {
-  int s = h0 + h1, incl = s;
+// Every thread owns B consecutive bins (v: their counts; B x blockDim.x = 2048): finds the bin
+// holding rank k.  sel[0] = bin, sel[1] = keys before it, sel[2] = keys in it; sel stays as preset
+// when k is out of range.
+template <int B>
+__device__ __forceinline__ void pick_from(const int (&v)[B], long long k, int *wave_tot, int *sel) {
+  int s = 0;
+#pragma unroll
+  for (int u = 0; u < B; ++u) s += v[u];
+  int incl = s;
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
+    int x = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += x;
   }
   if (lane == 63) wave_tot[wv] = incl;
   __syncthreads();
@@ -1373,26 +1392,28 @@ __device__ __forceinline__ void pick_bin(int h0, int h1, long long k, int *wave_
   for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
   int excl = before + incl - s;
   if (s > 0 && k >= excl && k < excl + s) {
-    if (k < excl + h0) { *sel_bin = 2 * threadIdx.x; *sel_before = excl; }
-    else { *sel_bin = 2 * threadIdx.x + 1; *sel_before = excl + h0; }
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      if (k >= excl && k < excl + v[u]) { sel[0] = B * (int)threadIdx.x + u; sel[1] = excl; sel[2] = v[u]; }
+      excl += v[u];
+    }
   }
   __syncthreads();
 }
+template <int T>
+__device__ __forceinline__ void pick_bin(const int *h, long long k, int *wave_tot, int *sel) {
+  constexpr int B = 2048 / T;
+  int v[B];
+#pragma unroll
+  for (int u = 0; u < B; ++u) v[u] = h[B * threadIdx.x + u];
+  pick_from<B>(v, k, wave_tot, sel);
+}
 
-__global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
-  __shared__ int hist[2048];
-  __shared__ int wave_tot[kSelThreads / 64];
-  __shared__ int sel_bin, sel_before;
-  __shared__ double red_s[kSelThreads / 64];
-  __shared__ double red_c[kSelThreads / 64];
-  SelJob job = jobs[blockIdx.x];
-  int n = job.n0 + job.n1;
-  long long k = job.k, m = job.m_fixed;
-  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
-  if (n <= 0 || k < 0 || k >= n) {
-    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m; }
-    return;
-  }
+// 6-pass MSB radix select of rank k among n keys by one kSelThreads block; returns the key.
+// hist: 2048 ints, wave_tot: kSelThreads / 64 ints, sel: 3 ints of LDS.
+template <typename KeyAt>
+__device__ __forceinline__ unsigned long long radix_select_block(KeyAt key_at, int n, long long k, int *hist,
+                                                                 int *wave_tot, int *sel) {
   unsigned long long prefix = 0, mask = 0;
   const int shifts[6] = {53, 42, 31, 20, 9, 0};
   const int widths[6] = {11, 11, 11, 11, 11, 9};
@@ -1405,19 +1426,37 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
       bool act = false;
       int dgt = 0;
       if (i < n) {
-        unsigned long long key = job_key(job, i);
+        unsigned long long key = key_at(i);
         act = (key & mask) == prefix;
         dgt = (int)((key >> shift) & (unsigned long long)(bins - 1));
       }
       hist_add(hist, act, dgt);
     }
     __syncthreads();
-    pick_bin(hist[2 * threadIdx.x], hist[2 * threadIdx.x + 1], k, wave_tot, &sel_bin, &sel_before);
-    prefix |= (unsigned long long)sel_bin << shift;
+    pick_bin<kSelThreads>(hist, k, wave_tot, sel);
+    prefix |= (unsigned long long)sel[0] << shift;
     mask |= (unsigned long long)(bins - 1) << shift;
-    k -= sel_before;
+    k -= sel[1];
     __syncthreads();
   }
+  return prefix;
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
+  __shared__ int hist[2048];
+  __shared__ int wave_tot[kSelThreads / 64];
+  __shared__ int sel[3];
+  __shared__ double red_s[kSelThreads / 64];
+  __shared__ double red_c[kSelThreads / 64];
+  SelJob job = jobs[blockIdx.x];
+  int n = job.n0 + job.n1;
+  long long k = job.k, m = job.m_fixed;
+  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
+  if (n <= 0 || k < 0 || k >= n) {
+    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m; }
+    return;
+  }
+  unsigned long long prefix = radix_select_block([&](int i) { return job_key(job, i); }, n, k, hist, wave_tot, sel);
   double value = __longlong_as_double((long long)prefix);
   double sum = 0.0, cnt = 0.0;
   for (int i = threadIdx.x; i < n; i += kSelThreads) {
@@ -1434,66 +1473,192 @@ __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_sel_init(const SelJob *jobs, SelState *st, int *hist) {
-  SelJob job = jobs[blockIdx.x];
-  long long m = job.m_fixed;
-  if (job.cnt) {
-    double tot = block_total(job.cnt, job.cnt_a0, job.cnt_a1, 1, 0) + block_total(job.cnt, job.cnt_b0, job.cnt_b1, 1, 0);
-    m = (long long)tot;
+// window of a job: 2048 bins of 2^shift bit patterns, centred on the previous result of the job's
+// state slot, else on the job's first finite positive key.  Same value in every thread and in
+// every kernel of the three (the keys do not change in between).
+struct SelWindow { unsigned long long lo; int shift; };
+__device__ __forceinline__ SelWindow job_window(const SelJob &job, const double *prev) {
+  __shared__ unsigned long long centre;
+  __shared__ int first;
+  double c = job.state >= 0 ? prev[job.state] : 0.0;
+  const bool remembered = c > 0.0 && c < INFINITY;  // uniform
+  if (threadIdx.x == 0) { centre = (unsigned long long)__double_as_longlong(remembered ? c : 1.0); first = 0x7fffffff; }
+  __syncthreads();
+  if (!remembered) {  // lowest-index finite positive key among the first 4096
+    int n = min(job.n0 + job.n1, 4096);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      double v = __longlong_as_double((long long)job_key(job, i));
+      if (v > 0.0 && v < INFINITY) { atomicMin(&first, i); break; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && first != 0x7fffffff) centre = job_key(job, first);
+    __syncthreads();
   }
-  long long k = job.k;
-  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
-  if (k >= (long long)job.n0 + job.n1) k = -1;
-  for (int b = threadIdx.x; b < 2048; b += kBlock) hist[blockIdx.x * 2048 + b] = 0;
-  if (threadIdx.x == 0) { SelState s0; s0.prefix = 0; s0.mask = 0; s0.k = k; s0.m = m; st[blockIdx.x] = s0; }
+  const unsigned long long cbits = centre;
+  SelWindow w;
+  // 128 bins per binade up to 512k keys; narrower bins for longer key lists keep the bin of the
+  // median within the LDS capacity of the final block
+  long long n = (long long)job.n0 + job.n1;
+  w.shift = 45;
+  for (long long lim = 524288; n > lim && w.shift > 40; lim <<= 1) --w.shift;
+  unsigned long long half = 1024ull << w.shift;
+  w.lo = cbits > half ? cbits - half : 0ull;
+  return w;
+}
+__device__ __forceinline__ int window_bin(const SelWindow &w, unsigned long long key) {
+  if (key < w.lo) return 0;
+  unsigned long long b = (key - w.lo) >> w.shift;
+  return b > 2047ull ? 2047 : (int)b;
 }
 
-__global__ __launch_bounds__(kBlock) void k_sel_hist(const SelJob *jobs, const SelState *st, int *hist, int shift, int bins) {
-  __shared__ int lh[2048];
-  SelJob job = jobs[blockIdx.y];
-  SelState s0 = st[blockIdx.y];
-  if (s0.k < 0) return;
-  for (int b = threadIdx.x; b < 2048; b += kBlock) lh[b] = 0;
-  __syncthreads();
+// the three kernels issue every load whose address they know (the block's first kSelPre keys per
+// thread, the remembered centre, the count partials, the histogram) before their first barrier: one
+// memory round trip instead of a chain of them
+constexpr int kSelPre = 8;
+struct KeySlice { int lo, hi; unsigned long long kv[kSelPre]; };
+__device__ __forceinline__ void load_slice(const SelJob &job, KeySlice &ks) {
   int n = job.n0 + job.n1;
   int per = (n + gridDim.x - 1) / gridDim.x;
-  int lo = blockIdx.x * per, hi = min(lo + per, n);
-  for (int base = lo; base < hi; base += kBlock) {
+  ks.lo = blockIdx.x * per; ks.hi = min(ks.lo + per, n);
+#pragma unroll
+  for (int u = 0; u < kSelPre; ++u) {
+    int i = ks.lo + (int)threadIdx.x + u * kBlock;
+    ks.kv[u] = i < ks.hi ? job_key(job, i) : 0ull;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_selw_hist(const SelJob *jobs, const double *prev, int *hist) {
+  __shared__ int lh[2048];
+  SelJob job = jobs[blockIdx.y];
+  KeySlice ks;
+  load_slice(job, ks);
+  for (int b = threadIdx.x; b < 2048; b += kBlock) lh[b] = 0;
+  SelWindow w = job_window(job, prev);  // barriers inside: lh is clear after it
+#pragma unroll
+  for (int u = 0; u < kSelPre; ++u) {
+    bool act = ks.lo + (int)threadIdx.x + u * kBlock < ks.hi;
+    hist_add(lh, act, act ? window_bin(w, ks.kv[u]) : 0);
+  }
+  for (int base = ks.lo + kSelPre * kBlock; base < ks.hi; base += kBlock) {
     int i = base + threadIdx.x;
-    bool act = false;
-    int dgt = 0;
-    if (i < hi) {
-      unsigned long long key = job_key(job, i);
-      act = (key & s0.mask) == s0.prefix;
-      dgt = (int)((key >> shift) & (unsigned long long)(bins - 1));
-    }
-    hist_add(lh, act, dgt);
+    bool act = i < ks.hi;
+    hist_add(lh, act, act ? window_bin(w, job_key(job, i)) : 0);
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < bins; b += kBlock) {
+  for (int b = threadIdx.x; b < 2048; b += kBlock) {
     int v = lh[b];
     if (v) atomicAdd(&hist[blockIdx.y * 2048 + b], v);  // integer: order-independent
   }
 }
 
-__global__ __launch_bounds__(kSelThreads) void k_sel_pick(const SelJob *jobs, SelState *st, int *hist, int shift, int bins, int last) {
+__global__ __launch_bounds__(kBlock) void k_selw_collect(const SelJob *jobs, const double *prev, const int *hist,
+                                                         SelState *st, unsigned long long *coll, int *cursor) {
+  __shared__ int wave_tot[kBlock / 64];
+  __shared__ int sel[3];
+  __shared__ double csh[kBlock / 64];
+  SelJob job = jobs[blockIdx.y];
+  KeySlice ks;
+  load_slice(job, ks);
+  int v[2048 / kBlock];
+#pragma unroll
+  for (int u = 0; u < 2048 / kBlock; ++u) v[u] = hist[blockIdx.y * 2048 + (2048 / kBlock) * threadIdx.x + u];
+  double csum = 0.0;  // counts are whole numbers: their sum is exact in any order
+  if (job.cnt) {
+    for (int b = job.cnt_a0 + (int)threadIdx.x; b < job.cnt_a1; b += kBlock) csum += job.cnt[b];
+    for (int b = job.cnt_b0 + (int)threadIdx.x; b < job.cnt_b1; b += kBlock) csum += job.cnt[b];
+  }
+  if (threadIdx.x == 0) { sel[0] = -1; sel[1] = 0; sel[2] = 0; }
+  SelWindow w = job_window(job, prev);
+  csum = wave_sum(csum);
+  if ((threadIdx.x & 63) == 0) csh[threadIdx.x >> 6] = csum;
+  __syncthreads();
+  long long m = job.m_fixed;
+  if (job.cnt) { double tot = 0.0; for (int w2 = 0; w2 < kBlock / 64; ++w2) tot += csh[w2]; m = (long long)tot; }
+  long long k = job.k;
+  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;  // rrel_util_median_abs_dev_scale's rank
+  if (k >= (long long)job.n0 + job.n1) k = -1;
+  if (k >= 0) pick_from<2048 / kBlock>(v, k, wave_tot, sel);  // k is uniform
+  const int bin = sel[0], before = sel[1], count = sel[2];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    SelState s0;
+    s0.bin = bin; s0.count = count; s0.k = k; s0.k_in_bin = k - before; s0.m = m;
+    st[blockIdx.y] = s0;
+  }
+  if (k < 0 || bin <= 0 || bin >= 2047 || count > kSelCap) return;  // nothing to gather: trivial or fallback
+  // gather the keys of that bin: the block counts its matches, reserves a range of the job's
+  // buffer with ONE global atomic and writes them there
+  int mine = 0;
+  unsigned hit = 0;
+#pragma unroll
+  for (int u = 0; u < kSelPre; ++u)
+    if (ks.lo + (int)threadIdx.x + u * kBlock < ks.hi && window_bin(w, ks.kv[u]) == bin) { hit |= 1u << u; ++mine; }
+  for (int i = ks.lo + kSelPre * kBlock + (int)threadIdx.x; i < ks.hi; i += kBlock) mine += window_bin(w, job_key(job, i)) == bin;
+  int incl = mine;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int x = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += x;
+  }
+  if (lane == 63) wave_tot[wv] = incl;  // pick_from's last barrier lies behind every thread
+  __syncthreads();
+  int pos = incl - mine, total = 0;
+  for (int w2 = 0; w2 < kBlock / 64; ++w2) { if (w2 < wv) pos += wave_tot[w2]; total += wave_tot[w2]; }
+  if (threadIdx.x == 0) sel[0] = total ? atomicAdd(&cursor[blockIdx.y], total) : 0;
+  __syncthreads();
+  unsigned long long *dst = coll + (size_t)blockIdx.y * kSelCap + sel[0] + pos;
+#pragma unroll
+  for (int u = 0; u < kSelPre; ++u)
+    if (hit & (1u << u)) *dst++ = ks.kv[u];
+  for (int i = ks.lo + kSelPre * kBlock + (int)threadIdx.x; i < ks.hi; i += kBlock) {
+    unsigned long long key = job_key(job, i);
+    if (window_bin(w, key) == bin) *dst++ = key;
+  }
+}
+
+__global__ __launch_bounds__(kSelThreads) void k_selw_final(const SelJob *jobs, double *prev, int *hist, const SelState *st,
+                                                           const unsigned long long *coll, int *cursor) {
+  __shared__ unsigned long long keys[kSelCap];
+  __shared__ int lh[2048];
   __shared__ int wave_tot[kSelThreads / 64];
-  __shared__ int sel_bin, sel_before;
+  __shared__ int sel[3];
+  __shared__ unsigned long long picked;
   SelJob job = jobs[blockIdx.x];
   SelState s0 = st[blockIdx.x];
   int *h = hist + blockIdx.x * 2048;
+  for (int b = threadIdx.x; b < 2048; b += kSelThreads) h[b] = 0;  // ready for the next selection
+  if (threadIdx.x == 0) cursor[blockIdx.x] = 0;
   if (s0.k < 0) {
-    if (last && threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
+    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
     return;
   }
-  pick_bin(h[2 * threadIdx.x], h[2 * threadIdx.x + 1], s0.k, wave_tot, &sel_bin, &sel_before);
-  h[2 * threadIdx.x] = 0; h[2 * threadIdx.x + 1] = 0;  // ready for the next pass
+  unsigned long long value;
+  if (s0.bin <= 0 || s0.bin >= 2047 || s0.count > kSelCap) {  // window missed or bin too full: full select
+    int n = job.n0 + job.n1;
+    value = radix_select_block([&](int i) { return job_key(job, i); }, n, s0.k, lh, wave_tot, sel);
+  } else {
+    for (int i = threadIdx.x; i < s0.count; i += kSelThreads) keys[i] = coll[(size_t)blockIdx.x * kSelCap + i];
+    __syncthreads();
+    if (s0.count <= 256) {
+      // few keys: every thread ranks its own by counting; keys[j] is a broadcast read
+      const bool have = (int)threadIdx.x < s0.count;
+      const unsigned long long mine = have ? keys[threadIdx.x] : ~0ull;
+      int less = 0, leq = 0;
+      for (int j = 0; j < s0.count; ++j) {
+        unsigned long long kj = keys[j];
+        less += kj < mine; leq += kj <= mine;
+      }
+      if (have && s0.k_in_bin >= less && s0.k_in_bin < leq) picked = mine;  // equal keys write the same value
+      __syncthreads();
+      value = picked;
+    } else {
+      value = radix_select_block([&](int i) { return keys[i]; }, s0.count, s0.k_in_bin, lh, wave_tot, sel);
+    }
+  }
   if (threadIdx.x == 0) {
-    s0.prefix |= (unsigned long long)sel_bin << shift;
-    s0.mask |= (unsigned long long)(bins - 1) << shift;
-    s0.k -= sel_before;
-    st[blockIdx.x] = s0;
-    if (last) { job.out[0] = __longlong_as_double((long long)s0.prefix); job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
+    double v = __longlong_as_double((long long)value);
+    job.out[0] = v; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m;
+    if (job.state >= 0) prev[job.state] = v;
   }
 }
 
@@ -1752,18 +1917,14 @@ int finish_reduce(lrr_icp_ctx *ctx, int nblocks, int K, double *host_out) {
   return LRR_ICP_OK;
 }
 
-// k-th values of nj jobs already uploaded to ctx->d_jobs: 1 + 6 x 2 asynchronous launches
+// k-th values of nj jobs already uploaded to ctx->d_jobs: three asynchronous launches
 int launch_select_kth(lrr_icp_ctx *ctx, int nj) {
-  static const int shifts[6] = {53, 42, 31, 20, 9, 0};
-  static const int widths[6] = {11, 11, 11, 11, 11, 9};
-  hipLaunchKernelGGL(k_sel_init, dim3(nj), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_selstate, ctx->d_selhist);
+  hipLaunchKernelGGL(k_selw_hist, dim3(kSelHistBlocks, nj), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_selprev, ctx->d_selhist);
   HIPCHK(ctx, hipGetLastError());
-  for (int pass = 0; pass < 6; ++pass) {
-    hipLaunchKernelGGL(k_sel_hist, dim3(kSelHistBlocks, nj), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_selstate, ctx->d_selhist, shifts[pass], 1 << widths[pass]);
-    HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_sel_pick, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_selstate, ctx->d_selhist, shifts[pass], 1 << widths[pass], pass == 5 ? 1 : 0);
-    HIPCHK(ctx, hipGetLastError());
-  }
+  hipLaunchKernelGGL(k_selw_collect, dim3(kSelHistBlocks, nj), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_selprev, ctx->d_selhist, ctx->d_selstate, ctx->d_selcoll, ctx->d_selcursor);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_selw_final, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_selprev, ctx->d_selhist, ctx->d_selstate, ctx->d_selcoll, ctx->d_selcursor);
+  HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
 
@@ -1791,7 +1952,7 @@ int run_select(lrr_icp_ctx *ctx, std::vector<SelJob> &jobs, double *host_out, bo
 SelJob make_job(const double *k0, int n0, const double *k1, int n1, long long k, long long m) {
   SelJob j{};
   j.k0 = k0; j.n0 = n0; j.k1 = k1; j.n1 = n1; j.k = k; j.out = nullptr;
-  j.cnt = nullptr; j.cnt_a0 = j.cnt_a1 = j.cnt_b0 = j.cnt_b1 = 0; j.m_fixed = m;
+  j.cnt = nullptr; j.cnt_a0 = j.cnt_a1 = j.cnt_b0 = j.cnt_b1 = 0; j.m_fixed = m; j.state = -1;
   return j;
 }
 
@@ -1948,6 +2109,12 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selstate, sizeof(SelState) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selhist, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
+  if ((e = hipMemset(ctx->d_selhist, 0, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_selprev, sizeof(double) * kSelStates)) != hipSuccess) return bail(e);
+  if ((e = hipMemset(ctx->d_selprev, 0, sizeof(double) * kSelStates)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_selcoll, sizeof(unsigned long long) * kMaxSelJobs * kSelCap)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_selcursor, sizeof(int) * kMaxSelJobs)) != hipSuccess) return bail(e);
+  if ((e = hipMemset(ctx->d_selcursor, 0, sizeof(int) * kMaxSelJobs)) != hipSuccess) return bail(e);
   *out = ctx;
   return LRR_ICP_OK;
 }
@@ -1960,7 +2127,8 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   void *dev[] = {ctx->d_partials, ctx->d_final, ctx->d_jobs, ctx->d_bd, ctx->d_bi, ctx->d_hard, ctx->d_overflow,
-                 ctx->d_active, ctx->d_counts, ctx->d_order, ctx->d_fused, ctx->d_selstate, ctx->d_selhist};
+                 ctx->d_active, ctx->d_counts, ctx->d_order, ctx->d_fused, ctx->d_selstate, ctx->d_selhist,
+                 ctx->d_selprev, ctx->d_selcoll, ctx->d_selcursor};
   for (void *p : dev) if (p) (void)hipFree(p);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
@@ -2472,6 +2640,7 @@ int lrr_icp_weight_by_strength(lrr_icp_dir *a, lrr_icp_dir *b, double *grad_scal
     // masked / inactive entries carry +inf keys and sort last, so rank k among the m finite keys is rank k overall
     std::vector<SelJob> jobs(1, make_job(a->n > 0 ? a->key_g : nullptr, a->n > 0 ? na : 0,
                                          (b && b->n > 0) ? b->key_g : nullptr, (b && b->n > 0) ? nbsrc : 0, mad_rank(m), m));
+    jobs[0].state = 6;
     double res[4];
     if ((rc = run_select(ctx, jobs, res))) return rc;
     gs = mad_from_kth(m, res[0]);
@@ -2502,6 +2671,7 @@ int lrr_icp_weight_spatially(lrr_icp_dir *a, const lrr_icp_norm *norm_a, lrr_icp
   if (m > 1) {
     std::vector<SelJob> jobs(1, make_job(a->n > 0 ? a->key_s : nullptr, a->n > 0 ? na : 0,
                                          (b && b->n > 0) ? b->key_s : nullptr, (b && b->n > 0) ? nbsrc : 0, mad_rank(m), m));
+    jobs[0].state = 7;
     double res[4];
     if ((rc = run_select(ctx, jobs, res))) return rc;
     ss = mad_from_kth(m, res[0]);
@@ -2604,6 +2774,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
     SelJob j = make_job(k0, n0, k1, n1, -1, m);
     j.out = SEL + 4 * nj;
     j.cnt = counted ? P4 : nullptr; j.cnt_a0 = a0; j.cnt_a1 = a1; j.cnt_b0 = b0; j.cnt_b1 = b1;
+    j.state = (o->rrl ? 0 : 4) + nj;
     hj[nj++] = j;
   };
   if (o->rrl) {
