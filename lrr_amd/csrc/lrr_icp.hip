@@ -57,6 +57,7 @@ constexpr int kTileNx = 20;          // ... of at most this many cells each
 constexpr int kSelThreads = 1024;
 constexpr int kMaxSelJobs = 32;
 constexpr int kProfEvents = 4096;
+constexpr int kCountSlots = 64;      // K1 list counters: cleared once per kCountSlots submissions
 constexpr int kSelCap = 8192;        // keys of one window bin the final block can select from in LDS
 constexpr int kSelStates = 16;      // remembered results (window centres)
 constexpr int kSelHistBlocks = 128;  // blocks per job of the chip-wide select kernels (<= kSelPre keys per thread up to 262k keys)
@@ -84,6 +85,9 @@ struct SelJob {
   long long m_fixed;               // m when cnt == nullptr
   int state;                       // slot of the previous result that centres the window (< 0: none)
 };
+constexpr int kSelPack = 4;
+struct SelPack { SelJob j[kSelPack]; };  // the jobs of one windowed selection, passed as a kernel argument
+
 
 }  // namespace
 
@@ -94,7 +98,8 @@ struct lrr_icp_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double *d_partials = nullptr;  // kMaxBlocks * kMaxRed
   double *d_final = nullptr;     // kMaxRed + select outputs
-  double *h_pinned = nullptr;    // results staging
+  double *h_pinned = nullptr;    // results staging (mapped: kernels write it through h_pinned_dev)
+  double *h_pinned_dev = nullptr;
   SelJob *d_jobs = nullptr;
   SelJob *h_jobs = nullptr;
   SelState *d_selstate = nullptr;
@@ -103,11 +108,12 @@ struct lrr_icp_ctx {
   unsigned long long *d_selcoll = nullptr;  // kMaxSelJobs x kSelCap gathered keys
   int *d_selcursor = nullptr;    // kMaxSelJobs, zero between selections
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
-  double *h_fused = nullptr;
+  double *h_fused = nullptr, *h_fused_dev = nullptr;
   // K1 scratch
   double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;   // brute-force partial argmin
   int *d_hard = nullptr, *d_overflow = nullptr, *d_active = nullptr; size_t list_cap = 0;
-  int *d_counts = nullptr;       // [0] hard, [1] overflow, [2] active
+  int *d_counts = nullptr;       // kCountSlots x {hard, overflow, active, -}: one zeroed slot per K1 submission
+  int count_slot = 0;
   int *d_order = nullptr; size_t order_cap = 0;
   // match-kernel profile (event pairs resolved lazily)
   bool prof = false;
@@ -145,7 +151,8 @@ struct lrr_icp_dir {
   double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
   double *from_loc = nullptr;  // 3 per source: pre-mapped copies
   int from_is_copy = 0;
-  unsigned *flag = nullptr; int64_t flag_cap = 0;
+  unsigned *flag = nullptr; int64_t flag_cap = 0;  // per target: stamp of the last call that matched it
+  unsigned flag_gen = 0;
 };
 
 namespace {
@@ -288,12 +295,17 @@ __device__ __forceinline__ double block_total(const double *P, int r0, int r1, i
 
 // one wavefront per output value: lane l sums blocks l, l+64, ... in order, then the fixed
 // shuffle tree — deterministic for a given (nblocks, K)
-__global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, int nblocks, int K, double *out) {
+// The results also go straight into mapped host memory (host[head + k]; block 0 first forwards the
+// `head` scalars earlier kernels left in `fwd`): the host reads them after the stream
+// synchronisation, no copy in between.
+__global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, int nblocks, int K, double *out,
+                                                        const double *fwd, int head, double *host) {
   int k = blockIdx.x;
   double s = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * K + k];
   s = wave_sum(s);
-  if (threadIdx.x == 0) out[k] = s;
+  if (threadIdx.x == 0) { out[k] = s; host[head + k] = s; }
+  if (k == 0) for (int t = threadIdx.x; t < head; t += 64) host[t] = fwd[t];
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -1122,16 +1134,18 @@ __global__ __launch_bounds__(kBlock) void k_from_sum(PairSrc ps, double *partial
   block_reduce_store<3>(acc, partials);
 }
 
-__global__ void k_mark(const int *slot, const int *m_to, int nsrc, unsigned *flag) {
+// distinct matched targets: flag[j] == gen marks j for THIS call (the stamp changes per call, so the
+// array is never cleared)
+__global__ void k_mark(const int *slot, const int *m_to, int nsrc, unsigned *flag, unsigned gen) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < nsrc && slot[s] >= 0) flag[m_to[s]] = 1u;  // benign race: every writer stores 1
+  if (s < nsrc && slot[s] >= 0) flag[m_to[s]] = gen;  // benign race: every writer stores the same stamp
 }
 
-__global__ __launch_bounds__(kBlock) void k_to_sum(const double *to_rec, const unsigned *flag, int nt,
+__global__ __launch_bounds__(kBlock) void k_to_sum(const double *to_rec, const unsigned *flag, unsigned gen, int nt,
                                                    double *partials) {
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
-    if (flag[j]) {
+    if (flag[j] == gen) {
       const double *q = to_rec + (size_t)j * kRecStride;
       acc[0] += q[0]; acc[1] += q[1]; acc[2] += q[2]; acc[3] += 1.0;
     }
@@ -1139,7 +1153,7 @@ __global__ __launch_bounds__(kBlock) void k_to_sum(const double *to_rec, const u
   block_reduce_store<4>(acc, partials);
 }
 
-__global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, const double *to_rec, const unsigned *flag, int nt,
+__global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, const double *to_rec, const unsigned *flag, unsigned gen, int nt,
                                                   double cm0, double cm1, double cm2, double cf0, double cf1,
                                                   double cf2, double *partials) {
   double acc[2] = {0.0, 0.0};
@@ -1151,7 +1165,7 @@ __global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, const double *to_r
     acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
   }
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
-    if (flag[j]) {
+    if (flag[j] == gen) {
       const double *q = to_rec + (size_t)j * kRecStride;
       double q0 = q[0] - cf0, q1 = q[1] - cf1, q2 = q[2] - cf2;
       acc[1] += sqrt((q0 * q0 + q1 * q1) + q2 * q2);
@@ -1527,9 +1541,9 @@ __device__ __forceinline__ void load_slice(const SelJob &job, KeySlice &ks) {
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_selw_hist(const SelJob *jobs, const double *prev, int *hist) {
+__global__ __launch_bounds__(kBlock) void k_selw_hist(SelPack jobs, const double *prev, int *hist) {
   __shared__ int lh[2048];
-  SelJob job = jobs[blockIdx.y];
+  SelJob job = jobs.j[blockIdx.y];
   KeySlice ks;
   load_slice(job, ks);
   for (int b = threadIdx.x; b < 2048; b += kBlock) lh[b] = 0;
@@ -1551,12 +1565,12 @@ __global__ __launch_bounds__(kBlock) void k_selw_hist(const SelJob *jobs, const 
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_selw_collect(const SelJob *jobs, const double *prev, const int *hist,
+__global__ __launch_bounds__(kBlock) void k_selw_collect(SelPack jobs, const double *prev, const int *hist,
                                                          SelState *st, unsigned long long *coll, int *cursor) {
   __shared__ int wave_tot[kBlock / 64];
   __shared__ int sel[3];
   __shared__ double csh[kBlock / 64];
-  SelJob job = jobs[blockIdx.y];
+  SelJob job = jobs.j[blockIdx.y];
   KeySlice ks;
   load_slice(job, ks);
   int v[2048 / kBlock];
@@ -1616,14 +1630,14 @@ __global__ __launch_bounds__(kBlock) void k_selw_collect(const SelJob *jobs, con
   }
 }
 
-__global__ __launch_bounds__(kSelThreads) void k_selw_final(const SelJob *jobs, double *prev, int *hist, const SelState *st,
+__global__ __launch_bounds__(kSelThreads) void k_selw_final(SelPack jobs, double *prev, int *hist, const SelState *st,
                                                            const unsigned long long *coll, int *cursor) {
   __shared__ unsigned long long keys[kSelCap];
   __shared__ int lh[2048];
   __shared__ int wave_tot[kSelThreads / 64];
   __shared__ int sel[3];
   __shared__ unsigned long long picked;
-  SelJob job = jobs[blockIdx.x];
+  SelJob job = jobs.j[blockIdx.x];
   SelState s0 = st[blockIdx.x];
   int *h = hist + blockIdx.x * 2048;
   for (int b = threadIdx.x; b < 2048; b += kSelThreads) h[b] = 0;  // ready for the next selection
@@ -1671,7 +1685,7 @@ struct DirArgs {
   PairSrc ps;
   int n;               // active matches
   double *w, *wc, *r2, *key_s, *key_g;
-  unsigned *flag;
+  unsigned *flag, gen;  // distinct-target stamps of this call
   int float_product;
 };
 
@@ -1700,7 +1714,7 @@ __global__ __launch_bounds__(kBlock) void k_f_residual(DirArgs F, DirArgs B, int
       double p0, p1, p2;
       load_from(D.ps, s, p0, p1, p2);
       acc[2] += p0; acc[3] += p1; acc[4] += p2;
-      D.flag[D.ps.m_to[s]] = 1u;
+      D.flag[D.ps.m_to[s]] = D.gen;
     }
   }
   block_reduce_store<5>(acc, P1);
@@ -1727,7 +1741,7 @@ __global__ __launch_bounds__(kBlock) void k_f_radii(DirArgs F, int nbF, const do
     acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
   }
   for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
-    if (F.flag[j]) {
+    if (F.flag[j] == F.gen) {
       const double *q = to_rec + (size_t)j * kRecStride;
       double q0 = q[0] - cf[0], q1 = q[1] - cf[1], q2 = q[2] - cf[2];
       acc[1] += sqrt((q0 * q0 + q1 * q1) + q2 * q2);
@@ -1909,22 +1923,27 @@ PairSrc pairs_of(const lrr_icp_dir *d) {
 
 // finish a block-partials reduction: final sum on device, copy K doubles to host, synchronise
 int finish_reduce(lrr_icp_ctx *ctx, int nblocks, int K, double *host_out) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, ctx->stream, ctx->d_partials, nblocks, K, ctx->d_final);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, ctx->stream, ctx->d_partials, nblocks, K, ctx->d_final, (const double *)nullptr, 0, ctx->h_pinned_dev);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_final, sizeof(double) * K, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   std::memcpy(host_out, ctx->h_pinned, sizeof(double) * K);
   return LRR_ICP_OK;
 }
 
-// k-th values of nj jobs already uploaded to ctx->d_jobs: three asynchronous launches
+// k-th values of the nj jobs in ctx->h_jobs: three asynchronous launches per kSelPack jobs, the job
+// descriptors travel as kernel arguments
 int launch_select_kth(lrr_icp_ctx *ctx, int nj) {
-  hipLaunchKernelGGL(k_selw_hist, dim3(kSelHistBlocks, nj), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_selprev, ctx->d_selhist);
-  HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_selw_collect, dim3(kSelHistBlocks, nj), dim3(kBlock), 0, ctx->stream, ctx->d_jobs, ctx->d_selprev, ctx->d_selhist, ctx->d_selstate, ctx->d_selcoll, ctx->d_selcursor);
-  HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_selw_final, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs, ctx->d_selprev, ctx->d_selhist, ctx->d_selstate, ctx->d_selcoll, ctx->d_selcursor);
-  HIPCHK(ctx, hipGetLastError());
+  for (int j0 = 0; j0 < nj; j0 += kSelPack) {
+    int nc = std::min(kSelPack, nj - j0);
+    SelPack pk;
+    for (int j = 0; j < kSelPack; ++j) pk.j[j] = ctx->h_jobs[j0 + std::min(j, nc - 1)];
+    hipLaunchKernelGGL(k_selw_hist, dim3(kSelHistBlocks, nc), dim3(kBlock), 0, ctx->stream, pk, ctx->d_selprev, ctx->d_selhist);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_selw_collect, dim3(kSelHistBlocks, nc), dim3(kBlock), 0, ctx->stream, pk, ctx->d_selprev, ctx->d_selhist, ctx->d_selstate, ctx->d_selcoll, ctx->d_selcursor);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_selw_final, dim3(nc), dim3(kSelThreads), 0, ctx->stream, pk, ctx->d_selprev, ctx->d_selhist, ctx->d_selstate, ctx->d_selcoll, ctx->d_selcursor);
+    HIPCHK(ctx, hipGetLastError());
+  }
   return LRR_ICP_OK;
 }
 
@@ -1935,8 +1954,8 @@ int run_select(lrr_icp_ctx *ctx, std::vector<SelJob> &jobs, double *host_out, bo
   if (nj > kMaxSelJobs) return fail(ctx, LRR_ICP_ERR_ARG, "too many selection jobs");
   double *d_out = ctx->d_final + kMaxRed;
   for (int j = 0; j < nj; ++j) { jobs[j].out = d_out + 4 * j; ctx->h_jobs[j] = jobs[j]; }
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, ctx->h_jobs, sizeof(SelJob) * nj, hipMemcpyHostToDevice, ctx->stream));
   if (need_sums) {  // trimmed MUSE sums: single-block kernel that also accumulates the keys below the k-th
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, ctx->h_jobs, sizeof(SelJob) * nj, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_select, dim3(nj), dim3(kSelThreads), 0, ctx->stream, ctx->d_jobs);
     HIPCHK(ctx, hipGetLastError());
   } else {
@@ -1959,6 +1978,16 @@ SelJob make_job(const double *k0, int n0, const double *k1, int n1, long long k,
 // rrel_util_median_abs_dev_scale, dof = 1 (cdcl .txx:520-536): k-th of m values, 0 if m <= 1
 inline long long mad_rank(long long m) { return (m - 1) / 2 + 1; }
 inline double mad_from_kth(long long m, double kth) { return 1.4826 * (1 + 5.0 / (double)(m - 1)) * kth; }
+
+// a new stamp for the distinct-target flags; the array is cleared when the stamp wraps around
+int next_flag_gen(lrr_icp_dir *d, unsigned *gen) {
+  if (++d->flag_gen == 0u) {
+    HIPCHK(d->ctx, hipMemsetAsync(d->flag, 0, sizeof(unsigned) * d->flag_cap, d->ctx->stream));
+    d->flag_gen = 1u;
+  }
+  *gen = d->flag_gen;
+  return LRR_ICP_OK;
+}
 
 int ensure_dir_capacity(lrr_icp_dir *d) {
   lrr_icp_ctx *ctx = d->ctx;
@@ -2005,10 +2034,19 @@ unsigned host_fmix32(unsigned h) {
   return h;
 }
 
+// the list counters of one K1 submission: slots are handed out round robin and all cleared together
+// when the round starts over (every earlier submission has drained by then: same stream)
+int fresh_counts(lrr_icp_ctx *ctx, int **counts) {
+  if (ctx->count_slot == 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, kCountSlots * 4 * sizeof(int), ctx->stream));
+  *counts = ctx->d_counts + 4 * ctx->count_slot;
+  ctx->count_slot = (ctx->count_slot + 1) % kCountSlots;
+  return LRR_ICP_OK;
+}
+
 // phases 2 and 3 of the grid search; both read their list length on the device and fall through
 // when it is 0
-int launch_hard_phases(lrr_icp_ctx *ctx, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to) {
-  int *hard_count = ctx->d_counts, *over_count = ctx->d_counts + 1;
+int launch_hard_phases(lrr_icp_ctx *ctx, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts) {
+  int *hard_count = counts, *over_count = counts + 1;
   int hard_blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)n + 3) / 4));
   hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, ctx->stream, g, q, xf, ctx->d_hard, hard_count, q.src ? 1 : 0, to->rec, to->orig_of, m_to, ctx->d_overflow, over_count);
   HIPCHK(ctx, hipGetLastError());
@@ -2073,7 +2111,7 @@ DirArgs dir_args(lrr_icp_dir *d) {
   a.ps = pairs_of(d);
   a.n = (int)d->n;
   a.w = d->w; a.wc = d->wc; a.r2 = d->r2; a.key_s = d->key_s; a.key_g = d->key_g;
-  a.flag = d->flag;
+  a.flag = d->flag; a.gen = d->flag_gen;
   a.float_product = d->from->float_strength;
   return a;
 }
@@ -2101,12 +2139,14 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_partials, sizeof(double) * kMaxBlocks * kMaxRed)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_final, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs))) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs))) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs), hipHostMallocMapped)) != hipSuccess) return bail(e);
+  if ((e = hipHostGetDevicePointer((void **)&ctx->h_pinned_dev, ctx->h_pinned, 0)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
-  if ((e = hipMalloc(&ctx->d_counts, 4 * sizeof(int))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_counts, kCountSlots * 4 * sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256, hipHostMallocMapped)) != hipSuccess) return bail(e);
+  if ((e = hipHostGetDevicePointer((void **)&ctx->h_fused_dev, ctx->h_fused, 0)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selstate, sizeof(SelState) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selhist, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
   if ((e = hipMemset(ctx->d_selhist, 0, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
@@ -2320,6 +2360,7 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
   HIPCHK(ctx, hipSetDevice(ctx->device));
   d->flag_cap = std::max<int64_t>(to->n, 1);
   if (hipMalloc(&d->flag, sizeof(unsigned) * d->flag_cap) != hipSuccess) { delete d; return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: hipMalloc failed"); }
+  if (hipMemsetAsync(d->flag, 0, sizeof(unsigned) * d->flag_cap, ctx->stream) != hipSuccess) { lrr_icp_dir_destroy(d); return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: memset failed"); }
   int rc = ensure_dir_capacity(d);
   if (rc) { lrr_icp_dir_destroy(d); return rc; }
   if (hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, ctx->stream) != hipSuccess ||
@@ -2432,11 +2473,12 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
   q.src = d->from->src; q.raw = nullptr; q.want_orig = 0;
   XfD x = to_dev(xf);
   const bool dense = !order && n_points * 4 >= N;  // fine levels: every source feature is looked at
-  HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, 4 * sizeof(int), st));
+  int *counts = nullptr;
+  if ((rc = fresh_counts(ctx, &counts))) return rc;
   ProfScope prof(ctx);
   if (method == LRR_ICP_NN_BRUTE) {
     if (dense) {
-      hipLaunchKernelGGL(k_slots_dense, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->from->src, kk, half, (int)N, (int)n_points, d->slot, d->w, ctx->d_active, ctx->d_counts + 2);
+      hipLaunchKernelGGL(k_slots_dense, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->from->src, kk, half, (int)N, (int)n_points, d->slot, d->w, ctx->d_active, counts + 2);
     } else {
       HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
       hipLaunchKernelGGL(k_slots_sparse, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, (int)n_points, d->slot, d->w, ctx->d_active);
@@ -2448,15 +2490,15 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
   const bool steady = dense && d->prev_n == n_points;
   d->prev_n = dense ? n_points : -1;
   if (steady) {
-    hipLaunchKernelGGL(k_match_ball, dim3(blocks_for(N)), dim3(kBlock), 0, st, g, d->from->src, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->m_to, d->w, ctx->d_hard, ctx->d_counts, kBallBudget, kBallCells * g.h);
+    hipLaunchKernelGGL(k_match_ball, dim3(blocks_for(N)), dim3(kBlock), 0, st, g, d->from->src, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->m_to, d->w, ctx->d_hard, counts, kBallBudget, kBallCells * g.h);
   } else if (dense) {
-    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts, kTileBudget);
+    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, ctx->d_hard, counts, kTileBudget);
   } else {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
-    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, g, q, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, x, (int)n_points, d->slot, d->m_to, d->w, ctx->d_hard, ctx->d_counts);
+    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, g, q, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, x, (int)n_points, d->slot, d->m_to, d->w, ctx->d_hard, counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  return launch_hard_phases(ctx, d->to, g, q, x, (int)n_points, d->m_to);
+  return launch_hard_phases(ctx, d->to, g, q, x, (int)n_points, d->m_to, counts);
 }
 
 int lrr_icp_premap(lrr_icp_dir *d, const lrr_icp_xform *G) {
@@ -2583,18 +2625,19 @@ int lrr_icp_normalize_stats(lrr_icp_dir *d, lrr_icp_norm *out) {
   int rc = finish_reduce(ctx, nb, 3, r);
   if (rc) return rc;
   for (int k = 0; k < 3; ++k) out->cm[k] = r[k] / (double)n;
-  HIPCHK(ctx, hipMemsetAsync(d->flag, 0, sizeof(unsigned) * d->flag_cap, ctx->stream));
-  hipLaunchKernelGGL(k_mark, dim3(blocks_for(ps.nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->m_to, ps.nsrc, d->flag);
+  unsigned gen = 0;
+  if ((rc = next_flag_gen(d, &gen))) return rc;
+  hipLaunchKernelGGL(k_mark, dim3(blocks_for(ps.nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->m_to, ps.nsrc, d->flag, gen);
   HIPCHK(ctx, hipGetLastError());
   int nbt = grid_for(nt);
-  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kBlock), 0, ctx->stream, d->to->rec, d->flag, (int)nt, ctx->d_partials);
+  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kBlock), 0, ctx->stream, d->to->rec, d->flag, gen, (int)nt, ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   rc = finish_reduce(ctx, nbt, 4, r);
   if (rc) return rc;
   double nd = r[3];
   for (int k = 0; k < 3; ++k) out->cf[k] = r[k] / nd;
   int nb2 = std::max(nb, nbt);
-  hipLaunchKernelGGL(k_radii, dim3(nb2), dim3(kBlock), 0, ctx->stream, ps, d->to->rec, d->flag, (int)nt,
+  hipLaunchKernelGGL(k_radii, dim3(nb2), dim3(kBlock), 0, ctx->stream, ps, d->to->rec, d->flag, gen, (int)nt,
                      out->cm[0], out->cm[1], out->cm[2], out->cf[0], out->cf[1], out->cf[2], ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   rc = finish_reduce(ctx, nb2, 2, r);
@@ -2749,7 +2792,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   int nb3 = std::max(nbF, nbT);
   NormD ident = to_dev((const lrr_icp_norm *)nullptr);
   // F1
-  if (o->normalize) HIPCHK(ctx, hipMemsetAsync(F->flag, 0, sizeof(unsigned) * F->flag_cap, st));
+  if (o->normalize) { int rc = next_flag_gen(F, &aF.gen); if (rc) return rc; }
   hipLaunchKernelGGL(k_f_residual, dim3(nbF + nbB), dim3(kBlock), 0, st, aF, aB, nbF, nbB, to_dev(xfF), to_dev(xfB), ident, o->normalize, P1);
   HIPCHK(ctx, hipGetLastError());
   // scale modes; MUSE needs the sorted residuals: its tables and argmin stay on the host (first
@@ -2760,7 +2803,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   if (wo.mode_f == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &wo.inj_f); if (rc) return rc; wo.mode_f = LRR_ICP_SCALE_INJECTED; }
   if (wo.mode_b == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(B, &wo.inj_b); if (rc) return rc; wo.mode_b = LRR_ICP_SCALE_INJECTED; }
   if (o->normalize) {
-    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kBlock), 0, st, F->to->rec, F->flag, nt, P2);
+    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kBlock), 0, st, F->to->rec, F->flag, aF.gen, nt, P2);
     HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kBlock), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
     HIPCHK(ctx, hipGetLastError());
@@ -2786,7 +2829,6 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
     job(F->key_g, nsF, B->key_g, nsB, 0, true, 0, nbF, nbF, nbF + nbB);
     job(F->key_s, nsF, B->key_s, nsB, F->n + B->n, false, 0, 0, 0, 0);
   }
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, hj, sizeof(SelJob) * nj, hipMemcpyHostToDevice, st));
   { int rc = launch_select_kth(ctx, nj); if (rc) return rc; }
   // F6 + final reduction
   int nbAF = std::min(nbF, kAccBlocks), nbAB = std::min(nbB, kAccBlocks);
@@ -2797,9 +2839,8 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   else if (o->rrl) hipLaunchKernelGGL((k_f_accumulate<6, true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   else hipLaunchKernelGGL((k_f_accumulate<6, false>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_fused, OUT, sizeof(double) * (FIN_OFF + K), hipMemcpyDeviceToHost, st));
   HIPCHK(ctx, hipStreamSynchronize(st));
   const double *h = ctx->h_fused;
   for (int k = 0; k < 3; ++k) { out->norm.cm[k] = h[SC_CM + k]; out->norm.cf[k] = h[SC_CF + k]; }
@@ -2855,7 +2896,8 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
   HIPCHK(ctx, hipMalloc(&dq, sizeof(double) * 3 * nq));
   if (hipMalloc(&dto, sizeof(int) * nq) != hipSuccess) { (void)hipFree(dq); return fail(ctx, LRR_ICP_ERR_HIP, "nearest: hipMalloc failed"); }
   if (hipMemcpy(dq, query, sizeof(double) * 3 * nq, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: upload failed");
-  if (!rc && hipMemsetAsync(ctx->d_counts, 0, 4 * sizeof(int), ctx->stream) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: memset failed");
+  int *counts = nullptr;
+  if (!rc) rc = fresh_counts(ctx, &counts);
   if (!rc) {
     GridView g = view_of(cloud);
     QSrc q;
@@ -2867,9 +2909,9 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
     ProfScope prof(ctx);
     if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, cloud, g, q, nullptr, x, (int)nq, dto);
     else {
-      hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, ctx->d_hard, ctx->d_counts);
+      hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, ctx->d_hard, counts);
       if (hipGetLastError() != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: launch failed");
-      if (!rc) rc = launch_hard_phases(ctx, cloud, g, q, x, (int)nq, dto);
+      if (!rc) rc = launch_hard_phases(ctx, cloud, g, q, x, (int)nq, dto, counts);
     }
   }
   std::vector<int> tmp((size_t)nq);

@@ -192,6 +192,28 @@ def test_roi_queries_set_features(E, ob):
     g.close()
 
 
+def test_strength_ties_and_scale_jumps(E, ob):
+    """the MAD order statistics outside their fast path: every gain capped at 90000 (all keys tie: the
+    histogram bin of the median overflows the in-LDS select), then strengths 1e-6 times smaller on the
+    same estimator (the window around the previous result misses) — both must stay exact"""
+    import dataclasses
+    pair = synth.make_pair(30000, 30000, 77, kind="affine")
+    T0 = synth.perturbed(pair.planted, 4)
+    big = dataclasses.replace(pair, moving=dataclasses.replace(pair.moving, strength=np.full(pair.moving.n, 1e4)),
+                              fixed=dataclasses.replace(pair.fixed, strength=np.full(pair.fixed.n, 1e4)))
+    g, c = _both(E, ob, E.RRL_SYMMETRIC, 12, big, T0, 21, True)
+    for it in range(14):
+        _compare_iteration(g, c, it, (0, 1))
+    small_m = dataclasses.replace(pair.moving, strength=pair.moving.strength * 1e-6)
+    small_f = dataclasses.replace(pair.fixed, strength=pair.fixed.strength * 1e-6)
+    for e in (g, c):
+        e.set_features(small_m, small_f)
+        e.set_transform(T0.A, T0.t, T0.c)
+    for it in range(14):
+        _compare_iteration(g, c, it, (0, 1))
+    g.close()
+
+
 def test_small_and_ragged_inputs(E, ob):
     """fewer than 1000 points, unequal sizes, a single moving point"""
     for nm, nf in ((1, 40), (37, 900), (999, 1001)):
