@@ -63,7 +63,7 @@ constexpr int kSelStates = 16;      // remembered results (window centres)
 constexpr int kSelHistBlocks = 128;  // blocks per job of the chip-wide select kernels (<= kSelPre keys per thread up to 262k keys)
 // fused scratch: P1 (2*kMaxBlocks x 5), P2 (kMaxBlocks x 4), P3 (kMaxBlocks x 2), P4 (2*kMaxBlocks x 1),
 // P6 (2*256 x 96), output block
-constexpr int kAccBlocks = 256;      // accumulate grid per direction (90 fp64 accumulators per thread: 2 waves/SIMD)
+constexpr int kAccBlocks = 128;      // accumulate grid per direction (90 fp64 accumulators per thread: 2 waves/SIMD)
 constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * kMaxBlocks * 5, kFusedP3 = kFusedP2 + kMaxBlocks * 4,
               kFusedP4 = kFusedP3 + kMaxBlocks * 2, kFusedP6 = kFusedP4 + 2 * kMaxBlocks,
               kFusedOut = kFusedP6 + 2 * kAccBlocks * 96, kFusedDoubles = kFusedOut + 256;
@@ -259,15 +259,38 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // Block-wide sum of K per-thread values; result for value k lands in partials[blockIdx.x*K + k].
-// Fixed order: lanes by shuffle tree, then the 4 waves in index order.
+// Fixed order.  Few values: lanes by shuffle tree, then the 4 waves in index order.  Many values
+// (the normal equations: 90): a shuffle tree per value costs 12 cross-lane operations each, so the
+// wave transposes 16 values at a time through LDS instead — lane (part, k) adds value k of 16
+// lanes in lane order, two shuffles join the four parts — then the 4 waves in index order.
 template <int K>
 __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *partials) {
   __shared__ double red[kBlock / 64][K];
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if constexpr (K <= 8) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    double s = wave_sum(v[k]);
-    if (lane == 0) red[wv][k] = s;
+    for (int k = 0; k < K; ++k) {
+      double s = wave_sum(v[k]);
+      if (lane == 0) red[wv][k] = s;
+    }
+  } else {
+    constexpr int C = 16;
+    __shared__ double tr[kBlock / 64][C][65];  // [value][lane], rows padded against bank conflicts
+    const int kk = lane & 15, part = lane >> 4;
+#pragma unroll
+    for (int c0 = 0; c0 < K; c0 += C) {
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+        if (c0 + k < K) tr[wv][k][lane] = v[c0 + k];
+      __syncthreads();
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += tr[wv][kk][part * 16 + j];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lane < C && c0 + lane < K) red[wv][c0 + lane] = s;
+      __syncthreads();
+    }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += kBlock) {
@@ -1832,13 +1855,20 @@ __device__ __forceinline__ double mad_factor(const double *sel) {  // 1 / rrel_u
   return 1.0 / gs;
 }
 
-// F6: final weights and the normal equations of both lists (backward list role-reversed)
+// F6: final weights and the normal equations of both lists (backward list role-reversed).
+// The upper triangle lives in registers (90 doubles for dof 12), so few wavefronts fit a CU and
+// nothing hides a dependent load chain: each thread therefore takes its matches kAccBatch at a time
+// and issues the loads of the whole batch level by level (weights and match indices, then the
+// feature records) before any arithmetic — three memory round trips per batch instead of three
+// per match.
+constexpr int kAccBatch = 7;
 template <int DOF, bool PREMUL>
 __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
                                                          const double *SC, const double *SEL, double c0,
                                                          double c1, double c2, int rigid_increment,
                                                          double *P6) {
   constexpr int NT = Tri<DOF>::N;
+  constexpr int U = kAccBatch;
   const bool isF = (int)blockIdx.x < nbF;
   const DirArgs &D = isF ? F : B;
   const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
@@ -1849,20 +1879,63 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
   const double fg = strength ? mad_factor(SEL + 4 * (o.rrl ? (isF ? 0 : 1) : 0)) : 1.0;
   const double fs = mad_factor(SEL + 4 * (o.rrl ? (isF ? 2 : 3) : 1));
   double *wbuf = clone ? D.wc : D.w;
+  const double *prec = isF ? D.ps.to_rec : D.ps.from_rec;  // whose error projector the term uses
   double acc[NT + DOF];
 #pragma unroll
   for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
-  for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
-    if (D.ps.slot[s] < 0) continue;
-    double wi = wbuf[s];
-    if (strength) wi = wi * fg;
-    wi = wi * D.key_s[s];
-    wi = wi * fs;
-    wbuf[s] = wi;
-    if (PREMUL && wi < 1e-4) continue;
-    double jx, jy, jz, b0, b1, b2, P[6];
-    load_oriented(D.ps, s, nm, isF ? 0 : 1, jx, jy, jz, b0, b1, b2, P);
-    accumulate_pair<DOF, PREMUL>(acc, wi, jx, jy, jz, b0, b1, b2, P, c0, c1, c2, rigid_increment);
+  const int stride = nb * kBlock;
+  for (int s0 = lb * kBlock + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
+    int mt[U];
+    double wi[U];
+    bool on[U];
+    {
+      int sl[U];
+      double wv[U], ks[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + u * stride;
+        const bool in = s < D.ps.nsrc;
+        sl[u] = in ? D.ps.slot[s] : -1;
+        wv[u] = in ? wbuf[s] : 0.0;
+        ks[u] = in ? D.key_s[s] : 0.0;
+        mt[u] = in ? D.ps.m_to[s] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        on[u] = sl[u] >= 0;
+        double v = wv[u];
+        if (strength) v = v * fg;
+        v = v * ks[u];
+        v = v * fs;
+        wi[u] = v;
+        if (on[u]) wbuf[s0 + u * stride] = v;
+        if (PREMUL && v < 1e-4) on[u] = false;
+      }
+    }
+    double pl[U][3], ql[U][3], Pq[U][6];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      const int s = s0 + u * stride;
+      load_from(D.ps, s, pl[u][0], pl[u][1], pl[u][2]);
+      const double *qr = D.ps.to_rec + (size_t)mt[u] * kRecStride;
+      ql[u][0] = qr[0]; ql[u][1] = qr[1]; ql[u][2] = qr[2];
+      const double *pr = prec + (size_t)(isF ? mt[u] : s) * kRecStride;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      // normalised coordinates, oriented (backward list: role-reversed term)
+      double p0 = (pl[u][0] - nm.cm[0]) / nm.rm, p1 = (pl[u][1] - nm.cm[1]) / nm.rm, p2 = (pl[u][2] - nm.cm[2]) / nm.rm;
+      double q0 = (ql[u][0] - nm.cf[0]) / nm.rf, q1 = (ql[u][1] - nm.cf[1]) / nm.rf, q2 = (ql[u][2] - nm.cf[2]) / nm.rf;
+      double P[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) P[k] = Pq[u][k];
+      if (isF) accumulate_pair<DOF, PREMUL>(acc, wi[u], p0, p1, p2, q0, q1, q2, P, c0, c1, c2, rigid_increment);
+      else accumulate_pair<DOF, PREMUL>(acc, wi[u], q0, q1, q2, p0, p1, p2, P, c0, c1, c2, rigid_increment);
+    }
   }
   block_reduce_store<NT + DOF>(acc, P6);
 }
