@@ -259,6 +259,24 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     lrr_icp_perm_keys(&rng_, keys);
     const int64_t *order = explicit_order_.empty() ? nullptr : explicit_order_.data();
     check(lrr_icp_match(dir_, &xf, keys, order, (int64_t)number_points_, nn_method_), "find_closest_euclidean");
+    matched();
+  }
+  // the symmetric classes' pair of searches, submitted together (same results as one after the other)
+  static void find_closest_euclidean_pair(icp_direction &f, icp_direction &b) {
+    lrr_icp_xform xf_f = xform_of(f.trans_), xf_b = xform_of(b.trans_);
+    uint32_t keys_f[4], keys_b[4];
+    lrr_icp_perm_keys(&f.rng_, keys_f);
+    lrr_icp_perm_keys(&b.rng_, keys_b);
+    const int64_t *order_f = f.explicit_order_.empty() ? nullptr : f.explicit_order_.data();
+    const int64_t *order_b = b.explicit_order_.empty() ? nullptr : b.explicit_order_.data();
+    int method = f.nn_method_ == b.nn_method_ ? f.nn_method_ : -1;
+    if (method < 0) { f.find_closest_euclidean(); b.find_closest_euclidean(); return; }
+    check(lrr_icp_match_pair(f.dir_, &xf_f, keys_f, order_f, (int64_t)f.number_points_, b.dir_, &xf_b, keys_b, order_b,
+                             (int64_t)b.number_points_, method), "find_closest_euclidean");
+    f.matched();
+    b.matched();
+  }
+  void matched() {
     explicit_order_.clear();
     norm_ = identity_norm();
     touch();
@@ -599,7 +617,7 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
   }
   virtual void initialize() { forward_->initialize(); backward_->initialize(); }
   virtual bool run(void * = 0, display_callback_type = 0) { return false; }  // stub in the reference (rrl sym .h)
-  void find_closest_euclidean() { forward_->find_closest_euclidean(); backward_->find_closest_euclidean(); }
+  void find_closest_euclidean() { estimation_type::find_closest_euclidean_pair(*forward_, *backward_); }
 
   // (rrl sym .txx:341-438; cdcl sym .txx:268-363)
   virtual bool one_iteration(void *caller, display_callback_type display_points, unsigned int iteration) {

@@ -93,6 +93,14 @@ int64_t lrr_icp_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]);
  * keyed permutation is used. */
 int  lrr_icp_match(lrr_icp_dir *dir, const lrr_icp_xform *xf, const uint32_t keys[4],
                    const int64_t *order, int64_t n_points, int method);
+/* The symmetric classes search both lists back to back (forward_->find_closest_euclidean();
+ * backward_->find_closest_euclidean(): rrl/rrl_estimation_symmetric_ICP_matching_all.txx:341-356,
+ * cdcl/cdcl_estimation_symmetric_ICP_matching_all.txx:268-283).  Same results as two lrr_icp_match
+ * calls; the two searches are submitted together and run concurrently on the device. */
+int  lrr_icp_match_pair(lrr_icp_dir *fwd, const lrr_icp_xform *xf_fwd, const uint32_t keys_fwd[4],
+                        const int64_t *order_fwd, int64_t n_fwd,
+                        lrr_icp_dir *bwd, const lrr_icp_xform *xf_bwd, const uint32_t keys_bwd[4],
+                        const int64_t *order_bwd, int64_t n_bwd, int method);
 
 /* rigid pre-map (cdcl .txx:455-484; cdcl sym .txx:400-456): every match's from_ becomes a new
  * feature located at G(p) */

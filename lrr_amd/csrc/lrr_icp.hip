@@ -91,6 +91,15 @@ struct SelPack { SelJob j[kSelPack]; };  // the jobs of one windowed selection, 
 
 }  // namespace
 
+struct K1Lane {
+  hipStream_t stream = nullptr;
+  double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;   // brute-force partial argmin
+  int *d_hard = nullptr, *d_overflow = nullptr, *d_active = nullptr; size_t list_cap = 0;
+  int *d_counts = nullptr;       // kCountSlots x {hard, overflow, active, -}: one zeroed slot per K1 submission
+  int count_slot = 0;
+  int *d_order = nullptr; size_t order_cap = 0;
+};
+
 struct lrr_icp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -109,12 +118,10 @@ struct lrr_icp_ctx {
   int *d_selcursor = nullptr;    // kMaxSelJobs, zero between selections
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
   double *h_fused = nullptr, *h_fused_dev = nullptr;
-  // K1 scratch
-  double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;   // brute-force partial argmin
-  int *d_hard = nullptr, *d_overflow = nullptr, *d_active = nullptr; size_t list_cap = 0;
-  int *d_counts = nullptr;       // kCountSlots x {hard, overflow, active, -}: one zeroed slot per K1 submission
-  int count_slot = 0;
-  int *d_order = nullptr; size_t order_cap = 0;
+  // K1 scratch: one set per submission lane.  Lane 0 runs on `stream`; lane 1 has its own stream so
+  // that the two directions of a symmetric estimator search concurrently (lrr_icp_match_pair).
+  K1Lane lane[2];
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // match-kernel profile (event pairs resolved lazily)
   bool prof = false;
   std::vector<hipEvent_t> pe;
@@ -2082,17 +2089,17 @@ int ensure_dir_capacity(lrr_icp_dir *d) {
   return LRR_ICP_OK;
 }
 
-int ensure_lists(lrr_icp_ctx *ctx, size_t need) {
-  if (need <= ctx->list_cap) return LRR_ICP_OK;
-  if (ctx->d_hard) (void)hipFree(ctx->d_hard);
-  if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
-  if (ctx->d_active) (void)hipFree(ctx->d_active);
-  ctx->d_hard = ctx->d_overflow = ctx->d_active = nullptr;
-  ctx->list_cap = 0;
-  HIPCHK(ctx, hipMalloc(&ctx->d_hard, sizeof(int) * need));
-  HIPCHK(ctx, hipMalloc(&ctx->d_overflow, sizeof(int) * need));
-  HIPCHK(ctx, hipMalloc(&ctx->d_active, sizeof(int) * need));
-  ctx->list_cap = need;
+int ensure_lists(lrr_icp_ctx *ctx, K1Lane &L, size_t need) {
+  if (need <= L.list_cap) return LRR_ICP_OK;
+  if (L.d_hard) (void)hipFree(L.d_hard);
+  if (L.d_overflow) (void)hipFree(L.d_overflow);
+  if (L.d_active) (void)hipFree(L.d_active);
+  L.d_hard = L.d_overflow = L.d_active = nullptr;
+  L.list_cap = 0;
+  HIPCHK(ctx, hipMalloc(&L.d_hard, sizeof(int) * need));
+  HIPCHK(ctx, hipMalloc(&L.d_overflow, sizeof(int) * need));
+  HIPCHK(ctx, hipMalloc(&L.d_active, sizeof(int) * need));
+  L.list_cap = need;
   return LRR_ICP_OK;
 }
 
@@ -2109,26 +2116,26 @@ unsigned host_fmix32(unsigned h) {
 
 // the list counters of one K1 submission: slots are handed out round robin and all cleared together
 // when the round starts over (every earlier submission has drained by then: same stream)
-int fresh_counts(lrr_icp_ctx *ctx, int **counts) {
-  if (ctx->count_slot == 0) HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, kCountSlots * 4 * sizeof(int), ctx->stream));
-  *counts = ctx->d_counts + 4 * ctx->count_slot;
-  ctx->count_slot = (ctx->count_slot + 1) % kCountSlots;
+int fresh_counts(lrr_icp_ctx *ctx, K1Lane &L, int **counts) {
+  if (L.count_slot == 0) HIPCHK(ctx, hipMemsetAsync(L.d_counts, 0, kCountSlots * 4 * sizeof(int), L.stream));
+  *counts = L.d_counts + 4 * L.count_slot;
+  L.count_slot = (L.count_slot + 1) % kCountSlots;
   return LRR_ICP_OK;
 }
 
 // phases 2 and 3 of the grid search; both read their list length on the device and fall through
 // when it is 0
-int launch_hard_phases(lrr_icp_ctx *ctx, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts) {
+int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts) {
   int *hard_count = counts, *over_count = counts + 1;
   int hard_blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)n + 3) / 4));
-  hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, ctx->stream, g, q, xf, ctx->d_hard, hard_count, q.src ? 1 : 0, to->rec, to->orig_of, m_to, ctx->d_overflow, over_count);
+  hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, L.stream, g, q, xf, L.d_hard, hard_count, q.src ? 1 : 0, to->rec, to->orig_of, m_to, L.d_overflow, over_count);
   HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, ctx->stream, g, q, xf, ctx->d_overflow, over_count, m_to);
+  hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, L.stream, g, q, xf, L.d_overflow, over_count, m_to);
   HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
 
-int launch_brute(lrr_icp_ctx *ctx, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const int *active,
+int launch_brute(lrr_icp_ctx *ctx, K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const int *active,
                  const XfD &xf, int n, int *m_to) {
   int bx = (n + kBlock * kBruteQ - 1) / (kBlock * kBruteQ);
   int S = std::max(1, std::min(64, 1024 / bx));
@@ -2138,32 +2145,35 @@ int launch_brute(lrr_icp_ctx *ctx, const lrr_icp_cloud *to, const GridView &g, c
   chunk = ((chunk + kBruteTile - 1) / kBruteTile) * kBruteTile;
   S = (int)((to->n + chunk - 1) / chunk);
   size_t need = (size_t)S * (size_t)n;
-  if (need > ctx->brute_cap) {
-    if (ctx->d_bd) (void)hipFree(ctx->d_bd);
-    if (ctx->d_bi) (void)hipFree(ctx->d_bi);
-    ctx->d_bd = nullptr; ctx->d_bi = nullptr;
-    ctx->brute_cap = 0;
-    HIPCHK(ctx, hipMalloc(&ctx->d_bd, sizeof(double) * need));
-    HIPCHK(ctx, hipMalloc(&ctx->d_bi, sizeof(int) * 2 * need));
-    ctx->brute_cap = need;
+  if (need > L.brute_cap) {
+    if (L.d_bd) (void)hipFree(L.d_bd);
+    if (L.d_bi) (void)hipFree(L.d_bi);
+    L.d_bd = nullptr; L.d_bi = nullptr;
+    L.brute_cap = 0;
+    HIPCHK(ctx, hipMalloc(&L.d_bd, sizeof(double) * need));
+    HIPCHK(ctx, hipMalloc(&L.d_bi, sizeof(int) * 2 * need));
+    L.brute_cap = need;
   }
-  int *po = ctx->d_bi, *pc = ctx->d_bi + need;
-  hipLaunchKernelGGL(k_match_brute, dim3(bx, S), dim3(kBlock), 0, ctx->stream, g, q, active, xf, n, chunk, ctx->d_bd, po, pc);
+  int *po = L.d_bi, *pc = L.d_bi + need;
+  hipLaunchKernelGGL(k_match_brute, dim3(bx, S), dim3(kBlock), 0, L.stream, g, q, active, xf, n, chunk, L.d_bd, po, pc);
   HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, ctx->stream, ctx->d_bd, po, pc, n, S, q, active, m_to);
+  hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, L.stream, L.d_bd, po, pc, n, S, q, active, m_to);
   HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
 
-struct ProfScope {  // HIP events around one K1 submission (all phases)
+struct ProfScope {  // HIP events around K1 submissions (all phases), recorded on the stream that runs them
   lrr_icp_ctx *ctx;
+  hipStream_t st;
+  int launches;
   bool on;
-  explicit ProfScope(lrr_icp_ctx *c) : ctx(c), on(c->prof && c->pe_used + 2 <= (int)c->pe.size()) {
-    if (on) (void)hipEventRecord(ctx->pe[ctx->pe_used], ctx->stream);
+  ProfScope(lrr_icp_ctx *c, hipStream_t stream, int n_launches)
+      : ctx(c), st(stream), launches(n_launches), on(n_launches > 0 && c->prof && c->pe_used + 2 <= (int)c->pe.size()) {
+    if (on) (void)hipEventRecord(ctx->pe[ctx->pe_used], st);
   }
   ~ProfScope() {
-    if (on) { (void)hipEventRecord(ctx->pe[ctx->pe_used + 1], ctx->stream); ctx->pe_used += 2; }
-    ctx->match_launches += 1;
+    if (on) { (void)hipEventRecord(ctx->pe[ctx->pe_used + 1], st); ctx->pe_used += 2; }
+    ctx->match_launches += launches;
   }
 };
 
@@ -2216,7 +2226,12 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_pinned_dev, ctx->h_pinned, 0)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
-  if ((e = hipMalloc(&ctx->d_counts, kCountSlots * 4 * sizeof(int))) != hipSuccess) return bail(e);
+  ctx->lane[0].stream = ctx->stream;
+  if ((e = hipStreamCreateWithFlags(&ctx->lane[1].stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+  if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(e);
+  if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e);
+  for (K1Lane &L : ctx->lane)
+    if ((e = hipMalloc(&L.d_counts, kCountSlots * 4 * sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256, hipHostMallocMapped)) != hipSuccess) return bail(e);
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_fused_dev, ctx->h_fused, 0)) != hipSuccess) return bail(e);
@@ -2235,12 +2250,19 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
 void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->lane[1].stream) (void)hipStreamSynchronize(ctx->lane[1].stream);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t ev : ctx->pe) (void)hipEventDestroy(ev);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  for (K1Lane &L : ctx->lane) {
+    void *ls[] = {L.d_bd, L.d_bi, L.d_hard, L.d_overflow, L.d_active, L.d_counts, L.d_order};
+    for (void *p : ls) if (p) (void)hipFree(p);
+  }
+  if (ctx->lane[1].stream) (void)hipStreamDestroy(ctx->lane[1].stream);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  void *dev[] = {ctx->d_partials, ctx->d_final, ctx->d_jobs, ctx->d_bd, ctx->d_bi, ctx->d_hard, ctx->d_overflow,
-                 ctx->d_active, ctx->d_counts, ctx->d_order, ctx->d_fused, ctx->d_selstate, ctx->d_selhist,
+  void *dev[] = {ctx->d_partials, ctx->d_final, ctx->d_jobs, ctx->d_fused, ctx->d_selstate, ctx->d_selhist,
                  ctx->d_selprev, ctx->d_selcoll, ctx->d_selcursor};
   for (void *p : dev) if (p) (void)hipFree(p);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -2495,8 +2517,9 @@ int64_t lrr_icp_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]) {
   return (int64_t)x;
 }
 
-int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4], const int64_t *order,
-                  int64_t n_points, int method) {
+// one K1 submission on lane L (argument checks, slot map, the search phases)
+static int match_on(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4], const int64_t *order,
+                    int64_t n_points, int method, K1Lane &L, bool profile) {
   if (!d || !xf || n_points < 0) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = d->ctx;
   const int64_t N = d->from->n;
@@ -2510,23 +2533,23 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
   if (rc) return rc;
   d->from_is_copy = 0;
   d->n = n_points;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = L.stream;
   if (n_points == 0) {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
     return LRR_ICP_OK;
   }
-  if ((rc = ensure_lists(ctx, (size_t)N))) return rc;
+  if ((rc = ensure_lists(ctx, L, (size_t)N))) return rc;
   Keys kk;
   std::memset(&kk, 0, sizeof kk);
   if (keys) for (int r = 0; r < 4; ++r) kk.k[r] = keys[r];
   const int half = perm_half(N);
   const int *d_order = nullptr;
   if (order) {
-    if ((size_t)n_points > ctx->order_cap) {
-      if (ctx->d_order) (void)hipFree(ctx->d_order);
-      ctx->d_order = nullptr; ctx->order_cap = 0;
-      HIPCHK(ctx, hipMalloc(&ctx->d_order, sizeof(int) * (size_t)n_points));
-      ctx->order_cap = (size_t)n_points;
+    if ((size_t)n_points > L.order_cap) {
+      if (L.d_order) (void)hipFree(L.d_order);
+      L.d_order = nullptr; L.order_cap = 0;
+      HIPCHK(ctx, hipMalloc(&L.d_order, sizeof(int) * (size_t)n_points));
+      L.order_cap = (size_t)n_points;
     }
     std::vector<int> o32((size_t)n_points);
     std::vector<unsigned char> seen((size_t)N, 0);
@@ -2536,9 +2559,9 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
       seen[(size_t)order[i]] = 1;
       o32[(size_t)i] = (int)order[i];
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_order, o32.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(L.d_order, o32.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));  // o32 is pageable and dies at scope exit
-    d_order = ctx->d_order;
+    d_order = L.d_order;
   }
   if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
   GridView g = view_of(d->to);
@@ -2547,31 +2570,63 @@ int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4
   XfD x = to_dev(xf);
   const bool dense = !order && n_points * 4 >= N;  // fine levels: every source feature is looked at
   int *counts = nullptr;
-  if ((rc = fresh_counts(ctx, &counts))) return rc;
-  ProfScope prof(ctx);
+  if ((rc = fresh_counts(ctx, L, &counts))) return rc;
+  ProfScope prof(ctx, st, profile ? 1 : 0);
   if (method == LRR_ICP_NN_BRUTE) {
     if (dense) {
-      hipLaunchKernelGGL(k_slots_dense, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->from->src, kk, half, (int)N, (int)n_points, d->slot, d->w, ctx->d_active, counts + 2);
+      hipLaunchKernelGGL(k_slots_dense, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->from->src, kk, half, (int)N, (int)n_points, d->slot, d->w, L.d_active, counts + 2);
     } else {
       HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
-      hipLaunchKernelGGL(k_slots_sparse, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, (int)n_points, d->slot, d->w, ctx->d_active);
+      hipLaunchKernelGGL(k_slots_sparse, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, (int)n_points, d->slot, d->w, L.d_active);
     }
     HIPCHK(ctx, hipGetLastError());
-    return launch_brute(ctx, d->to, g, q, ctx->d_active, x, (int)n_points, d->m_to);
+    return launch_brute(ctx, L, d->to, g, q, L.d_active, x, (int)n_points, d->m_to);
   }
   // a level's later iterations: every active source carries its previous match -> ball search
   const bool steady = dense && d->prev_n == n_points;
   d->prev_n = dense ? n_points : -1;
   if (steady) {
-    hipLaunchKernelGGL(k_match_ball, dim3(blocks_for(N)), dim3(kBlock), 0, st, g, d->from->src, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->m_to, d->w, ctx->d_hard, counts, kBallBudget, kBallCells * g.h);
+    hipLaunchKernelGGL(k_match_ball, dim3(blocks_for(N)), dim3(kBlock), 0, st, g, d->from->src, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->m_to, d->w, L.d_hard, counts, kBallBudget, kBallCells * g.h);
   } else if (dense) {
-    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, ctx->d_hard, counts, kTileBudget);
+    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, L.d_hard, counts, kTileBudget);
   } else {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
-    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, g, q, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, x, (int)n_points, d->slot, d->m_to, d->w, ctx->d_hard, counts);
+    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, g, q, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  return launch_hard_phases(ctx, d->to, g, q, x, (int)n_points, d->m_to, counts);
+  return launch_hard_phases(ctx, L, d->to, g, q, x, (int)n_points, d->m_to, counts);
+}
+
+int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4], const int64_t *order,
+                  int64_t n_points, int method) {
+  if (!d) return LRR_ICP_ERR_ARG;
+  return match_on(d, xf, keys, order, n_points, method, d->ctx->lane[0], true);
+}
+
+// Both directions of a symmetric estimator in one submission: the forward search runs on the
+// context's stream, the backward search on a second stream, forked and joined with events, so the
+// short phases of one direction (far queries, overflow) overlap the other's wide kernels.
+int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t keys_f[4], const int64_t *order_f,
+                       int64_t n_f, lrr_icp_dir *b, const lrr_icp_xform *xf_b, const uint32_t keys_b[4],
+                       const int64_t *order_b, int64_t n_b, int method) {
+  if (!f || !b) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = f->ctx;
+  if (b->ctx != ctx) return fail(ctx, LRR_ICP_ERR_ARG, "match_pair: directions of different contexts");
+  if (f == b) return fail(ctx, LRR_ICP_ERR_ARG, "match_pair: the two directions must differ");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc, rc2;
+  {
+    ProfScope prof(ctx, ctx->stream, 2);  // fork .. join on the main stream: both searches
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->lane[1].stream, ctx->ev_fork, 0));
+    rc = match_on(f, xf_f, keys_f, order_f, n_f, method, ctx->lane[0], false);
+    rc2 = match_on(b, xf_b, keys_b, order_b, n_b, method, ctx->lane[1], false);
+    // join even after a failed submission: the main stream must not run ahead of lane 1
+    hipError_t e1 = hipEventRecord(ctx->ev_join, ctx->lane[1].stream);
+    hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) : e1;
+    if (e2 != hipSuccess && !rc && !rc2) return fail(ctx, LRR_ICP_ERR_HIP, std::string("match_pair join: ") + hipGetErrorString(e2));
+  }
+  return rc ? rc : rc2;
 }
 
 int lrr_icp_premap(lrr_icp_dir *d, const lrr_icp_xform *G) {
@@ -2962,7 +3017,8 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
   if (nq == 0) return LRR_ICP_OK;
   if (cloud->n <= 0) { for (int64_t i = 0; i < nq; ++i) idx[i] = -1; return LRR_ICP_OK; }
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = ensure_lists(ctx, (size_t)nq);
+  K1Lane &L = ctx->lane[0];
+  int rc = ensure_lists(ctx, L, (size_t)nq);
   if (rc) return rc;
   double *dq = nullptr;
   int *dto = nullptr;
@@ -2970,7 +3026,7 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
   if (hipMalloc(&dto, sizeof(int) * nq) != hipSuccess) { (void)hipFree(dq); return fail(ctx, LRR_ICP_ERR_HIP, "nearest: hipMalloc failed"); }
   if (hipMemcpy(dq, query, sizeof(double) * 3 * nq, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: upload failed");
   int *counts = nullptr;
-  if (!rc) rc = fresh_counts(ctx, &counts);
+  if (!rc) rc = fresh_counts(ctx, L, &counts);
   if (!rc) {
     GridView g = view_of(cloud);
     QSrc q;
@@ -2979,12 +3035,12 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
     std::memset(&kk, 0, sizeof kk);
     XfD x = identity_xf();
     if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
-    ProfScope prof(ctx);
-    if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, cloud, g, q, nullptr, x, (int)nq, dto);
+    ProfScope prof(ctx, ctx->stream, 1);
+    if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, L, cloud, g, q, nullptr, x, (int)nq, dto);
     else {
-      hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, ctx->d_hard, counts);
+      hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, L.d_hard, counts);
       if (hipGetLastError() != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: launch failed");
-      if (!rc) rc = launch_hard_phases(ctx, cloud, g, q, x, (int)nq, dto, counts);
+      if (!rc) rc = launch_hard_phases(ctx, L, cloud, g, q, x, (int)nq, dto, counts);
     }
   }
   std::vector<int> tmp((size_t)nq);

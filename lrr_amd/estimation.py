@@ -28,7 +28,7 @@ ICP_SYMBOLS = [
     "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile",
     "lrr_icp_cloud_create", "lrr_icp_cloud_destroy", "lrr_icp_cloud_size",
     "lrr_icp_dir_create", "lrr_icp_dir_destroy", "lrr_icp_dir_set_from", "lrr_icp_dir_num_matches",
-    "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_premap",
+    "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
     "lrr_icp_residual_pass", "lrr_icp_muse_scale", "lrr_icp_assign_weights",
     "lrr_icp_normalize_stats", "lrr_icp_clone_weights", "lrr_icp_weight_by_strength",
     "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_get_matches",
