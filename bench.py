@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--n", type=int, default=N_FEATURES, help="features per volume (default: BASELINE size)")
     ap.add_argument("--nn", choices=["grid", "brute"], default="grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--cpu-iters", type=int, default=60)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on fewer GPUs)")
     ap.add_argument("--workload", choices=["c3", "locations"], default="c3",
@@ -225,7 +225,9 @@ def main():
                        "nn": args.nn, "schedule_iterations_before_timing": schedule_iters,
                        "parallelism": f"{world} independent problem(s), one per GPU; one all_gather of the final transforms"},
             "roofline": {"bound": "hbm",
-                         "kernel": ("K1 find_closest_euclidean = k_match_tile + k_match_hard + k_match_overflow"
+                         "kernel": ("K1 find_closest_euclidean = k_match_ball + k_match_hard + k_match_overflow per direction; "
+                                    "forward and backward searches run concurrently (lrr_icp_match_pair): kernel_ms = "
+                                    "HIP-event time of the pair / 2"
                                     if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
