@@ -733,58 +733,82 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
 constexpr int kBallRows = 9;        // (z,y) rows whose cell bounds a lane fetches in one round trip
 constexpr int kBallBudget = 64;     // candidates a lane may scan before handing its query over
 constexpr double kBallCells = 2.0;  // widest ball (in cells) the thread-per-query search takes
-__global__ __launch_bounds__(kBlock) void k_match_ball(GridView g, const SrcPoint *src, Keys keys, int half,
-                                                       int nsrc, int n_points, XfD xf, const double *to_rec,
-                                                       const int *to_orig_of, int *slot, const int *m_prev, int *m_to, double *w,
-                                                       int *hard, int *hard_count, int budget, double max_rad) {
+struct BallArgs {  // one direction of a ball search
+  GridView g;
+  const SrcPoint *src;
+  Keys keys;
+  int half, nsrc, n_points;
+  XfD xf;
+  const double *to_rec;
+  const int *to_orig_of;
+  int *slot, *m_to;
+  double *w;
+  int *hard, *hard_count;
+  int budget;
+  double max_rad;
+};
+__device__ __forceinline__ void match_ball_body(const BallArgs &A) {
+  const GridView &g = A.g;
+  const SrcPoint *src = A.src;
+  const int nsrc = A.nsrc;
+  int budget = A.budget;
   const int s = blockIdx.x * kBlock + threadIdx.x;
   if (s >= nsrc) return;
   const SrcPoint sp = src[s];
-  const int prev = m_prev[s];
-  const int j = subset_perm_inv((int)sp.orig, nsrc, half, keys);
-  const bool active = j < n_points;
-  slot[s] = active ? j : -1;
+  const int prev = A.m_to[s];
+  const int j = subset_perm_inv((int)sp.orig, nsrc, A.half, A.keys);
+  const bool active = j < A.n_points;
+  A.slot[s] = active ? j : -1;
   if (!active) return;
-  w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-  if (prev < 0) { hard[atomicAdd(hard_count, 1)] = s; return; }
+  A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+  if (prev < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }
   double yx, yy, yz;
-  map_loc(xf, sp.x, sp.y, sp.z, yx, yy, yz);
+  map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
   Best b;
   {
-    const double *q = to_rec + (size_t)prev * kRecStride;
+    const double *q = A.to_rec + (size_t)prev * kRecStride;
     b.d = dist2(yx, yy, yz, q[0], q[1], q[2]);
-    b.orig = to_orig_of[prev];
+    b.orig = A.to_orig_of[prev];
     b.canon = prev;
   }
   const double rad = sqrt(b.d) + 2.0 * g.tol;
-  if (!(rad <= max_rad)) { hard[atomicAdd(hard_count, 1)] = s; return; }  // outlier: a whole wavefront serves it better
+  if (!(rad <= A.max_rad)) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }  // outlier: a whole wavefront serves it better
   const double inv_hx = g.inv_h * g.fine;
   const int fdx = g.dx * g.fine;  // x-slices per row
   const int xa0 = clampi((int)floor((yx - rad - g.lox) * inv_hx), 0, fdx - 1), xb0 = clampi((int)floor((yx + rad - g.lox) * inv_hx), 0, fdx - 1);
   const int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
   const int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
   const int nyr = yb - ya + 1, nrows = nyr * (zb - za + 1);
+  // Row pruning runs in single precision on cell units and only has to be CONSERVATIVE: the query
+  // in cells (error < 1e-4 cell for grids of <= 512 cells), the radius rounded up plus 1e-3 cell.
+  const float uy = (float)((yy - g.loy) * g.inv_h), uz = (float)((yz - g.loz) * g.inv_h);
+  const float uxs = (float)((yx - g.lox) * inv_hx), finef = (float)g.fine;
+  const float inv_hf = (float)g.inv_h * 1.000001f;
   int yi = ya, zi = za;  // (z,y) of row r0: advanced without integer division
+  int row = (za * g.dy + ya) * fdx;
+  const int row_wrap = (g.dy - nyr) * fdx;
   for (int r0 = 0; r0 < nrows; r0 += kBallRows) {
+    const float rc = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + 1e-3f;
+    const float rc2 = rc * rc;
     int rs[kBallRows], re[kBallRows];
 #pragma unroll
     for (int u = 0; u < kBallRows; ++u) {
       rs[u] = 0; re[u] = 0;
       if (r0 + u < nrows) {
-        const double gz_ = slab_gap(yz, g.loz + zi * g.h, g.loz + (zi + 1) * g.h, g.tol);
-        const double gy_ = slab_gap(yy, g.loy + yi * g.h, g.loy + (yi + 1) * g.h, g.tol);
-        const double dyz2 = gz_ * gz_ + gy_ * gy_;
-        if (dyz2 <= b.d) {  // strictly farther rows cannot hold a better or an equal candidate
-          // half-width of the ball in this row, rounded UP (single-precision root, 1 ulp, plus margin)
-          const double rx = (double)(__builtin_amdgcn_sqrtf((float)(b.d - dyz2)) * 1.000002f) + 2.0 * g.tol;
-          const int xa = max(xa0, (int)floor((yx - rx - g.lox) * inv_hx)), xb = min(xb0, (int)floor((yx + rx - g.lox) * inv_hx));
+        const float fy = (float)yi, fz = (float)zi;
+        const float gy_ = fmaxf(fmaxf(fy - uy, uy - (fy + 1.0f)), 0.0f);
+        const float gz_ = fmaxf(fmaxf(fz - uz, uz - (fz + 1.0f)), 0.0f);
+        const float dyz2 = gz_ * gz_ + gy_ * gy_;
+        if (dyz2 <= rc2) {  // farther rows cannot hold a better or an equal candidate
+          const float rxs = __builtin_amdgcn_sqrtf(rc2 - dyz2) * finef;  // half-width of the ball in this row, in slices
+          const int xa = max(xa0, (int)floorf(uxs - rxs)), xb = min(xb0, (int)floorf(uxs + rxs));
           if (xa <= xb) {
-            const int row = (zi * g.dy + yi) * fdx;
             rs[u] = g.fine_start[row + xa];
             re[u] = g.fine_start[row + xb + 1];
           }
         }
-        if (++yi > yb) { yi = ya; ++zi; }
+        row += fdx;
+        if (++yi > yb) { yi = ya; ++zi; row += row_wrap; }
       }
     }
     // candidate c of the concatenated runs sits at c + off[u], off[u] = rs[u] - pre[u], for the last
@@ -797,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void k_match_ball(GridView g, const SrcPoin
       total += re[u] - rs[u];
     }
     budget -= total;
-    if (budget < 0) { hard[atomicAdd(hard_count, 1)] = s; return; }  // m_to[s] keeps the previous match
+    if (budget < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }  // m_to[s] keeps the previous match
     for (int c0 = 0; c0 < total; c0 += kScanUnroll) {
       GridPoint pt[kScanUnroll];
 #pragma unroll
@@ -813,7 +837,14 @@ __global__ __launch_bounds__(kBlock) void k_match_ball(GridView g, const SrcPoin
         if (c0 + v < total) consider(b, dist2(yx, yy, yz, pt[v].x, pt[v].y, pt[v].z), pt[v].orig, pt[v].canon);
     }
   }
-  m_to[s] = b.canon;
+  A.m_to[s] = b.canon;
+}
+
+__global__ __launch_bounds__(kBlock) void k_match_ball(BallArgs A) { match_ball_body(A); }
+// both directions of a symmetric estimator in one launch: blockIdx.y picks the direction
+__global__ __launch_bounds__(kBlock) void k_match_ball2(BallArgs A, BallArgs B) {
+  if (blockIdx.y == 0) match_ball_body(A);
+  else match_ball_body(B);
 }
 
 // K1 phase 2: the queries phase 1 handed over (far from any target feature, next to cells too
@@ -861,14 +892,29 @@ __device__ __forceinline__ void wave_scan_runs(const GridView &g, int (*seg_s)[6
   consider(b, l.d, l.orig, l.canon);
 }
 
-__global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QSrc q, XfD xf, const int *hard,
-                                                       const int *hard_count, int use_prev,
-                                                       const double *to_rec, const int *to_orig_of, int *m_to,
-                                                       int *overflow, int *overflow_count) {
+struct HardArgs {  // one direction of the wave-per-query phase
+  GridView g;
+  QSrc q;
+  XfD xf;
+  const int *hard, *hard_count;
+  int use_prev;
+  const double *to_rec;
+  const int *to_orig_of;
+  int *m_to, *overflow, *overflow_count;
+};
+__device__ __forceinline__ void match_hard_body(const HardArgs &A) {
   __shared__ int seg_s[kBlock / 64][64], seg_pre[kBlock / 64][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const GridView &g = A.g;
+  const QSrc &q = A.q;
+  const XfD &xf = A.xf;
+  const int *hard = A.hard;
+  const int use_prev = A.use_prev;
+  const double *to_rec = A.to_rec;
+  const int *to_orig_of = A.to_orig_of;
+  int *m_to = A.m_to, *overflow = A.overflow, *overflow_count = A.overflow_count;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
-  const int cnt = *hard_count;
+  const int cnt = *A.hard_count;
   for (int o = wave; o < cnt; o += nwaves) {
     int s = hard[o];
     double x, y_, z_, yx, yy, yz;
@@ -955,13 +1001,23 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(GridView g, QSrc q, XfD x
     }
   }
 }
+__global__ __launch_bounds__(kBlock) void k_match_hard(HardArgs A) { match_hard_body(A); }
+__global__ __launch_bounds__(kBlock) void k_match_hard2(HardArgs A, HardArgs B) {
+  if (blockIdx.y == 0) match_hard_body(A);
+  else match_hard_body(B);
+}
 
 // K1 phase 3: brute force for the (rare) queries still open after kRingMax rings: one block each
-__global__ __launch_bounds__(kBlock) void k_match_overflow(GridView g, QSrc q, XfD xf, const int *overflow,
-                                                           const int *overflow_count, int *m_to) {
+struct OverArgs { GridView g; QSrc q; XfD xf; const int *overflow, *overflow_count; int *m_to; };
+__device__ __forceinline__ void match_overflow_body(const OverArgs &A) {
   __shared__ double sd[kBlock];
   __shared__ int so[kBlock], sc[kBlock];
-  int cnt = *overflow_count;
+  const GridView &g = A.g;
+  const QSrc &q = A.q;
+  const XfD &xf = A.xf;
+  const int *overflow = A.overflow;
+  int *m_to = A.m_to;
+  int cnt = *A.overflow_count;
   for (int o = blockIdx.x; o < cnt; o += gridDim.x) {
     int s = overflow[o];
     double x, y_, z_, yx, yy, yz;
@@ -986,6 +1042,11 @@ __global__ __launch_bounds__(kBlock) void k_match_overflow(GridView g, QSrc q, X
     if (threadIdx.x == 0) { Best a; a.d = sd[0]; a.orig = so[0]; a.canon = sc[0]; m_to[s] = result_index(q, a); }
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(kBlock) void k_match_overflow(OverArgs A) { match_overflow_body(A); }
+__global__ __launch_bounds__(kBlock) void k_match_overflow2(OverArgs A, OverArgs B) {
+  if (blockIdx.y == 0) match_overflow_body(A);
+  else match_overflow_body(B);
 }
 
 // slot assignment + active list for the all-vs-all matcher
@@ -2116,8 +2177,8 @@ unsigned host_fmix32(unsigned h) {
 
 // the list counters of one K1 submission: slots are handed out round robin and all cleared together
 // when the round starts over (every earlier submission has drained by then: same stream)
-int fresh_counts(lrr_icp_ctx *ctx, K1Lane &L, int **counts) {
-  if (L.count_slot == 0) HIPCHK(ctx, hipMemsetAsync(L.d_counts, 0, kCountSlots * 4 * sizeof(int), L.stream));
+int fresh_counts(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, int **counts) {
+  if (L.count_slot == 0) HIPCHK(ctx, hipMemsetAsync(L.d_counts, 0, kCountSlots * 4 * sizeof(int), st));
   *counts = L.d_counts + 4 * L.count_slot;
   L.count_slot = (L.count_slot + 1) % kCountSlots;
   return LRR_ICP_OK;
@@ -2125,17 +2186,32 @@ int fresh_counts(lrr_icp_ctx *ctx, K1Lane &L, int **counts) {
 
 // phases 2 and 3 of the grid search; both read their list length on the device and fall through
 // when it is 0
-int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts) {
-  int *hard_count = counts, *over_count = counts + 1;
-  int hard_blocks = (int)std::min<int64_t>(4096, std::max<int64_t>(1, ((int64_t)n + 3) / 4));
-  hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks), dim3(kBlock), 0, L.stream, g, q, xf, L.d_hard, hard_count, q.src ? 1 : 0, to->rec, to->orig_of, m_to, L.d_overflow, over_count);
+HardArgs hard_args(K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int *m_to, int *counts) {
+  HardArgs a;
+  a.g = g; a.q = q; a.xf = xf;
+  a.hard = L.d_hard; a.hard_count = counts;
+  a.use_prev = q.src ? 1 : 0;
+  a.to_rec = to->rec; a.to_orig_of = to->orig_of;
+  a.m_to = m_to; a.overflow = L.d_overflow; a.overflow_count = counts + 1;
+  return a;
+}
+OverArgs over_args(const HardArgs &h) {
+  OverArgs a;
+  a.g = h.g; a.q = h.q; a.xf = h.xf; a.overflow = h.overflow; a.overflow_count = h.overflow_count; a.m_to = h.m_to;
+  return a;
+}
+inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n + 3) / 4)); }
+
+int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts) {
+  HardArgs h = hard_args(L, to, g, q, xf, m_to, counts);
+  hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n)), dim3(kBlock), 0, st, h);
   HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, L.stream, g, q, xf, L.d_overflow, over_count, m_to);
+  hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, st, over_args(h));
   HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
 
-int launch_brute(lrr_icp_ctx *ctx, K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const int *active,
+int launch_brute(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const int *active,
                  const XfD &xf, int n, int *m_to) {
   int bx = (n + kBlock * kBruteQ - 1) / (kBlock * kBruteQ);
   int S = std::max(1, std::min(64, 1024 / bx));
@@ -2155,9 +2231,9 @@ int launch_brute(lrr_icp_ctx *ctx, K1Lane &L, const lrr_icp_cloud *to, const Gri
     L.brute_cap = need;
   }
   int *po = L.d_bi, *pc = L.d_bi + need;
-  hipLaunchKernelGGL(k_match_brute, dim3(bx, S), dim3(kBlock), 0, L.stream, g, q, active, xf, n, chunk, L.d_bd, po, pc);
+  hipLaunchKernelGGL(k_match_brute, dim3(bx, S), dim3(kBlock), 0, st, g, q, active, xf, n, chunk, L.d_bd, po, pc);
   HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, L.stream, L.d_bd, po, pc, n, S, q, active, m_to);
+  hipLaunchKernelGGL(k_brute_merge, dim3(blocks_for(n)), dim3(kBlock), 0, st, L.d_bd, po, pc, n, S, q, active, m_to);
   HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
@@ -2517,9 +2593,24 @@ int64_t lrr_icp_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]) {
   return (int64_t)x;
 }
 
-// one K1 submission on lane L (argument checks, slot map, the search phases)
-static int match_on(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4], const int64_t *order,
-                    int64_t n_points, int method, K1Lane &L, bool profile) {
+// what one K1 submission needs after its arguments have been checked
+struct MatchPrep {
+  Keys kk;
+  int half = 1;
+  const int *d_order = nullptr;
+  GridView g;
+  QSrc q;
+  XfD x;
+  int *counts = nullptr;
+  int64_t N = 0;
+  bool dense = false, steady = false, use_keys = false, empty = false;
+  int method = LRR_ICP_NN_GRID;
+};
+
+// argument checks, capacities, explicit order upload, counters: everything before the launches.
+// Work is queued on `st`; scratch comes from lane L.
+static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4], const int64_t *order,
+                         int64_t n_points, int method, K1Lane &L, hipStream_t st, MatchPrep &P) {
   if (!d || !xf || n_points < 0) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = d->ctx;
   const int64_t N = d->from->n;
@@ -2533,17 +2624,17 @@ static int match_on(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys
   if (rc) return rc;
   d->from_is_copy = 0;
   d->n = n_points;
-  hipStream_t st = L.stream;
-  if (n_points == 0) {
+  P.N = N;
+  P.empty = n_points == 0;
+  if (P.empty) {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
     return LRR_ICP_OK;
   }
   if ((rc = ensure_lists(ctx, L, (size_t)N))) return rc;
-  Keys kk;
-  std::memset(&kk, 0, sizeof kk);
-  if (keys) for (int r = 0; r < 4; ++r) kk.k[r] = keys[r];
-  const int half = perm_half(N);
-  const int *d_order = nullptr;
+  std::memset(&P.kk, 0, sizeof P.kk);
+  if (keys) for (int r = 0; r < 4; ++r) P.kk.k[r] = keys[r];
+  P.use_keys = keys != nullptr;
+  P.half = perm_half(N);
   if (order) {
     if ((size_t)n_points > L.order_cap) {
       if (L.d_order) (void)hipFree(L.d_order);
@@ -2561,40 +2652,64 @@ static int match_on(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys
     }
     HIPCHK(ctx, hipMemcpyAsync(L.d_order, o32.data(), sizeof(int) * (size_t)n_points, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));  // o32 is pageable and dies at scope exit
-    d_order = L.d_order;
+    P.d_order = L.d_order;
   }
-  if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
-  GridView g = view_of(d->to);
-  QSrc q;
-  q.src = d->from->src; q.raw = nullptr; q.want_orig = 0;
-  XfD x = to_dev(xf);
-  const bool dense = !order && n_points * 4 >= N;  // fine levels: every source feature is looked at
-  int *counts = nullptr;
-  if ((rc = fresh_counts(ctx, L, &counts))) return rc;
-  ProfScope prof(ctx, st, profile ? 1 : 0);
-  if (method == LRR_ICP_NN_BRUTE) {
-    if (dense) {
-      hipLaunchKernelGGL(k_slots_dense, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->from->src, kk, half, (int)N, (int)n_points, d->slot, d->w, L.d_active, counts + 2);
+  P.method = method == LRR_ICP_NN_AUTO ? LRR_ICP_NN_GRID : method;
+  P.g = view_of(d->to);
+  P.q.src = d->from->src; P.q.raw = nullptr; P.q.want_orig = 0;
+  P.x = to_dev(xf);
+  P.dense = !order && n_points * 4 >= N;  // fine levels: every source feature is looked at
+  if ((rc = fresh_counts(ctx, L, st, &P.counts))) return rc;
+  // a level's later iterations: every active source carries its previous match -> ball search
+  P.steady = P.method == LRR_ICP_NN_GRID && P.dense && d->prev_n == n_points;
+  if (P.method == LRR_ICP_NN_GRID) d->prev_n = P.dense ? n_points : -1;
+  return LRR_ICP_OK;
+}
+
+static BallArgs ball_args(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L) {
+  BallArgs a;
+  a.g = P.g; a.src = d->from->src; a.keys = P.kk; a.half = P.half; a.nsrc = (int)P.N; a.n_points = (int)d->n;
+  a.xf = P.x; a.to_rec = d->to->rec; a.to_orig_of = d->to->orig_of;
+  a.slot = d->slot; a.m_to = d->m_to; a.w = d->w; a.hard = L.d_hard; a.hard_count = P.counts;
+  a.budget = kBallBudget; a.max_rad = kBallCells * P.g.h;
+  return a;
+}
+
+// the launches of one prepared submission on stream st
+static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream_t st) {
+  lrr_icp_ctx *ctx = d->ctx;
+  if (P.empty) return LRR_ICP_OK;
+  const int64_t N = P.N, n_points = d->n;
+  if (P.method == LRR_ICP_NN_BRUTE) {
+    if (P.dense) {
+      hipLaunchKernelGGL(k_slots_dense, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->from->src, P.kk, P.half, (int)N, (int)n_points, d->slot, d->w, L.d_active, P.counts + 2);
     } else {
       HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
-      hipLaunchKernelGGL(k_slots_sparse, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, (int)n_points, d->slot, d->w, L.d_active);
+      hipLaunchKernelGGL(k_slots_sparse, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, (int)n_points, d->slot, d->w, L.d_active);
     }
     HIPCHK(ctx, hipGetLastError());
-    return launch_brute(ctx, L, d->to, g, q, L.d_active, x, (int)n_points, d->m_to);
+    return launch_brute(ctx, L, st, d->to, P.g, P.q, L.d_active, P.x, (int)n_points, d->m_to);
   }
-  // a level's later iterations: every active source carries its previous match -> ball search
-  const bool steady = dense && d->prev_n == n_points;
-  d->prev_n = dense ? n_points : -1;
-  if (steady) {
-    hipLaunchKernelGGL(k_match_ball, dim3(blocks_for(N)), dim3(kBlock), 0, st, g, d->from->src, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->m_to, d->w, L.d_hard, counts, kBallBudget, kBallCells * g.h);
-  } else if (dense) {
-    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, g, d->from->src, d->from->chunks, kk, half, (int)N, (int)n_points, x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, L.d_hard, counts, kTileBudget);
+  if (P.steady) {
+    hipLaunchKernelGGL(k_match_ball, dim3(blocks_for(N)), dim3(kBlock), 0, st, ball_args(d, P, L));
+  } else if (P.dense) {
+    hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, P.g, d->from->src, d->from->chunks, P.kk, P.half, (int)N, (int)n_points, P.x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, L.d_hard, P.counts, kTileBudget);
   } else {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
-    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, g, q, d_order, keys ? 1 : 0, kk, half, (int)N, d->from->canon_of, x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, counts);
+    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, P.counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  return launch_hard_phases(ctx, L, d->to, g, q, x, (int)n_points, d->m_to, counts);
+  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts);
+}
+
+// one K1 submission on lane L and its stream
+static int match_on(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4], const int64_t *order,
+                    int64_t n_points, int method, K1Lane &L, bool profile) {
+  MatchPrep P;
+  int rc = match_prepare(d, xf, keys, order, n_points, method, L, L.stream, P);
+  if (rc) return rc;
+  ProfScope prof(d->ctx, L.stream, profile && !P.empty ? 1 : 0);
+  return match_launch(d, P, L, L.stream);
 }
 
 int lrr_icp_match(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys[4], const int64_t *order,
@@ -2615,6 +2730,34 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
   if (f == b) return fail(ctx, LRR_ICP_ERR_ARG, "match_pair: the two directions must differ");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc, rc2;
+  // Later iterations of a level (both directions in the ball-search state): every phase handles both
+  // directions in ONE launch on the main stream (blockIdx.y = direction) — no fork/join at all.
+  const bool both_steady = method != LRR_ICP_NN_BRUTE && !order_f && !order_b && n_f > 0 && n_b > 0 &&
+                           n_f * 4 >= f->from->n && n_b * 4 >= b->from->n && f->prev_n == n_f && b->prev_n == n_b;
+  if (both_steady) {
+    MatchPrep Pf, Pb;
+    hipStream_t st = ctx->stream;
+    if ((rc = match_prepare(f, xf_f, keys_f, order_f, n_f, method, ctx->lane[0], st, Pf))) return rc;
+    if ((rc = match_prepare(b, xf_b, keys_b, order_b, n_b, method, ctx->lane[1], st, Pb))) return rc;
+    if (Pf.steady && Pb.steady) {
+      ProfScope prof(ctx, st, 2);
+      BallArgs af = ball_args(f, Pf, ctx->lane[0]), ab = ball_args(b, Pb, ctx->lane[1]);
+      hipLaunchKernelGGL(k_match_ball2, dim3(std::max(blocks_for(Pf.N), blocks_for(Pb.N)), 2), dim3(kBlock), 0, st, af, ab);
+      HIPCHK(ctx, hipGetLastError());
+      HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);
+      HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
+      hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
+      HIPCHK(ctx, hipGetLastError());
+      hipLaunchKernelGGL(k_match_overflow2, dim3(128, 2), dim3(kBlock), 0, st, over_args(hf), over_args(hb));
+      HIPCHK(ctx, hipGetLastError());
+      return LRR_ICP_OK;
+    }
+    // (not reached: the test above mirrors match_prepare's) fall through to separate launches
+    ProfScope prof(ctx, st, 2);
+    rc = match_launch(f, Pf, ctx->lane[0], st);
+    rc2 = match_launch(b, Pb, ctx->lane[1], st);
+    return rc ? rc : rc2;
+  }
   {
     ProfScope prof(ctx, ctx->stream, 2);  // fork .. join on the main stream: both searches
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -3026,7 +3169,7 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
   if (hipMalloc(&dto, sizeof(int) * nq) != hipSuccess) { (void)hipFree(dq); return fail(ctx, LRR_ICP_ERR_HIP, "nearest: hipMalloc failed"); }
   if (hipMemcpy(dq, query, sizeof(double) * 3 * nq, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: upload failed");
   int *counts = nullptr;
-  if (!rc) rc = fresh_counts(ctx, L, &counts);
+  if (!rc) rc = fresh_counts(ctx, L, ctx->stream, &counts);
   if (!rc) {
     GridView g = view_of(cloud);
     QSrc q;
@@ -3036,11 +3179,11 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
     XfD x = identity_xf();
     if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
     ProfScope prof(ctx, ctx->stream, 1);
-    if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, L, cloud, g, q, nullptr, x, (int)nq, dto);
+    if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, L, ctx->stream, cloud, g, q, nullptr, x, (int)nq, dto);
     else {
       hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, L.d_hard, counts);
       if (hipGetLastError() != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: launch failed");
-      if (!rc) rc = launch_hard_phases(ctx, L, cloud, g, q, x, (int)nq, dto, counts);
+      if (!rc) rc = launch_hard_phases(ctx, L, ctx->stream, cloud, g, q, x, (int)nq, dto, counts);
     }
   }
   std::vector<int> tmp((size_t)nq);
