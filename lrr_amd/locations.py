@@ -21,9 +21,10 @@ def location_seed(seed: int, index: int) -> int:
     return (int(seed) * 1000003 + int(index) * 7919 + 1) & 0xFFFFFFFFFFFFFFFF
 
 
-def _run_block(pair, rois, inits, indices, seed):
-    """One estimator object re-used over `indices` (a host thread = one device context)."""
-    est = None
+def _run_block(pair, rois, inits, indices, seed, est=None):
+    """One estimator object re-used over `indices` (a host thread = one device context).  `est`: an
+    estimator that already holds the two volumes (uploaded by an earlier block); returns it for the
+    next one."""
     rows, pairs = [], 0
     for i in indices:
         _, _, mi, fi = rois[i]
@@ -42,37 +43,48 @@ def _run_block(pair, rois, inits, indices, seed):
         pairs += p
         A, t, c, _ = est.get_transform()
         rows.append(multi_gpu.pack_result(i, converged, it, A, t, c, est.weighted_error(), est.RMS_error()))
-    if est is not None:
-        est.close()
-    return rows, pairs
+    return rows, pairs, est
 
 
 def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1,
-                       seed: int = 7, gather_device=None, workers: int = 1, device_index=None):
+                       seed: int = 7, gather_device=None, workers: int = 1, device_index=None,
+                       estimators=None):
     """rois: list of (centre_fixed, centre_moving, moving_idx, fixed_idx) (synth.query_rois);
     inits: list of synth.Transform, the initial transform of every location.
     workers > 1: the rank's block is dealt round-robin to that many host threads, each with its own
-    device context and estimator (a single small problem leaves the GPU mostly idle: the iterations
-    of a 1-3k-feature ROI are kernel-boundary bound), so their streams overlap.  Every location is
-    estimated by exactly one estimator started from its own initial transform: results do not
-    depend on `workers`.
+    device context and estimator.  Every location is estimated by exactly one estimator started from
+    its own initial transform: results do not depend on `workers`.
+    estimators: a list (one slot per worker, None = not built yet) that keeps the estimator objects —
+    and with them the two uploaded volumes — alive between calls; without it they are built and
+    closed inside the call.
     Returns (rows of multi_gpu.RESULT_WIDTH for ALL locations, matched pairs processed by this rank)."""
     mine = list(multi_gpu.shard(len(rois), rank, world))
+    keep = estimators is not None
+    if estimators is None:
+        estimators = [None] * max(1, workers)
+    while len(estimators) < max(1, workers):
+        estimators.append(None)
     if workers <= 1 or len(mine) <= 1:
-        rows, pairs = _run_block(pair, rois, inits, mine, seed)
+        rows, pairs, estimators[0] = _run_block(pair, rois, inits, mine, seed, estimators[0])
     else:
         from concurrent.futures import ThreadPoolExecutor
 
         def work(k):
             if device_index is not None:
                 E.set_device(device_index)  # contexts are per host thread
-            return _run_block(pair, rois, inits, mine[k::workers], seed)
+            return _run_block(pair, rois, inits, mine[k::workers], seed, estimators[k])
 
         with ThreadPoolExecutor(max_workers=workers) as pool:
             parts = list(pool.map(work, range(workers)))
+        for k, part in enumerate(parts):
+            estimators[k] = part[2]
         rows = [r for p in parts for r in p[0]]
         rows.sort(key=lambda r: r[19])
         pairs = sum(p[1] for p in parts)
+    if not keep:
+        for e in estimators:
+            if e is not None:
+                e.close()
     local = np.stack(rows) if rows else np.zeros((0, multi_gpu.RESULT_WIDTH))
     if world == 1:  # also a single-rank call made inside a multi-rank job (bench warm-up): no collective
         return local, pairs
