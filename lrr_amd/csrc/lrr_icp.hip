@@ -162,6 +162,7 @@ struct lrr_icp_dir {
   int *slot = nullptr;   // list position of source s, -1 when s is not in the active subset
   int *m_to = nullptr;   // canonical target index
   double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
+  double *q_loc = nullptr;     // 3 per source: location of the matched target, cached by the fused residual pass
   double *from_loc = nullptr;  // 3 per source: pre-mapped copies
   int from_is_copy = 0;
   unsigned *flag = nullptr; int64_t flag_cap = 0;  // per target: stamp of the last call that matched it
@@ -314,19 +315,27 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *parti
   }
 }
 
-// sum of column k over rows [r0, r1) of a row-major partials table; same value in every thread
-__device__ __forceinline__ double block_total(const double *P, int r0, int r1, int K, int k) {
-  __shared__ double sh[kBlock / 64];
-  double s = 0.0;
-  for (int b = r0 + (int)threadIdx.x; b < r1; b += kBlock) s += P[(size_t)b * K + k];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  double tot = sh[0];
+// K block-wide totals at once (per-thread partial sums in, totals out, same value in every thread
+// and in every block: lanes by shuffle tree, then the 4 waves in index order).  The consumer kernels
+// of the fused estimate derive their scalars from the producers' partial tables with it: one memory
+// round trip and one barrier pair for all scalars of a kernel.
+template <int K>
+__device__ __forceinline__ void block_sum_all(double (&v)[K]) {
+  __shared__ double sh[kBlock / 64][K];
 #pragma unroll
-  for (int w2 = 1; w2 < kBlock / 64; ++w2) tot += sh[w2];
+  for (int k = 0; k < K; ++k) {
+    double s = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = s;
+  }
   __syncthreads();
-  return tot;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double t = sh[0][k];
+#pragma unroll
+    for (int w2 = 1; w2 < kBlock / 64; ++w2) t += sh[w2][k];
+    v[k] = t;
+  }
+  __syncthreads();
 }
 
 // one wavefront per output value: lane l sums blocks l, l+64, ... in order, then the fixed
@@ -1791,6 +1800,7 @@ struct DirArgs {
   PairSrc ps;
   int n;               // active matches
   double *w, *wc, *r2, *key_s, *key_g;
+  double *q_loc;       // matched target locations: written by F1, streamed by F4 and F6 (no second and third gather)
   unsigned *flag, gen;  // distinct-target stamps of this call
   int float_product;
 };
@@ -1810,15 +1820,27 @@ __global__ __launch_bounds__(kBlock) void k_f_residual(DirArgs F, DirArgs B, int
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
     if (D.ps.slot[s] < 0) { D.key_s[s] = INFINITY; continue; }
-    double r2 = pair_residual2(D.ps, s, xf, ident);
+    // the one gather of the matched target's record in this estimate: location and strength gain
+    // are kept per source for the weight and normal-equation passes
+    double p0, p1, p2, y0, y1, y2;
+    load_from(D.ps, s, p0, p1, p2);
+    const double *q = D.ps.to_rec + (size_t)D.ps.m_to[s] * kRecStride;
+    const double q0 = q[0], q1 = q[1], q2 = q[2];
+    map_loc(xf, (p0 - ident.cm[0]) / ident.rm, (p1 - ident.cm[1]) / ident.rm, (p2 - ident.cm[2]) / ident.rm, y0, y1, y2);
+    double r2 = proj_residual2(y0, y1, y2, (q0 - ident.cf[0]) / ident.rf, (q1 - ident.cf[1]) / ident.rf, (q2 - ident.cf[2]) / ident.rf,
+                               q[3], q[4], q[5], q[6], q[7], q[8]);
+    D.q_loc[3 * (size_t)s] = q0; D.q_loc[3 * (size_t)s + 1] = q1; D.q_loc[3 * (size_t)s + 2] = q2;
+    {
+      const double sp = D.ps.from_rec[(size_t)s * kRecStride + 9], sq = q[9];
+      const double g = D.float_product ? (double)((float)sp * (float)sq) : sp * sq;
+      D.key_g[s] = g > 90000.0 ? 90000.0 : g;  // strength_gain(); F4 turns it into the selection key
+    }
     double wp = D.w[s];
     acc[0] += wp * r2;
     acc[1] += wp;
     D.r2[s] = r2;
     D.key_s[s] = sqrt(r2);
     if (isF && want_stats) {
-      double p0, p1, p2;
-      load_from(D.ps, s, p0, p1, p2);
       acc[2] += p0; acc[3] += p1; acc[4] += p2;
       D.flag[D.ps.m_to[s]] = D.gen;
     }
@@ -1831,9 +1853,14 @@ __global__ __launch_bounds__(kBlock) void k_f_radii(DirArgs F, int nbF, const do
                                                     int nbT, const double *to_rec, int nt, double *P3,
                                                     double *SC) {
   double cm[3], cf[3];
-  for (int k = 0; k < 3; ++k) cm[k] = block_total(P1, 0, nbF, 5, 2 + k) / (double)F.n;
-  double nd = block_total(P2, 0, nbT, 4, 3);
-  for (int k = 0; k < 3; ++k) cf[k] = block_total(P2, 0, nbT, 4, k) / nd;
+  double tot[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // from-sums (3), distinct-to sums (3) and their count
+  for (int b = threadIdx.x; b < nbF; b += kBlock)
+    for (int k = 0; k < 3; ++k) tot[k] += P1[(size_t)b * 5 + 2 + k];
+  for (int b = threadIdx.x; b < nbT; b += kBlock)
+    for (int k = 0; k < 4; ++k) tot[3 + k] += P2[(size_t)b * 4 + k];
+  block_sum_all<7>(tot);
+  const double nd = tot[6];
+  for (int k = 0; k < 3; ++k) { cm[k] = tot[k] / (double)F.n; cf[k] = tot[3 + k] / nd; }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int k = 0; k < 3; ++k) { SC[SC_CM + k] = cm[k]; SC[SC_CF + k] = cf[k]; }
     SC[SC_ND] = nd;
@@ -1884,17 +1911,17 @@ __global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int 
   const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
   const int r0 = isF ? 0 : nbF, r1 = isF ? nbF : nbF + nbB;
   const int mode = isF ? o.mode_f : o.mode_b;
-  double scale;
-  if (mode == LRR_ICP_SCALE_RMS) {
-    double S = block_total(P1, r0, r1, 5, 0), W = block_total(P1, r0, r1, 5, 1);
-    scale = sqrt(S / W);
-  } else {
-    scale = isF ? o.inj_f : o.inj_b;
-  }
+  double tot[4] = {0.0, 0.0, 0.0, 0.0};  // S, W of this list's residuals; radius sums of both clouds
+  if (mode == LRR_ICP_SCALE_RMS)
+    for (int b = r0 + (int)threadIdx.x; b < r1; b += kBlock) { tot[0] += P1[(size_t)b * 5]; tot[1] += P1[(size_t)b * 5 + 1]; }
+  if (o.normalize)
+    for (int b = threadIdx.x; b < nb3; b += kBlock) { tot[2] += P3[(size_t)b * 2]; tot[3] += P3[(size_t)b * 2 + 1]; }
+  block_sum_all<4>(tot);
+  const double scale = mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : (isF ? o.inj_f : o.inj_b);
   __shared__ double sc_norm[8];
   if (o.normalize) {
-    double rm = block_total(P3, 0, nb3, 2, 0) / (double)F.n;
-    double rf = block_total(P3, 0, nb3, 2, 1) / SC[SC_ND];
+    double rm = tot[2] / (double)F.n;
+    double rf = tot[3] / SC[SC_ND];
     if (threadIdx.x == 0) {
       for (int k = 0; k < 3; ++k) { sc_norm[k] = SC[SC_CM + k]; sc_norm[4 + k] = SC[SC_CF + k]; }
       sc_norm[3] = rm; sc_norm[7] = rf;
@@ -1920,13 +1947,24 @@ __global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int 
     if (clone) D.w[s] = wi;  // the backward list itself keeps its Beaton-Tukey weights (cdcl sym .txx:665)
     double key = INFINITY;
     if (strength && wi != 0) {
-      double g = strength_gain(D.ps, s, D.float_product);
+      double g = D.key_g[s];  // strength_gain() of the pair, left here by F1
       wi = wi * g;
       key = g;
       acc[0] += 1.0;
     }
     D.key_g[s] = key;
-    D.key_s[s] = spatial_weight(D.ps, s, nm, clone ? 1 : 0);
+    {  // weight_spatially's 1 / (1 + 5 |q~|^2) on the normalised to-location (clones: their from-location)
+      double q0, q1, q2;
+      if (clone) {
+        load_from(D.ps, s, q0, q1, q2);
+        q0 = (q0 - nm.cm[0]) / nm.rm; q1 = (q1 - nm.cm[1]) / nm.rm; q2 = (q2 - nm.cm[2]) / nm.rm;
+      } else {
+        const double *q = D.q_loc + 3 * (size_t)s;
+        q0 = (q[0] - nm.cf[0]) / nm.rf; q1 = (q[1] - nm.cf[1]) / nm.rf; q2 = (q[2] - nm.cf[2]) / nm.rf;
+      }
+      double dq = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
+      D.key_s[s] = 1.0 / (1.0 + 5.0 * dq * dq);
+    }
     wdst[s] = wi;
   }
   block_reduce_store<1>(acc, P4);
@@ -2001,7 +2039,7 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
       if (!on[u]) continue;
       const int s = s0 + u * stride;
       load_from(D.ps, s, pl[u][0], pl[u][1], pl[u][2]);
-      const double *qr = D.ps.to_rec + (size_t)mt[u] * kRecStride;
+      const double *qr = D.q_loc + 3 * (size_t)s;  // cached by F1: the backward list needs no gather at all
       ql[u][0] = qr[0]; ql[u][1] = qr[1]; ql[u][2] = qr[2];
       const double *pr = prec + (size_t)(isF ? mt[u] : s) * kRecStride;
 #pragma unroll
@@ -2167,9 +2205,9 @@ int ensure_dir_capacity(lrr_icp_dir *d) {
   lrr_icp_ctx *ctx = d->ctx;
   int64_t need = std::max<int64_t>(d->from->n, 1);
   if (need <= d->cap) return LRR_ICP_OK;
-  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc};
+  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc};
   for (void *p : ptrs) if (p) (void)hipFree(p);
-  d->slot = d->m_to = nullptr; d->w = d->wc = d->r2 = d->key_g = d->key_s = d->from_loc = nullptr;
+  d->slot = d->m_to = nullptr; d->w = d->wc = d->r2 = d->key_g = d->key_s = d->from_loc = d->q_loc = nullptr;
   d->cap = 0;
   HIPCHK(ctx, hipMalloc(&d->slot, sizeof(int) * need));
   HIPCHK(ctx, hipMalloc(&d->m_to, sizeof(int) * need));
@@ -2179,6 +2217,7 @@ int ensure_dir_capacity(lrr_icp_dir *d) {
   HIPCHK(ctx, hipMalloc(&d->key_g, sizeof(double) * need));
   HIPCHK(ctx, hipMalloc(&d->key_s, sizeof(double) * need));
   HIPCHK(ctx, hipMalloc(&d->from_loc, sizeof(double) * 3 * need));
+  HIPCHK(ctx, hipMalloc(&d->q_loc, sizeof(double) * 3 * need));
   d->cap = need;
   return LRR_ICP_OK;
 }
@@ -2302,7 +2341,7 @@ DirArgs dir_args(lrr_icp_dir *d) {
   DirArgs a;
   a.ps = pairs_of(d);
   a.n = (int)d->n;
-  a.w = d->w; a.wc = d->wc; a.r2 = d->r2; a.key_s = d->key_s; a.key_g = d->key_g;
+  a.w = d->w; a.wc = d->wc; a.r2 = d->r2; a.key_s = d->key_s; a.key_g = d->key_g; a.q_loc = d->q_loc;
   a.flag = d->flag; a.gen = d->flag_gen;
   a.float_product = d->from->float_strength;
   return a;
@@ -2586,7 +2625,7 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
 void lrr_icp_dir_destroy(lrr_icp_dir *d) {
   if (!d) return;
   if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
-  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->flag};
+  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->flag};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete d;
 }
