@@ -230,7 +230,7 @@ def main():
                        "nn": args.nn, "schedule_iterations_before_timing": schedule_iters,
                        "parallelism": f"{world} independent problem(s), one per GPU; one all_gather of the final transforms"},
             "roofline": {"bound": "hbm",
-                         "kernel": ("K1 find_closest_euclidean = k_match_ball2 + k_match_hard2 + k_match_overflow2: every phase "
+                         "kernel": ("K1 find_closest_euclidean = k_match_ball2 + k_match_hard2: every phase "
                                     "handles the forward and the backward search in one launch (lrr_icp_match_pair); "
                                     "kernel_ms = HIP-event time of the pair / 2 = one direction"
                                     if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),

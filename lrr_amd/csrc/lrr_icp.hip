@@ -960,7 +960,7 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
       int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
       int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
       int nyb = yb - ya + 1, nitems = (zb - za + 1) * nyb;
-      if (nitems <= 64 * 64) {  // the rows of the ball; otherwise fall back to the ring search
+      {  // the rows of the ball, 64 at a time: exact whatever its size, so a query with a previous match never overflows
         for (int base = 0; base < nitems; base += 64) {
           int t = base + lane, s0 = 0, e0 = 0;
           if (t < nitems) {
@@ -1068,10 +1068,6 @@ __device__ __forceinline__ void match_overflow_body(const OverArgs &A) {
   }
 }
 __global__ __launch_bounds__(kBlock) void k_match_overflow(OverArgs A) { match_overflow_body(A); }
-__global__ __launch_bounds__(kBlock) void k_match_overflow2(OverArgs A, OverArgs B) {
-  if (blockIdx.y == 0) match_overflow_body(A);
-  else match_overflow_body(B);
-}
 
 // slot assignment + active list for the all-vs-all matcher
 __global__ void k_slots_dense(const SrcPoint *src, Keys keys, int half, int nsrc, int n_points, int *slot,
@@ -2274,10 +2270,13 @@ OverArgs over_args(const HardArgs &h) {
 }
 inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n + 3) / 4)); }
 
-int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts) {
+// all_have_prev: every handed-over query carries a previous match (ball-search state), so phase 2
+// settles all of them and phase 3 has nothing to do
+int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts, bool all_have_prev) {
   HardArgs h = hard_args(L, to, g, q, xf, m_to, counts);
   hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n)), dim3(kBlock), 0, st, h);
   HIPCHK(ctx, hipGetLastError());
+  if (all_have_prev) return LRR_ICP_OK;
   hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, st, over_args(h));
   HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
@@ -2781,7 +2780,7 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, P.counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts);
+  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady);
 }
 
 // one K1 submission on lane L and its stream
@@ -2830,9 +2829,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
       hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
       HIPCHK(ctx, hipGetLastError());
-      hipLaunchKernelGGL(k_match_overflow2, dim3(128, 2), dim3(kBlock), 0, st, over_args(hf), over_args(hb));
-      HIPCHK(ctx, hipGetLastError());
-      return LRR_ICP_OK;
+      return LRR_ICP_OK;  // no phase 3: every query of this state carries a previous match, which phase 2 settles
     }
     // (not reached: the test above mirrors match_prepare's) fall through to separate launches
     ProfScope prof(ctx, st, 2);
@@ -3266,7 +3263,7 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
     else {
       hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, L.d_hard, counts);
       if (hipGetLastError() != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: launch failed");
-      if (!rc) rc = launch_hard_phases(ctx, L, ctx->stream, cloud, g, q, x, (int)nq, dto, counts);
+      if (!rc) rc = launch_hard_phases(ctx, L, ctx->stream, cloud, g, q, x, (int)nq, dto, counts, false);
     }
   }
   std::vector<int> tmp((size_t)nq);

@@ -214,6 +214,26 @@ def test_strength_ties_and_scale_jumps(E, ob):
     g.close()
 
 
+def test_transform_jump_keeps_matches_exact(E, ob):
+    """a level's later iteration after the transform jumped by tens of cells: every previous match is a
+    poor bound, the searches fall through to the wave-per-query phase with balls of hundreds of rows
+    and must still return the exact nearest neighbours"""
+    pair = synth.make_pair(20000, 20000, 91, kind="affine")
+    T0 = synth.perturbed(pair.planted, 2)
+    g, c = _both(E, ob, E.CDCL_FORWARD, 12, pair, T0, 23, False, n_points=20000, inject=(1.0, 1.0))
+    for it in range(2):
+        _compare_iteration(g, c, it, (0,))
+    far = synth.Transform(T0.A.copy(), T0.t + np.array([37.0, -29.0, 18.0]), T0.c.copy())
+    for e in (g, c):
+        e.set_transform(far.A, far.t, far.c)
+        e.set_number_points(20000)
+        e.find_closest_euclidean()
+    fg, tg, _ = g.matches(0)
+    fc, tc, _ = c.matches(0)
+    assert np.array_equal(fg, fc) and np.array_equal(tg, tc)
+    g.close()
+
+
 def test_small_and_ragged_inputs(E, ob):
     """fewer than 1000 points, unequal sizes, a single moving point"""
     for nm, nf in ((1, 40), (37, 900), (999, 1001)):
