@@ -2369,7 +2369,7 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_partials, sizeof(double) * kMaxBlocks * kMaxRed)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_final, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs))) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs), hipHostMallocMapped)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_pinned, sizeof(double) * (kMaxRed + 4 * kMaxSelJobs), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_pinned_dev, ctx->h_pinned, 0)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_jobs, sizeof(SelJob) * kMaxSelJobs)) != hipSuccess) return bail(e);
@@ -2380,9 +2380,9 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   for (K1Lane &L : ctx->lane)
     if ((e = hipMalloc(&L.d_counts, kCountSlots * 4 * sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256, hipHostMallocMapped)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_fused_dev, ctx->h_fused, 0)) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc(&ctx->h_seq, 64, hipHostMallocMapped)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_seq, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
   *ctx->h_seq = 0;
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_seq_dev, ctx->h_seq, 0)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_done, sizeof(int))) != hipSuccess) return bail(e);
