@@ -2268,7 +2268,7 @@ OverArgs over_args(const HardArgs &h) {
   a.g = h.g; a.q = h.q; a.xf = h.xf; a.overflow = h.overflow; a.overflow_count = h.overflow_count; a.m_to = h.m_to;
   return a;
 }
-inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(4096, std::max<int64_t>(1, (n + 3) / 4)); }
+inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + 3) / 4)); }
 
 // all_have_prev: every handed-over query carries a previous match (ball-search state), so phase 2
 // settles all of them and phase 3 has nothing to do
