@@ -211,6 +211,7 @@ def main():
         n_dir = n_pairs_step // 2
         k1_bytes = n_dir * K1_BYTES_PER_PAIR_FIXED + 24.0 * n  # per launch: n_dir queries vs one n-point cloud
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        traffic = pmc_traffic(args)  # measured HBM bytes per launch (PMC), for the bandwidth actually drawn
         out = {
             "metric": "ICP matched-feature-pairs/sec",
             "value": value,
@@ -235,7 +236,9 @@ def main():
                                     "kernel_ms = HIP-event time of the pair / 2 = one direction"
                                     if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_GBs": (traffic / (k1_ms * 1e-3) / 1e9) if (traffic and k1_ms > 0) else None,
+                         "traffic_frac": (traffic / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k1_ms > 0) else None,
                          "kernel_ms": k1_ms, "launches": match_launches,
                          "algorithmic_bytes_per_launch": k1_bytes,
                          "iteration_achieved_GBs": value / world * ITER_BYTES_PER_PAIR / 1e9,
