@@ -145,6 +145,7 @@ struct lrr_icp_cloud {
   int *orig_of = nullptr;       // canonical -> original index
   int *canon_of = nullptr;      // original -> canonical index
   GridPoint *gp = nullptr;      // n, sorted by grid cell (raster z,y,x): the search structure
+  GridPoint *cpt = nullptr;     // n, canonical order: location + indices of target `canon` in one 32-B read (previous-match bound)
   int *cell_start = nullptr;    // ncell + 1
   int *fine_start = nullptr;    // ncell * fine + 1: every cell cut into `fine` slices along x (ball search)
   int fine = 1;
@@ -763,8 +764,7 @@ struct BallArgs {  // one direction of a ball search
   Keys keys;
   int half, nsrc, n_points;
   XfD xf;
-  const double *to_rec;
-  const int *to_orig_of;
+  const GridPoint *to_pt;  // target points in canonical order
   int *slot, *m_to;
   double *w;
   int *hard, *hard_count;
@@ -790,9 +790,9 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
   map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
   Best b;
   {
-    const double *q = A.to_rec + (size_t)prev * kRecStride;
-    b.d = dist2(yx, yy, yz, q[0], q[1], q[2]);
-    b.orig = A.to_orig_of[prev];
+    const GridPoint q = A.to_pt[prev];  // one 32-B gather: location and original index of the previous match
+    b.d = dist2(yx, yy, yz, q.x, q.y, q.z);
+    b.orig = q.orig;
     b.canon = prev;
   }
   const double rad = sqrt(b.d) + 2.0 * g.tol;
@@ -922,8 +922,7 @@ struct HardArgs {  // one direction of the wave-per-query phase
   XfD xf;
   const int *hard, *hard_count;
   int use_prev;
-  const double *to_rec;
-  const int *to_orig_of;
+  const GridPoint *to_pt;  // target points in canonical order
   int *m_to, *overflow, *overflow_count;
 };
 __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
@@ -934,8 +933,6 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
   const XfD &xf = A.xf;
   const int *hard = A.hard;
   const int use_prev = A.use_prev;
-  const double *to_rec = A.to_rec;
-  const int *to_orig_of = A.to_orig_of;
   int *m_to = A.m_to, *overflow = A.overflow, *overflow_count = A.overflow_count;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
   const int cnt = *A.hard_count;
@@ -952,9 +949,9 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
     bool done = false;
     int prev = use_prev ? m_to[s] : -1;
     if (prev >= 0) {
-      const double *pq = to_rec + (size_t)prev * kRecStride;
-      b.d = dist2(yx, yy, yz, pq[0], pq[1], pq[2]);
-      b.orig = to_orig_of[prev];
+      const GridPoint pq = A.to_pt[prev];
+      b.d = dist2(yx, yy, yz, pq.x, pq.y, pq.z);
+      b.orig = pq.orig;
       b.canon = prev;
       double rad = sqrt(b.d) + 2.0 * g.tol;
       int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
@@ -2259,7 +2256,7 @@ HardArgs hard_args(K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const 
   a.g = g; a.q = q; a.xf = xf;
   a.hard = L.d_hard; a.hard_count = counts;
   a.use_prev = q.src ? 1 : 0;
-  a.to_rec = to->rec; a.to_orig_of = to->orig_of;
+  a.to_pt = to->cpt;
   a.m_to = m_to; a.overflow = L.d_overflow; a.overflow_count = counts + 1;
   return a;
 }
@@ -2567,6 +2564,11 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
     int pos = cursor[(size_t)slice[(size_t)i]]++;
     gp[(size_t)pos] = GridPoint{loc[3 * i], loc[3 * i + 1], loc[3 * i + 2], canon_of[(size_t)i], (int)i};
   }
+  std::vector<GridPoint> cpt(m);
+  for (int64_t sidx = 0; sidx < n; ++sidx) {
+    const int i = orig_of[(size_t)sidx];
+    cpt[(size_t)sidx] = GridPoint{loc[3 * (int64_t)i], loc[3 * (int64_t)i + 1], loc[3 * (int64_t)i + 2], (int)sidx, i};
+  }
   c->nchunks = (int)chunks.size();
   if (chunks.empty()) chunks.push_back(Chunk{0, 0});
   auto cleanup = [&](int code, const std::string &msg) { lrr_icp_cloud_destroy(c); return fail(ctx, code, msg); };
@@ -2577,6 +2579,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
       {(void **)&c->rec, rec.data(), sizeof(double) * m * kRecStride, 0},
       {(void **)&c->src, src.data(), sizeof(SrcPoint) * m, 0},
       {(void **)&c->gp, gp.data(), sizeof(GridPoint) * m, 0},
+      {(void **)&c->cpt, cpt.data(), sizeof(GridPoint) * m, 0},
       {(void **)&c->orig_of, orig_of.data(), sizeof(int) * m, 0},
       {(void **)&c->canon_of, canon_of.data(), sizeof(int) * m, 0},
       {(void **)&c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), 0},
@@ -2750,7 +2753,7 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
 static BallArgs ball_args(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L) {
   BallArgs a;
   a.g = P.g; a.src = d->from->src; a.keys = P.kk; a.half = P.half; a.nsrc = (int)P.N; a.n_points = (int)d->n;
-  a.xf = P.x; a.to_rec = d->to->rec; a.to_orig_of = d->to->orig_of;
+  a.xf = P.x; a.to_pt = d->to->cpt;
   a.slot = d->slot; a.m_to = d->m_to; a.w = d->w; a.hard = L.d_hard; a.hard_count = P.counts;
   a.budget = kBallBudget; a.max_rad = kBallCells * P.g.h;
   return a;
