@@ -302,7 +302,43 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     return scale;
   }
   // (cdcl .txx:1009-1093; rrl .txx:783-859)
+  // The steps below in one device submission (lrr_icp_estimate_forward): statistics of the matches
+  // and trans_->normalize, estimate_scale_and_assign_weight, weight_by_strength, AtA / Atb; the host
+  // then normalises its transform object with the returned statistics, solves and un-normalises.
   void estimate_LS(bool estimate_parameters = false) {
+    lrr_icp_fwd_opts o;
+    o.dof = (int)dof;
+    o.normalize = normalize_matches_ ? 1 : 0;
+    o.strength = weight_by_strength_ ? 1 : 0;
+    o.rigid_transform = is_rigid() ? 1 : 0;
+    o.rigid_increment = (!RRL && is_rigid()) ? 1 : 0;
+    o.injected = 0.0;
+    if (scale_estimated_) o.scale_mode = LRR_ICP_SCALE_RMS;
+    else if (injected_scale_ > 0.0) { o.scale_mode = LRR_ICP_SCALE_INJECTED; o.injected = injected_scale_; }
+    else o.scale_mode = LRR_ICP_SCALE_MUSE;
+    // centre of the transform as the accumulation sees it: the affine normalize() zeroes it
+    // (cdcl_trans_affine.txx:252), the rigid one keeps it (cdcl_trans_rigid3d.cxx:260-280)
+    for (int d = 0; d < 3; ++d) o.jac_centre[d] = (normalize_matches_ && !is_rigid()) ? 0.0 : trans_->center_moving_[d];
+    lrr_icp_xform xf = xform_of(trans_);
+    lrr_icp_sym_out r;
+    check(lrr_icp_estimate_forward(dir_, &xf, &o, &r), "fused forward estimate");
+    scale_estimated_ = true;
+    last_scale_ = r.sigma_f;
+    touch();
+    vec3 cm(0.0), cf(0.0);
+    double rm = 0.0, rf = 0.0;
+    if (normalize_matches_) {
+      for (int d = 0; d < 3; ++d) { cm[d] = r.norm.cm[d]; cf[d] = r.norm.cf[d]; }
+      rm = r.norm.rm;
+      rf = r.norm.rf;
+      trans_->normalize(rm, rf, cm, cf);
+    }
+    solve_and_set(trans_, r.AtA, r.Atb, estimate_parameters);
+    if (normalize_matches_) trans_->unnormalize(rm, rf, cm, cf);
+    norm_ = identity_norm();
+  }
+  // the same estimate step by step through the granular C-ABI calls (each with its own host round trip)
+  void estimate_LS_stepwise(bool estimate_parameters = false) {
     vec3 cm(0.0), cf(0.0);
     double rm = 0.0, rf = 0.0;
     if (normalize_matches_) {

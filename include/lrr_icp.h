@@ -173,6 +173,25 @@ int  lrr_icp_estimate_symmetric(lrr_icp_dir *fwd, lrr_icp_dir *bwd, const lrr_ic
                                 const lrr_icp_xform *xf_bwd, const lrr_icp_sym_opts *opts,
                                 lrr_icp_sym_out *out);
 
+/* estimate_LS of the forward classes in one submission (cdcl/cdcl_estimation_ICP_matching_all.txx:1009-1093,
+ * rrl/rrl_estimation_ICP_matching_all.txx:783-859): cdcl_normalize_matches statistics (.txx:1159-1240) and
+ * trans_->normalize on the device, estimate_scale_and_assign_weight (.txx:660-822), weight_by_strength
+ * (.txx:826-862), AtA / Atb (.txx:1039-1069).  xf is the transform BEFORE normalisation; the host repeats
+ * normalize / unnormalize on its own transform object around the solve with the returned statistics.
+ * Same results as the granular calls above, one host round trip instead of eight. */
+typedef struct {
+  int dof;               /* 6 or 12 */
+  int normalize;         /* normalize_matches_ */
+  int strength;          /* weight_by_strength_ */
+  int rigid_transform;   /* cdcl_trans_rigid3d: normalize() keeps center_moving_ (cdcl_trans_rigid3d.cxx:260-280) */
+  int rigid_increment;   /* right-hand side q - p (cdcl .txx:1051-1057) */
+  int scale_mode;        /* LRR_ICP_SCALE_* */
+  double injected;       /* scale for LRR_ICP_SCALE_INJECTED */
+  double jac_centre[3];  /* center_moving_ of the transform as the accumulation sees it */
+} lrr_icp_fwd_opts;
+int  lrr_icp_estimate_forward(lrr_icp_dir *dir, const lrr_icp_xform *xf, const lrr_icp_fwd_opts *opts,
+                              lrr_icp_sym_out *out);
+
 /* matches_ on demand (callbacks, sheet/tube angles): from/to indices into the clouds, weights */
 int  lrr_icp_get_matches(lrr_icp_dir *dir, int64_t *from_idx, int64_t *to_idx, double *w);
 

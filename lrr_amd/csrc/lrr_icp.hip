@@ -2055,6 +2055,186 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused FORWARD estimate (cdcl / rrl estimate_LS of one list: cdcl .txx:1009-1093, rrl .txx:783-859):
+// normalisation statistics of the matches, residuals in normalised coordinates under the normalised
+// transform, scale, Beaton-Tukey weights, strength gain with its MAD scale, normal equations — one
+// host round trip.  The transform is normalised on the device from the statistics (the host does
+// the same for its own bookkeeping once they arrive).
+// ---------------------------------------------------------------------------------------------
+// FW0: sums of the from-locations, stamps of the distinct matched targets (cdcl .txx:1159-1190)
+__global__ __launch_bounds__(kBlock) void k_fw_stats(DirArgs F, double *P1) {
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // columns 2..4: the layout k_f_radii reads
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+    if (F.ps.slot[s] < 0) continue;
+    double p0, p1, p2;
+    load_from(F.ps, s, p0, p1, p2);
+    acc[2] += p0; acc[3] += p1; acc[4] += p2;
+    F.flag[F.ps.m_to[s]] = F.gen;
+  }
+  block_reduce_store<5>(acc, P1);
+}
+
+struct FwdOpts {
+  int normalize, strength, rigid;   // rigid: cdcl_trans_rigid3d keeps its centre when normalised
+  int mode;                         // LRR_ICP_SCALE_RMS or _INJECTED (MUSE arrives as injected)
+  double injected;
+};
+
+// cdcl_trans_rigid3d::normalize / cdcl_trans_affine::normalize on (A, t, c)
+// (cdcl_trans_rigid3d.cxx:260-280, cdcl_trans_affine.txx:220-253)
+__device__ __forceinline__ XfD normalized_xf(const XfD &T, const NormD &nm, int rigid) {
+  XfD N;
+  const double f = nm.rm / nm.rf;
+  for (int k = 0; k < 9; ++k) N.A[k] = f * T.A[k];
+  const double d0 = nm.cm[0] - T.c[0], d1 = nm.cm[1] - T.c[1], d2 = nm.cm[2] - T.c[2];
+  for (int r = 0; r < 3; ++r) {
+    const double Ad = (N.A[3 * r] * d0 + N.A[3 * r + 1] * d1) + N.A[3 * r + 2] * d2;
+    N.t[r] = (T.t[r] / nm.rf + Ad / nm.rm) - nm.cf[r] / nm.rf;
+    N.c[r] = rigid ? T.c[r] : 0.0;
+  }
+  return N;
+}
+
+// scalars of the forward list: (cm, rm, cf, rf) from the statistics kernels, or the identity
+__device__ __forceinline__ NormD fwd_norm(const FwdOpts &o, const DirArgs &F, const double *P3, int nb3, double *SC) {
+  __shared__ double sc_norm[8];
+  double tot[2] = {0.0, 0.0};
+  if (o.normalize)
+    for (int b = threadIdx.x; b < nb3; b += kBlock) { tot[0] += P3[(size_t)b * 2]; tot[1] += P3[(size_t)b * 2 + 1]; }
+  block_sum_all<2>(tot);
+  if (threadIdx.x == 0) {
+    if (o.normalize) {
+      for (int k = 0; k < 3; ++k) { sc_norm[k] = SC[SC_CM + k]; sc_norm[4 + k] = SC[SC_CF + k]; }
+      sc_norm[3] = tot[0] / (double)F.n; sc_norm[7] = tot[1] / SC[SC_ND];
+    } else {
+      for (int k = 0; k < 8; ++k) sc_norm[k] = (k == 3 || k == 7) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  return norm_from_scalars(sc_norm, false);
+}
+
+// FW1: residuals (cdcl .txx:660-735): also leaves the matched target's location and the pair's
+// strength gain per source, and the sums for the RMS scale under the previous weights
+__global__ __launch_bounds__(kBlock) void k_fw_residual(DirArgs F, FwdOpts o, XfD xf, const double *P3, int nb3,
+                                                        double *SC, double *P1) {
+  const NormD nm = fwd_norm(o, F, P3, nb3, SC);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!o.normalize) for (int k = 0; k < 3; ++k) { SC[SC_CM + k] = 0.0; SC[SC_CF + k] = 0.0; }
+    SC[SC_RM] = nm.rm; SC[SC_RF] = nm.rf;
+  }
+  const XfD T = o.normalize ? normalized_xf(xf, nm, o.rigid) : xf;
+  double acc[2] = {0.0, 0.0};
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+    if (F.ps.slot[s] < 0) { F.key_s[s] = INFINITY; continue; }
+    double p0, p1, p2, y0, y1, y2;
+    load_from(F.ps, s, p0, p1, p2);
+    const double *q = F.ps.to_rec + (size_t)F.ps.m_to[s] * kRecStride;
+    const double q0 = q[0], q1 = q[1], q2 = q[2];
+    map_loc(T, (p0 - nm.cm[0]) / nm.rm, (p1 - nm.cm[1]) / nm.rm, (p2 - nm.cm[2]) / nm.rm, y0, y1, y2);
+    const double r2 = proj_residual2(y0, y1, y2, (q0 - nm.cf[0]) / nm.rf, (q1 - nm.cf[1]) / nm.rf, (q2 - nm.cf[2]) / nm.rf,
+                                     q[3], q[4], q[5], q[6], q[7], q[8]);
+    F.q_loc[3 * (size_t)s] = q0; F.q_loc[3 * (size_t)s + 1] = q1; F.q_loc[3 * (size_t)s + 2] = q2;
+    {
+      const double sp = F.ps.from_rec[(size_t)s * kRecStride + 9], sq = q[9];
+      const double g = F.float_product ? (double)((float)sp * (float)sq) : sp * sq;
+      F.key_g[s] = g > 90000.0 ? 90000.0 : g;
+    }
+    const double wp = F.w[s];
+    acc[0] += wp * r2;
+    acc[1] += wp;
+    F.r2[s] = r2;
+    F.key_s[s] = sqrt(r2);  // MUSE sorts these (first estimate)
+  }
+  block_reduce_store<2>(acc, P1);
+}
+
+// FW2: scale, Beaton-Tukey weights (cdcl .txx:736-822), strength gain and its key (cdcl .txx:826-862)
+__global__ __launch_bounds__(kBlock) void k_fw_weights(DirArgs F, FwdOpts o, const double *P1, int nb1, double *SC,
+                                                       double *P4) {
+  double tot[2] = {0.0, 0.0};
+  if (o.mode == LRR_ICP_SCALE_RMS)
+    for (int b = threadIdx.x; b < nb1; b += kBlock) { tot[0] += P1[(size_t)b * 2]; tot[1] += P1[(size_t)b * 2 + 1]; }
+  block_sum_all<2>(tot);
+  const double scale = o.mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : o.injected;
+  if (blockIdx.x == 0 && threadIdx.x == 0) SC[SC_SIGF] = scale;
+  const double scale2 = scale * scale;
+  double acc[1] = {0.0};
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+    if (F.ps.slot[s] < 0) { F.key_g[s] = INFINITY; continue; }
+    double u = F.r2[s] / scale2, bt = 0.0;
+    if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
+    double wi = bt / scale2;
+    double key = INFINITY;
+    if (o.strength && wi != 0) {
+      const double g = F.key_g[s];
+      wi = wi * g;
+      key = g;
+      acc[0] += 1.0;
+    }
+    F.key_g[s] = key;
+    F.w[s] = wi;
+  }
+  block_reduce_store<1>(acc, P4);
+}
+
+// FW3: final weights and the normal equations (cdcl .txx:1039-1069)
+template <int DOF>
+__global__ __launch_bounds__(kBlock) void k_fw_accumulate(DirArgs F, FwdOpts o, const double *SC, const double *SEL,
+                                                          double c0, double c1, double c2, int rigid_increment,
+                                                          double *P6) {
+  constexpr int NT = Tri<DOF>::N;
+  constexpr int U = kAccBatch;
+  const NormD nm = norm_from_scalars(SC, false);
+  const double fg = o.strength ? mad_factor(SEL) : 1.0;
+  double acc[NT + DOF];
+#pragma unroll
+  for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
+  const int stride = gridDim.x * kBlock;
+  for (int s0 = blockIdx.x * kBlock + threadIdx.x; s0 < F.ps.nsrc; s0 += U * stride) {
+    int mt[U];
+    double wi[U];
+    bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * stride;
+      const bool in = s < F.ps.nsrc;
+      on[u] = in && F.ps.slot[s] >= 0;
+      wi[u] = in ? F.w[s] : 0.0;
+      mt[u] = in ? F.ps.m_to[s] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      if (o.strength) { wi[u] = wi[u] * fg; F.w[s0 + u * stride] = wi[u]; }
+    }
+    double pl[U][3], ql[U][3], Pq[U][6];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      const int s = s0 + u * stride;
+      load_from(F.ps, s, pl[u][0], pl[u][1], pl[u][2]);
+      const double *qc = F.q_loc + 3 * (size_t)s;
+      ql[u][0] = qc[0]; ql[u][1] = qc[1]; ql[u][2] = qc[2];
+      const double *pr = F.ps.to_rec + (size_t)mt[u] * kRecStride;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      double p0 = (pl[u][0] - nm.cm[0]) / nm.rm, p1 = (pl[u][1] - nm.cm[1]) / nm.rm, p2 = (pl[u][2] - nm.cm[2]) / nm.rm;
+      double q0 = (ql[u][0] - nm.cf[0]) / nm.rf, q1 = (ql[u][1] - nm.cf[1]) / nm.rf, q2 = (ql[u][2] - nm.cf[2]) / nm.rf;
+      double P[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) P[k] = Pq[u][k];
+      accumulate_pair<DOF, false>(acc, wi[u], p0, p1, p2, q0, q1, q2, P, c0, c1, c2, rigid_increment);
+    }
+  }
+  block_reduce_store<NT + DOF>(acc, P6);
+}
+
+// ---------------------------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------------------------
 inline int grid_for(int64_t n) {
@@ -3203,6 +3383,69 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   auto mad = [&](int slot) { const double *sl = h + SEL_OFF + 4 * slot; return sl[3] > 1.0 ? 1.4826 * (1 + 5.0 / (sl[3] - 1.0)) * sl[0] : 0.0; };
   if (o->rrl) { out->grad_scale[0] = mad(0); out->grad_scale[1] = mad(1); out->spatial_scale[0] = mad(2); out->spatial_scale[1] = mad(3); }
   else { out->grad_scale[0] = out->grad_scale[1] = mad(0); out->spatial_scale[0] = out->spatial_scale[1] = mad(1); }
+  int t = 0;
+  for (int a = 0; a < o->dof; ++a)
+    for (int b = a; b < o->dof; ++b) { out->AtA[a * o->dof + b] = h[FIN_OFF + t]; out->AtA[b * o->dof + a] = h[FIN_OFF + t]; ++t; }
+  for (int a = 0; a < o->dof; ++a) out->Atb[a] = h[FIN_OFF + nt2 + a];
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_icp_fwd_opts *o, lrr_icp_sym_out *out) {
+  if (!F || !xf || !o || !out || (o->dof != 6 && o->dof != 12)) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = F->ctx;
+  if (F->n <= 0) return fail(ctx, LRR_ICP_ERR_STATE, "estimate_forward: the direction needs matches");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  double *P1 = ctx->d_fused + kFusedP1, *P2 = ctx->d_fused + kFusedP2, *P3 = ctx->d_fused + kFusedP3;
+  double *P4 = ctx->d_fused + kFusedP4, *P6 = ctx->d_fused + kFusedP6, *OUT = ctx->d_fused + kFusedOut;
+  double *SC = OUT, *SEL = OUT + SEL_OFF, *FIN = OUT + FIN_OFF;
+  DirArgs aF = dir_args(F);
+  const int nsF = aF.ps.nsrc, nbF = grid_for(nsF), nt = (int)F->to->n, nbT = grid_for(nt), nb3 = std::max(nbF, nbT);
+  if (o->normalize) {
+    int rc = next_flag_gen(F, &aF.gen);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fw_stats, dim3(nbF), dim3(kBlock), 0, st, aF, P1);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kBlock), 0, st, F->to->rec, F->flag, aF.gen, nt, P2);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kBlock), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  FwdOpts fo;
+  fo.normalize = o->normalize; fo.strength = o->strength; fo.rigid = o->rigid_transform;
+  fo.mode = o->scale_mode; fo.injected = o->injected;
+  hipLaunchKernelGGL(k_fw_residual, dim3(nbF), dim3(kBlock), 0, st, aF, fo, to_dev(xf), P3, nb3, SC, P1);
+  HIPCHK(ctx, hipGetLastError());
+  // MUSE needs the sorted residuals: its tables and argmin stay on the host (first estimate only)
+  if (fo.mode == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &fo.injected); if (rc) return rc; fo.mode = LRR_ICP_SCALE_INJECTED; }
+  hipLaunchKernelGGL(k_fw_weights, dim3(nbF), dim3(kBlock), 0, st, aF, fo, P1, nbF, SC, P4);
+  HIPCHK(ctx, hipGetLastError());
+  if (o->strength) {
+    SelJob j = make_job(F->key_g, nsF, nullptr, 0, -1, 0);
+    j.out = SEL;
+    j.cnt = P4; j.cnt_a0 = 0; j.cnt_a1 = nbF; j.cnt_b0 = 0; j.cnt_b1 = 0;
+    j.state = 8;
+    ctx->h_jobs[0] = j;
+    int rc = launch_select_kth(ctx, 1);
+    if (rc) return rc;
+  }
+  const int nbA = std::min(nbF, kAccBlocks);
+  const double *c = o->jac_centre;
+  const int nt2 = o->dof * (o->dof + 1) / 2, K = nt2 + o->dof;
+  if (o->dof == 12) hipLaunchKernelGGL((k_fw_accumulate<12>), dim3(nbA), dim3(kBlock), 0, st, aF, fo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  else hipLaunchKernelGGL((k_fw_accumulate<6>), dim3(nbA), dim3(kBlock), 0, st, aF, fo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  HIPCHK(ctx, hipGetLastError());
+  const unsigned long long seq = ++ctx->seq;
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbA, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq);
+  HIPCHK(ctx, hipGetLastError());
+  { int rc = wait_results(ctx, seq); if (rc) return rc; }
+  const double *h = ctx->h_fused;
+  for (int k = 0; k < 3; ++k) { out->norm.cm[k] = h[SC_CM + k]; out->norm.cf[k] = h[SC_CF + k]; }
+  out->norm.rm = h[SC_RM]; out->norm.rf = h[SC_RF];
+  out->sigma_f = h[SC_SIGF]; out->sigma_b = 0.0;
+  const double *sl = h + SEL_OFF;
+  out->grad_scale[0] = out->grad_scale[1] = (o->strength && sl[3] > 1.0) ? 1.4826 * (1 + 5.0 / (sl[3] - 1.0)) * sl[0] : 0.0;
+  out->spatial_scale[0] = out->spatial_scale[1] = 0.0;
   int t = 0;
   for (int a = 0; a < o->dof; ++a)
     for (int b = a; b < o->dof; ++b) { out->AtA[a * o->dof + b] = h[FIN_OFF + t]; out->AtA[b * o->dof + a] = h[FIN_OFF + t]; ++t; }

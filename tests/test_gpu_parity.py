@@ -133,6 +133,25 @@ def test_forward_run_matches_oracle_config1(E, ob, kind_name, dof):
     g.close()
 
 
+@pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("RRL_FORWARD", 12)])
+def test_forward_normalised_strength_weighted(E, ob, kind_name, dof):
+    """estimate_LS of the forward classes with normalize_matches and weight_by_strength on: the fused
+    forward estimate normalises the transform on the device (rigid: centre kept, affine: centre
+    zeroed) and must follow the oracle's step-by-step path iteration by iteration.  Clouds centred on
+    the origin: the rigid class with normalisation drifts otherwise (reproduced defect)."""
+    import dataclasses
+    pair = synth.make_pair(9000, 8000, 57, kind="rigid" if dof == 6 else "affine")
+    shift = 150.0
+    pair = dataclasses.replace(pair, moving=dataclasses.replace(pair.moving, loc=pair.moving.loc - shift),
+                               fixed=dataclasses.replace(pair.fixed, loc=pair.fixed.loc - shift),
+                               planted=synth.Transform(pair.planted.A, pair.planted.t - shift, pair.planted.c - shift))
+    T0 = synth.perturbed(pair.planted, 8, rot_deg=0.2, trans_mm=0.3)
+    g, c = _both(E, ob, getattr(E, kind_name), dof, pair, T0, 29, False, n_points=8000, normalize=True, strength=True)
+    for it in range(6):
+        _compare_iteration(g, c, it, (0,))
+    g.close()
+
+
 def test_forward_50k_single_estimate_config2(E, ob):
     """config 2: 50k x 50k, single ICP estimate at n = all points, MUSE scale included"""
     pair = synth.make_pair(50000, 50000, 20242, kind="rigid")
