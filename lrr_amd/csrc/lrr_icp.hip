@@ -1,13 +1,17 @@
 // lrr_icp.hip — hand-written HIP kernels (gfx950 / CDNA4) + the C-ABI of include/lrr_icp.h.
 //
 // The per-iteration hot path of LRR's robust ICP:
-//   K1  map moving features + exact nearest fixed feature      (k_match_tile / k_match_direct /
-//                                                               k_match_hard / k_match_overflow /
-//                                                               k_match_brute)
-//   K2  projected residuals, robust scale, Beaton-Tukey weights (k_f_residual, k_sel_*, k_f_weights)
-//   K5  normalisation statistics                                (k_to_sum, k_f_radii)
-//   K3  weighted normal equations J^T P J, J^T P b              (k_f_accumulate)
+//   K1  map moving features + exact nearest fixed feature      (k_match_ball[2] on the later iterations
+//                                                               of a level, k_match_tile on the first,
+//                                                               k_match_direct on coarse levels; then
+//                                                               k_match_hard[2], k_match_overflow;
+//                                                               k_match_brute: literal all-vs-all)
+//   K2  projected residuals, robust scale, Beaton-Tukey weights (k_f_residual, k_f_weights, k_selw_*;
+//                                                               forward classes: k_fw_residual, k_fw_weights)
+//   K5  normalisation statistics                                (k_to_sum, k_f_radii, k_fw_stats)
+//   K3  weighted normal equations J^T P J, J^T P b              (k_f_accumulate, k_fw_accumulate)
 //   K4  error metrics                                           (k_errors)
+// plus the step-by-step twins behind the granular C-ABI calls (k_residual, k_strength, ...).
 // Everything is fp64: the reference is double throughout (cdcl/cdcl_feature.h:21) and "match
 // sets exactly" is a parity requirement.  This is distance search + small reductions: no MFMA.
 // The file is compiled with -ffp-contract=off so that per-pair quantities are bit-identical to
