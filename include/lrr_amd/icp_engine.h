@@ -211,6 +211,13 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     int64_t count = lrr_icp_dir_num_matches(dir_);
     return count != 0 ? std::sqrt(s2 / double(count)) : s2;
   }
+  // (cdcl .txx:159-190; rrl .txx:177-203)
+  double median_error() {
+    lrr_icp_xform xf = xform_of(trans_);
+    double med = 0.0;
+    check(lrr_icp_median_error(dir_, &xf, &med), "median error");
+    return med;
+  }
   // (cdcl .txx:236-268)
   double weighted_error() {
     double s2 = 0, swr = 0, sw = 0;

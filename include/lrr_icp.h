@@ -143,6 +143,11 @@ int  lrr_icp_accumulate(lrr_icp_dir *dir, int dof, const double jac_centre[3],
 int  lrr_icp_errors(lrr_icp_dir *dir, const lrr_icp_xform *xf, double *sum_r2, double *sum_wr,
                     double *sum_w);
 
+/* median_error (cdcl .txx:159-190; rrl .txx:177-203): element (n-1)/2 + 1 of the sorted sqrt(r2_i)
+ * (vcl_nth_element at begin + (n-1)/2 + 1); 0 for fewer than two matches, where the reference reads
+ * past the end of its list */
+int  lrr_icp_median_error(lrr_icp_dir *dir, const lrr_icp_xform *xf, double *median);
+
 /* ---- fused symmetric estimate ----------------------------------------------------------------
  * The device part of {cdcl,rrl}_estimation_symmetric_ICP_matching_all::estimate_LS
  * (rrl sym .txx:699-878; cdcl sym .txx:458-628) as ONE asynchronous submission with a single

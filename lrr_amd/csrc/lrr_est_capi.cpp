@@ -120,6 +120,7 @@ struct est_base {
   virtual void estimate_LS_backward(bool) = 0;
   virtual void get_transform(int dir, double *A, double *t, double *c, double *covar) = 0;
   virtual double RMS_error() = 0;
+  virtual double median_error() = 0;
   virtual double weighted_error(int dir) = 0;
   virtual double sheet_angles(int dir) = 0;
   virtual double tube_angles(int dir) = 0;
@@ -174,6 +175,7 @@ struct fwd_impl : est_base {
   void estimate_LS_backward(bool) override {}
   void get_transform(int, double *A, double *t, double *c, double *covar) override { read_trans<DOF>(e->get_transform(), A, t, c, covar); }
   double RMS_error() override { return e->RMS_error(); }
+  double median_error() override { return e->median_error(); }
   double weighted_error(int) override { return e->weighted_error(); }
   double sheet_angles(int) override { return e->sheet_angles(); }
   double tube_angles(int) override { return e->tube_angles(); }
@@ -231,6 +233,7 @@ struct sym_impl : est_base {
     read_trans<DOF>(dir ? e->get_transform_backward() : e->get_transform(), A, t, c, covar);
   }
   double RMS_error() override { return e->RMS_error(); }
+  double median_error() override { return e->forward().median_error(); }  // (the symmetric classes have none: their forward list's)
   double weighted_error(int dir) override { return dir ? e->weighted_error_backward() : e->weighted_error(); }
   double sheet_angles(int dir) override { return dir ? e->sheet_angles_backward() : e->sheet_angles(); }
   double tube_angles(int dir) override { return dir ? e->tube_angles_backward() : e->tube_angles(); }
@@ -331,6 +334,7 @@ int lrr_est_estimate_LS(lrr_est *e, int p) { return guard([&] { E(e)->estimate_L
 int lrr_est_estimate_LS_backward(lrr_est *e, int p) { return guard([&] { E(e)->estimate_LS_backward(p != 0); }); }
 int lrr_est_get_transform(lrr_est *e, int dir, double *A, double *t, double *c, double *covar) { return guard([&] { E(e)->get_transform(dir, A, t, c, covar); }); }
 int lrr_est_RMS_error(lrr_est *e, double *out) { return guard([&] { *out = E(e)->RMS_error(); }); }
+int lrr_est_median_error(lrr_est *e, double *out) { return guard([&] { *out = E(e)->median_error(); }); }
 int lrr_est_weighted_error(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->weighted_error(dir); }); }
 int lrr_est_sheet_angles(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->sheet_angles(dir); }); }
 int lrr_est_tube_angles(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->tube_angles(dir); }); }

@@ -3394,6 +3394,33 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   return LRR_ICP_OK;
 }
 
+int lrr_icp_median_error(lrr_icp_dir *d, const lrr_icp_xform *xf, double *median) {
+  if (!d || !xf || !median) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  *median = 0.0;
+  const int64_t n = d->n;
+  if (n < 2) return LRR_ICP_OK;  // the reference reads past the end of its list here
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairSrc ps = pairs_of(d);
+  // a diagnostic outside the iteration: its residuals go to scratch of their own, not to the arrays
+  // an estimate in progress may still need
+  double *tmp = nullptr;
+  HIPCHK(ctx, hipMalloc(&tmp, sizeof(double) * 2 * (size_t)ps.nsrc));
+  int nb = grid_for(ps.nsrc);
+  hipLaunchKernelGGL(k_residual, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, tmp, tmp + ps.nsrc, ctx->d_partials);
+  int rc = hipGetLastError() == hipSuccess ? LRR_ICP_OK : fail(ctx, LRR_ICP_ERR_HIP, "median_error: launch failed");
+  double res[4] = {0, 0, 0, 0};
+  if (!rc) {
+    // inactive sources carry +inf and sort last: rank (n-1)/2 + 1 among the n active ones is that rank overall
+    std::vector<SelJob> jobs(1, make_job(tmp + ps.nsrc, ps.nsrc, nullptr, 0, (n - 1) / 2 + 1, n));
+    rc = run_select(ctx, jobs, res);
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(tmp);
+  if (!rc) *median = res[0];
+  return rc;
+}
+
 int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_icp_fwd_opts *o, lrr_icp_sym_out *out) {
   if (!F || !xf || !o || !out || (o->dof != 6 && o->dof != 12)) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = F->ctx;

@@ -31,7 +31,7 @@ ICP_SYMBOLS = [
     "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
     "lrr_icp_residual_pass", "lrr_icp_muse_scale", "lrr_icp_assign_weights",
     "lrr_icp_normalize_stats", "lrr_icp_clone_weights", "lrr_icp_weight_by_strength",
-    "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_get_matches",
+    "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_median_error", "lrr_icp_get_matches",
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
     "lrr_icp_nearest",
 ]
@@ -115,6 +115,7 @@ def est_lib() -> C.CDLL:
         L.lrr_est_estimate_LS_backward.argtypes = [C.c_void_p, C.c_int]
         L.lrr_est_get_transform.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
         L.lrr_est_RMS_error.argtypes = [C.c_void_p, _dp]
+        L.lrr_est_median_error.argtypes = [C.c_void_p, _dp]
         for name in ("weighted_error", "sheet_angles", "tube_angles", "last_scale"):
             getattr(L, "lrr_est_" + name).argtypes = [C.c_void_p, C.c_int, _dp]
         L.lrr_est_compute_transfer_error_covariance.argtypes = [C.c_void_p, _dp, _dp]
@@ -326,6 +327,9 @@ class Estimator:
 
     def RMS_error(self):
         return self._scalar(est_lib().lrr_est_RMS_error)
+
+    def median_error(self):
+        return self._scalar(est_lib().lrr_est_median_error)
 
     def weighted_error(self, direction=0):
         return self._scalar(est_lib().lrr_est_weighted_error, direction)

@@ -59,7 +59,7 @@ def lib() -> C.CDLL:
         L.lrr_oracle_estimate_LS.argtypes = [C.c_void_p, C.c_int]
         L.lrr_oracle_estimate_LS_backward.argtypes = [C.c_void_p, C.c_int]
         L.lrr_oracle_get_transform.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
-        for name in ("RMS_error",):
+        for name in ("RMS_error", "median_error"):
             getattr(L, "lrr_oracle_" + name).argtypes = [C.c_void_p]
             getattr(L, "lrr_oracle_" + name).restype = C.c_double
         for name in ("weighted_error", "sheet_angles", "tube_angles", "last_scale"):
@@ -228,6 +228,9 @@ class OracleEstimator:
 
     def RMS_error(self):
         return lib().lrr_oracle_RMS_error(self._h)
+
+    def median_error(self):
+        return lib().lrr_oracle_median_error(self._h)
 
     def weighted_error(self, direction=0):
         return lib().lrr_oracle_weighted_error(self._h, direction)

@@ -841,6 +841,20 @@ static double fwd_RMS_error(const fwd_est *f) {
   return error;
 }
 
+/* median_error (cdcl .txx:159-190; rrl .txx:177-203): element (n-1)/2 + 1 of the sorted sqrt
+ * residuals (vcl_nth_element at begin + (n-1)/2 + 1).  With fewer than two matches the reference
+ * dereferences end(): 0 is returned here. */
+static double fwd_median_error(const fwd_est *f) {
+  int64_t n = f->nmatch;
+  if (n < 2) return 0.0;
+  double *errors = (double *)malloc(sizeof(double) * (size_t)n);
+  for (int64_t i = 0; i < n; ++i) errors[i] = sqrt(fwd_residual2(f, i));
+  qsort(errors, (size_t)n, sizeof(double), cmp_double);
+  double med = errors[(n - 1) / 2 + 1];
+  free(errors);
+  return med;
+}
+
 /* weighted_error (cdcl .txx:236-268; rrl .txx:247-276) */
 static double fwd_weighted_error(const fwd_est *f) {
   double error = 0.0, sum_weight = 0.0;
@@ -1519,6 +1533,7 @@ void lrr_oracle_get_transform(lrr_oracle_est *e, int dir, double *A, double *t, 
 }
 
 double lrr_oracle_RMS_error(lrr_oracle_est *e) { return fwd_RMS_error(e->fwd); }
+double lrr_oracle_median_error(lrr_oracle_est *e) { return fwd_median_error(e->fwd); }
 double lrr_oracle_weighted_error(lrr_oracle_est *e, int dir) {
   fwd_est *f = dir ? e->bwd : e->fwd;
   return f ? fwd_weighted_error(f) : NAN;

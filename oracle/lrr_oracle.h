@@ -76,6 +76,7 @@ void lrr_oracle_estimate_LS_backward(lrr_oracle_est *e, int estimate_parameters)
 /* dir: 0 forward, 1 backward */
 void   lrr_oracle_get_transform(lrr_oracle_est *e, int dir, double *A, double *t, double *c, double *covar /*dof*dof*/);
 double lrr_oracle_RMS_error(lrr_oracle_est *e);
+double lrr_oracle_median_error(lrr_oracle_est *e);
 double lrr_oracle_weighted_error(lrr_oracle_est *e, int dir);
 double lrr_oracle_sheet_angles(lrr_oracle_est *e, int dir);
 double lrr_oracle_tube_angles(lrr_oracle_est *e, int dir);

@@ -149,6 +149,8 @@ def test_forward_normalised_strength_weighted(E, ob, kind_name, dof):
     g, c = _both(E, ob, getattr(E, kind_name), dof, pair, T0, 29, False, n_points=8000, normalize=True, strength=True)
     for it in range(6):
         _compare_iteration(g, c, it, (0,))
+    assert abs(g.median_error() - c.median_error()) <= 1e-9 * max(1.0, c.median_error())
+    assert abs(g.RMS_error() - c.RMS_error()) <= 1e-9 * max(1.0, c.RMS_error())
     g.close()
 
 

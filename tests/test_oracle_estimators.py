@@ -268,3 +268,19 @@ def test_diagnostics_smoke(oracle_lib):
     _, _, _, covb = e.get_transform(1)
     assert np.all(np.isfinite(covb)) and np.abs(covb).max() > 0
     assert not e.oscillated()
+
+
+def test_median_error_against_numpy(oracle_lib):
+    """median_error (cdcl .txx:159-190): element (n-1)/2 + 1 of the sorted sqrt residuals"""
+    pair = synth.make_pair(2500, 2400, 31, kind="affine")
+    T0 = synth.perturbed(pair.planted, 4)
+    for kind in (ob.CDCL_FORWARD, ob.RRL_FORWARD):
+        e = ob.OracleEstimator(kind, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=3)
+        e.inject_initial_scale(1.0, 1.0)
+        e.set_transform(T0.A, T0.t, T0.c)
+        e.find_closest_euclidean()
+        f, t, _ = e.matches(0)
+        A, tt, c, _ = e.get_transform(0)
+        r = np.sqrt(ref.residual2(A, tt, c, pair.moving.loc[f], pair.fixed.loc[t], pair.fixed.proj[t]))
+        want = np.sort(r)[(r.size - 1) // 2 + 1]
+        assert abs(e.median_error() - want) <= 1e-12 * max(1.0, want)
