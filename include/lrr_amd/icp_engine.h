@@ -760,6 +760,9 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     backward_ = b;
   }
 
+  // stubs in the reference too ("to be implemented": cdcl sym .h:90-93, rrl sym .h:104-107)
+  virtual bool estimate_parameters() { return false; }
+  virtual bool estimate_covariance() { return false; }
   trans_sptr_type get_transform() { return forward_->get_transform(); }
   trans_sptr_type get_transform_backward() { return backward_->get_transform(); }
   void weight_by_strength(bool flag) { forward_->weight_by_strength(flag); backward_->weight_by_strength(flag); }

@@ -90,6 +90,7 @@ class vnl_matrix_fixed {
   }
   vnl_vector_fixed<T, R> get_column(unsigned c) const { vnl_vector_fixed<T, R> v; for (unsigned r = 0; r < R; ++r) v[r] = d_[r][c]; return v; }
   vnl_matrix_fixed &operator*=(T s) { for (unsigned r = 0; r < R; ++r) for (unsigned c = 0; c < C; ++c) d_[r][c] *= s; return *this; }
+  vnl_matrix_fixed &operator/=(T s) { for (unsigned r = 0; r < R; ++r) for (unsigned c = 0; c < C; ++c) d_[r][c] /= s; return *this; }
   vnl_matrix_fixed &operator+=(const vnl_matrix_fixed &o) { for (unsigned r = 0; r < R; ++r) for (unsigned c = 0; c < C; ++c) d_[r][c] += o.d_[r][c]; return *this; }
   vnl_matrix_fixed operator*(T s) const { vnl_matrix_fixed m(*this); m *= s; return m; }
   vnl_vector_fixed<T, R> operator*(const vnl_vector_fixed<T, C> &v) const {

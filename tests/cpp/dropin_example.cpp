@@ -7,7 +7,19 @@
 #include <cstdlib>
 #include <vector>
 
+#include "lrr_amd/cdcl_estimation_ICP_matching_all.h"
+#include "lrr_amd/cdcl_estimation_symmetric_ICP_matching_all.h"
+#include "lrr_amd/rrl_estimation_ICP_matching_all.h"
 #include "lrr_amd/rrl_estimation_symmetric_ICP_matching_all.h"
+
+// every member of every drop-in class compiles (the instantiations the reference ships:
+// cdcl/cdcl_estimation_ICP_matching_all+3+6-.cxx etc.)
+template class cdcl_estimation_ICP_matching_all<3, 6>;
+template class cdcl_estimation_ICP_matching_all<3, 12>;
+template class rrl_estimation_ICP_matching_all<3, 12>;
+template class cdcl_estimation_symmetric_ICP_matching_all<3, 6>;
+template class cdcl_estimation_symmetric_ICP_matching_all<3, 12>;
+template class rrl_estimation_symmetric_ICP_matching_all<3, 12>;
 
 typedef cdcl_feature_ICP<3> feature_type;
 typedef feature_type::sptr feature_sptr_type;
