@@ -18,5 +18,7 @@ class rrl_estimation_ICP_matching_all : public lrr_amd::icp_direction<dof, cdcl_
   rrl_estimation_ICP_matching_all(vcl_vector<feature_sptr_type> const &moving, vcl_vector<feature_sptr_type> const &fixed,
      trans_sptr_type const &trans)
       : engine_type(moving, fixed, trans) {}
+  // the exact device search needs no precomputed Voronoi volume (rrl/rrl_estimation_ICP_matching_all.h:101)
+  template <class VoronoiPointer> void set_fixed_voronoi_map(VoronoiPointer const &) {}
 };
 #endif
