@@ -759,6 +759,7 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
 // previous point, slice bounds, candidates) with every query of the launch resident at once.
 // Lanes without a previous match, with a ball wider than kBallCells cells or more than `budget`
 // candidates go to the wave-per-query kernel.
+constexpr int kBallBlock = 64;      // one wavefront per block: the scheduler packs and refills SIMDs wave by wave
 constexpr int kBallRows = 9;        // (z,y) rows whose cell bounds a lane fetches in one round trip
 constexpr int kBallBudget = 64;     // candidates a lane may scan before handing its query over
 constexpr double kBallCells = 2.0;  // widest ball (in cells) the thread-per-query search takes
@@ -780,7 +781,7 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
   const SrcPoint *src = A.src;
   const int nsrc = A.nsrc;
   int budget = A.budget;
-  const int s = blockIdx.x * kBlock + threadIdx.x;
+  const int s = blockIdx.x * kBallBlock + threadIdx.x;
   if (s >= nsrc) return;
   const SrcPoint sp = src[s];
   const int prev = A.m_to[s];
@@ -868,9 +869,9 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
   A.m_to[s] = b.canon;
 }
 
-__global__ __launch_bounds__(kBlock) void k_match_ball(BallArgs A) { match_ball_body(A); }
+__global__ __launch_bounds__(kBallBlock) void k_match_ball(BallArgs A) { match_ball_body(A); }
 // both directions of a symmetric estimator in one launch: blockIdx.y picks the direction
-__global__ __launch_bounds__(kBlock) void k_match_ball2(BallArgs A, BallArgs B) {
+__global__ __launch_bounds__(kBallBlock) void k_match_ball2(BallArgs A, BallArgs B) {
   if (blockIdx.y == 0) match_ball_body(A);
   else match_ball_body(B);
 }
@@ -2959,7 +2960,7 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     return launch_brute(ctx, L, st, d->to, P.g, P.q, L.d_active, P.x, (int)n_points, d->m_to);
   }
   if (P.steady) {
-    hipLaunchKernelGGL(k_match_ball, dim3(blocks_for(N)), dim3(kBlock), 0, st, ball_args(d, P, L));
+    hipLaunchKernelGGL(k_match_ball, dim3((unsigned)((N + kBallBlock - 1) / kBallBlock)), dim3(kBallBlock), 0, st, ball_args(d, P, L));
   } else if (P.dense) {
     hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, P.g, d->from->src, d->from->chunks, P.kk, P.half, (int)N, (int)n_points, P.x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, L.d_hard, P.counts, kTileBudget);
   } else {
@@ -3010,7 +3011,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     if (Pf.steady && Pb.steady) {
       ProfScope prof(ctx, st, 2);
       BallArgs af = ball_args(f, Pf, ctx->lane[0]), ab = ball_args(b, Pb, ctx->lane[1]);
-      hipLaunchKernelGGL(k_match_ball2, dim3(std::max(blocks_for(Pf.N), blocks_for(Pb.N)), 2), dim3(kBlock), 0, st, af, ab);
+      hipLaunchKernelGGL(k_match_ball2, dim3((unsigned)((std::max(Pf.N, Pb.N) + kBallBlock - 1) / kBallBlock), 2), dim3(kBallBlock), 0, st, af, ab);
       HIPCHK(ctx, hipGetLastError());
       HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);
       HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
