@@ -762,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
 constexpr int kBallBlock = 64;      // one wavefront per block: the scheduler packs and refills SIMDs wave by wave
 constexpr int kBallRows = 9;        // (z,y) rows whose cell bounds a lane fetches in one round trip
 constexpr int kBallBudget = 64;     // candidates a lane may scan before handing its query over
-constexpr double kBallCells = 2.0;  // widest ball (in cells) the thread-per-query search takes
+constexpr double kBallCells = 2.5;  // widest ball (in cells) the thread-per-query search takes
 struct BallArgs {  // one direction of a ball search
   GridView g;
   const SrcPoint *src;
