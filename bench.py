@@ -36,8 +36,8 @@ ITER_BYTES_PER_PAIR = 180.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=N_FEATURES, help="features per volume (default: BASELINE size)")
     ap.add_argument("--nn", choices=["grid", "brute"], default="grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -2501,8 +2501,7 @@ struct ProfScope {  // HIP events around K1 submissions (all phases), recorded o
     if (on) (void)hipEventRecord(ctx->pe[ctx->pe_used], st);
   }
   ~ProfScope() {
-    if (on) { (void)hipEventRecord(ctx->pe[ctx->pe_used + 1], st); ctx->pe_used += 2; }
-    ctx->match_launches += launches;
+    if (on) { (void)hipEventRecord(ctx->pe[ctx->pe_used + 1], st); ctx->pe_used += 2; ctx->match_launches += launches; }  // timed submissions only: the mean stays a mean when the event pool runs out
   }
 };
 
