@@ -307,6 +307,28 @@ def test_full_size_properties_200k(E):
     e.close()
 
 
+def test_full_size_200k_schedule_against_oracle(E, ob):
+    """BASELINE configuration itself (200k x 200k noisy clouds with outliers, rrl symmetric, dof 12)
+    against the CPU oracle: the whole coarse-to-fine schedule and six finest-level iterations, every
+    iteration's match sets bit-exact and transforms / scales / weights within the bars of the small
+    cases.  About 10 s of oracle time."""
+    n = 200000
+    pair = synth.make_pair(n, n, 20243, kind="affine")
+    T0 = synth.perturbed(pair.planted, 3)
+    g, c = _both(E, ob, E.RRL_SYMMETRIC, 12, pair, T0, 7, True)
+    at_finest = 0
+    for it in range(60):
+        _compare_iteration(g, c, it, (0, 1))
+        assert g.finest_level() == c.finest_level()
+        if g.finest_level():
+            at_finest += 1
+            if at_finest >= 6:
+                break
+    assert at_finest >= 6 and g.number_points(0) == n and c.number_points(0) == n
+    assert abs(g.weighted_error(0) - c.weighted_error(0)) <= 1e-9 * max(1.0, c.weighted_error(0))
+    g.close()
+
+
 def test_locations_driver_against_oracle(E, ob):
     """config 5 driver (lrr_amd/locations.py): every location's final transform and iteration
     count equal the oracle's run of the same location"""
