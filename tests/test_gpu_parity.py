@@ -307,15 +307,16 @@ def test_full_size_properties_200k(E):
     e.close()
 
 
-def test_full_size_200k_schedule_against_oracle(E, ob):
-    """BASELINE configuration itself (200k x 200k noisy clouds with outliers, rrl symmetric, dof 12)
+@pytest.mark.parametrize("kind_name", ["RRL_SYMMETRIC", "CDCL_SYMMETRIC"])
+def test_full_size_200k_schedule_against_oracle(E, ob, kind_name):
+    """BASELINE configuration itself (200k x 200k noisy clouds with outliers, symmetric, dof 12)
     against the CPU oracle: the whole coarse-to-fine schedule and six finest-level iterations, every
     iteration's match sets bit-exact and transforms / scales / weights within the bars of the small
     cases.  About 10 s of oracle time."""
     n = 200000
     pair = synth.make_pair(n, n, 20243, kind="affine")
     T0 = synth.perturbed(pair.planted, 3)
-    g, c = _both(E, ob, E.RRL_SYMMETRIC, 12, pair, T0, 7, True)
+    g, c = _both(E, ob, getattr(E, kind_name), 12, pair, T0, 7, True)
     at_finest = 0
     for it in range(60):
         _compare_iteration(g, c, it, (0, 1))
