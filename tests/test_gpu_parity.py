@@ -73,6 +73,27 @@ def test_asymmetric_projector_rejected(E):
         E.DeviceCloud(pair.fixed)
 
 
+def test_bad_input_fails_loudly(E):
+    """errors surface as exceptions with the device library's message, never as silent wrong results"""
+    pair = synth.make_pair(300, 300, 5, kind="affine")
+    T0 = pair.planted
+    bad = pair.fixed.loc.copy()
+    bad[7, 1] = np.nan
+    import dataclasses
+    with pytest.raises(RuntimeError, match="non-finite"):
+        E.DeviceCloud(dataclasses.replace(pair.fixed, loc=bad))
+    e = E.Estimator(E.CDCL_FORWARD, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=1)
+    A = T0.A.copy()
+    A[0, 0] = np.inf
+    e.set_transform(A, T0.t, T0.c)
+    with pytest.raises(RuntimeError, match="non-finite transform"):
+        e.find_closest_euclidean()
+    e.set_transform(T0.A, T0.t, T0.c)
+    e.find_closest_euclidean()  # the estimator is still usable afterwards
+    assert e.matches(0)[0].shape[0] == 300
+    e.close()
+
+
 # ---- golden fixtures ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 @pytest.mark.parametrize("method", ["grid", "brute"])
