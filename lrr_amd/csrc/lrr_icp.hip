@@ -149,6 +149,7 @@ struct lrr_icp_cloud {
   int *orig_of = nullptr;       // canonical -> original index
   int *canon_of = nullptr;      // original -> canonical index
   GridPoint *gp = nullptr;      // n, sorted by grid cell (raster z,y,x): the search structure
+  double *str = nullptr;        // n, canonical order: strength_ alone (the passes that need nothing else of the from-record)
   GridPoint *cpt = nullptr;     // n, canonical order: location + indices of target `canon` in one 32-B read (previous-match bound)
   int *cell_start = nullptr;    // ncell + 1
   int *fine_start = nullptr;    // ncell * fine + 1: every cell cut into `fine` slices along x (ball search)
@@ -1158,6 +1159,8 @@ __global__ void k_brute_merge(const double *pd, const int *po, const int *pc, in
 // source feature that is not in the active subset.
 // ---------------------------------------------------------------------------------------------
 struct PairSrc {
+  const SrcPoint *from_src;        // compact from-locations and ...
+  const double *from_str;          // ... from-strengths: 40 B per source instead of the 80-B record
   const double *from_rec, *to_rec;
   const int *slot, *m_to;
   const double *from_loc;  // pre-mapped copies or nullptr
@@ -1168,8 +1171,8 @@ __device__ __forceinline__ void load_from(const PairSrc &ps, int s, double &p0, 
   if (ps.from_loc) {
     p0 = ps.from_loc[3 * (size_t)s]; p1 = ps.from_loc[3 * (size_t)s + 1]; p2 = ps.from_loc[3 * (size_t)s + 2];
   } else {
-    const double *r = ps.from_rec + (size_t)s * kRecStride;
-    p0 = r[0]; p1 = r[1]; p2 = r[2];
+    const SrcPoint r = ps.from_src[s];
+    p0 = r.x; p1 = r.y; p2 = r.z;
   }
 }
 
@@ -1288,7 +1291,7 @@ __global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, const double *to_r
 }
 
 __device__ __forceinline__ double strength_gain(const PairSrc &ps, int s, int float_product) {
-  double sp = ps.from_rec[(size_t)s * kRecStride + 9];
+  double sp = ps.from_str[s];
   double sq = ps.to_rec[(size_t)ps.m_to[s] * kRecStride + 9];
   double g = float_product ? (double)((float)sp * (float)sq) : sp * sq;
   return g > 90000.0 ? 90000.0 : g;
@@ -1817,30 +1820,33 @@ __global__ __launch_bounds__(kBlock) void k_f_residual(DirArgs F, DirArgs B, int
   const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
-    if (D.ps.slot[s] < 0) { D.key_s[s] = INFINITY; continue; }
-    // the one gather of the matched target's record in this estimate: location and strength gain
-    // are kept per source for the weight and normal-equation passes
+    // every load whose address does not depend on another is issued before the first test: two
+    // dependent memory levels per source (streams, then the gather) instead of three
+    const int sl = D.ps.slot[s], mt = D.ps.m_to[s];
     double p0, p1, p2, y0, y1, y2;
     load_from(D.ps, s, p0, p1, p2);
-    const double *q = D.ps.to_rec + (size_t)D.ps.m_to[s] * kRecStride;
+    const double sp = D.ps.from_str[s], wp = D.w[s];
+    if (sl < 0) { D.key_s[s] = INFINITY; continue; }
+    // the one gather of the matched target's record in this estimate: location and strength gain
+    // are kept per source for the weight and normal-equation passes
+    const double *q = D.ps.to_rec + (size_t)mt * kRecStride;
     const double q0 = q[0], q1 = q[1], q2 = q[2];
     map_loc(xf, (p0 - ident.cm[0]) / ident.rm, (p1 - ident.cm[1]) / ident.rm, (p2 - ident.cm[2]) / ident.rm, y0, y1, y2);
     double r2 = proj_residual2(y0, y1, y2, (q0 - ident.cf[0]) / ident.rf, (q1 - ident.cf[1]) / ident.rf, (q2 - ident.cf[2]) / ident.rf,
                                q[3], q[4], q[5], q[6], q[7], q[8]);
     D.q_loc[3 * (size_t)s] = q0; D.q_loc[3 * (size_t)s + 1] = q1; D.q_loc[3 * (size_t)s + 2] = q2;
     {
-      const double sp = D.ps.from_rec[(size_t)s * kRecStride + 9], sq = q[9];
+      const double sq = q[9];
       const double g = D.float_product ? (double)((float)sp * (float)sq) : sp * sq;
       D.key_g[s] = g > 90000.0 ? 90000.0 : g;  // strength_gain(); F4 turns it into the selection key
     }
-    double wp = D.w[s];
     acc[0] += wp * r2;
     acc[1] += wp;
     D.r2[s] = r2;
     D.key_s[s] = sqrt(r2);
     if (isF && want_stats) {
       acc[2] += p0; acc[3] += p1; acc[4] += p2;
-      D.flag[D.ps.m_to[s]] = D.gen;
+      D.flag[mt] = D.gen;
     }
   }
   block_reduce_store<5>(acc, P1);
@@ -2141,7 +2147,7 @@ __global__ __launch_bounds__(kBlock) void k_fw_residual(DirArgs F, FwdOpts o, Xf
                                      q[3], q[4], q[5], q[6], q[7], q[8]);
     F.q_loc[3 * (size_t)s] = q0; F.q_loc[3 * (size_t)s + 1] = q1; F.q_loc[3 * (size_t)s + 2] = q2;
     {
-      const double sp = F.ps.from_rec[(size_t)s * kRecStride + 9], sq = q[9];
+      const double sp = F.ps.from_str[s], sq = q[9];
       const double g = F.float_product ? (double)((float)sp * (float)sq) : sp * sq;
       F.key_g[s] = g > 90000.0 ? 90000.0 : g;
     }
@@ -2286,7 +2292,7 @@ GridView view_of(const lrr_icp_cloud *c) {
 
 PairSrc pairs_of(const lrr_icp_dir *d) {
   PairSrc ps;
-  ps.from_rec = d->from->rec; ps.to_rec = d->to->rec;
+  ps.from_src = d->from->src; ps.from_str = d->from->str; ps.from_rec = d->from->rec; ps.to_rec = d->to->rec;
   ps.slot = d->slot; ps.m_to = d->m_to;
   ps.from_loc = d->from_is_copy ? d->from_loc : nullptr;
   ps.nsrc = (int)d->from->n;
@@ -2749,6 +2755,8 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
     gp[(size_t)pos] = GridPoint{loc[3 * i], loc[3 * i + 1], loc[3 * i + 2], canon_of[(size_t)i], (int)i};
   }
   std::vector<GridPoint> cpt(m);
+  std::vector<double> strv(m, 0.0);
+  for (int64_t sidx = 0; sidx < n; ++sidx) strv[(size_t)sidx] = rec[(size_t)sidx * kRecStride + 9];
   for (int64_t sidx = 0; sidx < n; ++sidx) {
     const int i = orig_of[(size_t)sidx];
     cpt[(size_t)sidx] = GridPoint{loc[3 * (int64_t)i], loc[3 * (int64_t)i + 1], loc[3 * (int64_t)i + 2], (int)sidx, i};
@@ -2764,6 +2772,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
       {(void **)&c->src, src.data(), sizeof(SrcPoint) * m, 0},
       {(void **)&c->gp, gp.data(), sizeof(GridPoint) * m, 0},
       {(void **)&c->cpt, cpt.data(), sizeof(GridPoint) * m, 0},
+      {(void **)&c->str, strv.data(), sizeof(double) * m, 0},
       {(void **)&c->orig_of, orig_of.data(), sizeof(int) * m, 0},
       {(void **)&c->canon_of, canon_of.data(), sizeof(int) * m, 0},
       {(void **)&c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), 0},
