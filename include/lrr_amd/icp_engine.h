@@ -117,6 +117,17 @@ class device_cloud {
     }
     check(lrr_icp_cloud_create(device::ctx(), (int64_t)n, loc.data(), proj.data(), st.data(),
                                feature_traits<FeatureT>::float_strength ? 1 : 0, &h_), "cloud upload");
+    // shape_ and directions_ for the post-convergence diagnostics (sheet_angles / tube_angles)
+    std::vector<uint8_t> shape(n + 1, 0), ndirs(n + 1, 0);
+    std::vector<double> dirs(6 * n + 6, 0.0);
+    for (size_t i = 0; i < n; ++i) {
+      shape[i] = (uint8_t)f[i]->shape_;
+      const size_t nd = f[i]->directions_.size();
+      ndirs[i] = (uint8_t)(nd > 3 ? 3 : nd);
+      for (size_t k = 0; k < nd && k < 2; ++k)
+        for (int d = 0; d < 3; ++d) dirs[6 * i + 3 * k + d] = f[i]->directions_[k][d];
+    }
+    check(lrr_icp_cloud_set_shapes(h_, shape.data(), ndirs.data(), dirs.data()), "shape upload");
   }
   lrr_icp_cloud *handle() const { return h_; }
 
@@ -226,15 +237,12 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
   }
   // (cdcl .txx:388-404)
   void compute_transfer_error_covariance() {
-    const vcl_vector<match_sptr_type> &m = this->matches();
-    vnl_matrix_fixed<double, 3, 3> covarJ(0.0);
     vnl_matrix_fixed<double, dof, dof> covar = trans_->get_covariance();
-    vnl_matrix_fixed<double, 3, dof> J;
-    for (size_t i = 0; i < m.size(); ++i) {
-      trans_->jacobian_wrt_par_thread(m[i]->from_->location_, J);
-      covarJ += J * covar * J.transpose();
-    }
-    covarJ *= (1.0 / double(m.size()));
+    double c[3] = {trans_->center_moving_[0], trans_->center_moving_[1], trans_->center_moving_[2]}, sum[9];
+    check(lrr_icp_transfer_covariance(dir_, (int)dof, c, covar.data_block(), sum), "transfer error covariance");
+    vnl_matrix_fixed<double, 3, 3> covarJ(0.0);
+    for (int r = 0; r < 3; ++r) for (int e = 0; e < 3; ++e) covarJ(r, e) = sum[3 * r + e];
+    covarJ *= (1.0 / double(lrr_icp_dir_num_matches(dir_)));
     trans_->set_covarianceJ(covarJ);
   }
   double sheet_angles() { return angles(false); }
@@ -532,36 +540,10 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
   }
   // sheet_angles / tube_angles.  cdcl_feature_ICP: mapped directions_ (rrl .txx:281-375).
   double angles(bool tube) {
-    const vcl_vector<match_sptr_type> &m = this->matches();
-    const double pi = 3.14159265358979323846;
-    double avg = 0.0, sum_weight = 0.0;
-    for (size_t i = 0; i < m.size(); ++i) {
-      feature_type *p = m[i]->from_.as_pointer(), *q = m[i]->to_[0].as_pointer();
-      if (tube ? (p->shape_ != feature_type::TUBE || q->shape_ != feature_type::TUBE)
-               : (p->shape_ != feature_type::SHEET || q->shape_ != feature_type::SHEET)) continue;
-      vec3 dp, dq;
-      if (tube) {
-        if (p->directions_.size() < 2 || q->directions_.size() < 2) continue;
-        dp = cross(p->directions_[0], p->directions_[1]);
-        dq = cross(q->directions_[0], q->directions_[1]);
-      } else {
-        if (p->directions_.empty() || q->directions_.empty()) continue;
-        dp = p->directions_[0];
-        dq = q->directions_[0];
-      }
-      vec3 y = trans_->map_loc(p->location_), y2 = trans_->map_loc(p->location_ + dp);
-      vec3 d = y2 - y;
-      d /= d.magnitude();
-      double a = std::acos(dot_product(d, dq));
-      if (a > pi / 2) a = pi - a;
-      double w = m[i]->w_[0];
-      avg += w * a;
-      sum_weight += w;
-    }
-    return avg / sum_weight;
-  }
-  static vec3 cross(vec3 const &a, vec3 const &b) {
-    return vec3(a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]);
+    lrr_icp_xform xf = xform_of(trans_);
+    double sum_wa = 0.0, sum_w = 0.0;
+    check(lrr_icp_angles(dir_, &xf, tube ? 1 : 0, &sum_wa, &sum_w), "angle diagnostics");
+    return sum_wa / sum_w;
   }
 
   vcl_vector<vcl_vector<feature_sptr_type> > moving_, fixed_;

@@ -143,6 +143,18 @@ int  lrr_icp_accumulate(lrr_icp_dir *dir, int dof, const double jac_centre[3],
 int  lrr_icp_errors(lrr_icp_dir *dir, const lrr_icp_xform *xf, double *sum_r2, double *sum_wr,
                     double *sum_w);
 
+/* ---- post-convergence diagnostics (the verifier's inputs, rrl/itkLocationRegistration.cxx:1816-1871) --
+ * shapes and directions of a cloud's features: shape[i] in {0 CORNER, 1 TUBE, 2 SHEET}
+ * (cdcl/cdcl_feature_with_shape.h:28), ndirs[i] = directions_.size(), dirs6 = directions_[0], directions_[1] */
+int  lrr_icp_cloud_set_shapes(lrr_icp_cloud *cloud, const uint8_t *shape, const uint8_t *ndirs, const double *dirs6);
+/* sheet_angles (tube = 0) / tube_angles (tube = 1) (rrl/rrl_estimation_ICP_matching_all.txx:281-375;
+ * cdcl .txx:273-382): sum of w_i * angle_i and sum of w_i over the sheet-sheet / tube-tube matches */
+int  lrr_icp_angles(lrr_icp_dir *dir, const lrr_icp_xform *xf, int tube, double *sum_wa, double *sum_w);
+/* compute_transfer_error_covariance (cdcl .txx:388-404): sum_i J(p_i) C J(p_i)^T, 3x3 row-major, C = the
+ * dof x dof parameter covariance, J the Jacobian with respect to the parameters at the from-location */
+int  lrr_icp_transfer_covariance(lrr_icp_dir *dir, int dof, const double jac_centre[3], const double *covar,
+                                 double out9[9]);
+
 /* median_error (cdcl .txx:159-190; rrl .txx:177-203): element (n-1)/2 + 1 of the sorted sqrt(r2_i)
  * (vcl_nth_element at begin + (n-1)/2 + 1); 0 for fewer than two matches, where the reference reads
  * past the end of its list */

@@ -78,6 +78,9 @@ constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * kMaxBlocks * 5, kFusedP3 =
 struct GridPoint { double x, y, z; int canon, orig; };
 // one source feature in canonical order
 struct SrcPoint { double x, y, z; long long orig; };
+// shape_ and the directions the angle diagnostics compare: sheets directions_[0] (the normal), tubes
+// directions_[0] x directions_[1] (the tangent)
+struct ShapeRec { double sd[3], td[3]; int shape, ndirs; };
 struct Chunk { int start, count; };  // <= kBlock consecutive canonical features of ONE tile
 struct SelState { int bin, count; long long k, k_in_bin, m; };  // window bin holding rank k of one job
 
@@ -149,6 +152,7 @@ struct lrr_icp_cloud {
   int *orig_of = nullptr;       // canonical -> original index
   int *canon_of = nullptr;      // original -> canonical index
   GridPoint *gp = nullptr;      // n, sorted by grid cell (raster z,y,x): the search structure
+  ShapeRec *shp = nullptr;      // n, canonical order, own allocation: shapes and directions (post-convergence diagnostics); optional
   double *str = nullptr;        // n, canonical order: strength_ alone (the passes that need nothing else of the from-record)
   GridPoint *cpt = nullptr;     // n, canonical order: location + indices of target `canon` in one 32-B read (previous-match bound)
   int *cell_start = nullptr;    // ncell + 1
@@ -2066,6 +2070,93 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// post-convergence diagnostics of the verifier, on the matches where they live
+// ---------------------------------------------------------------------------------------------
+// sheet_angles / tube_angles (rrl .txx:281-375; cdcl .txx:273-382): weighted mean angle between
+// the mapped direction of p and the direction of q over the sheet-sheet (tube-tube) matches;
+// partial sums of w*a and w
+__global__ __launch_bounds__(kBlock) void k_angles(PairSrc ps, const ShapeRec *fshape, const ShapeRec *tshape, XfD xf,
+                                                   const double *w, int tube, double *partials) {
+  const double pi = 3.14159265358979323846;
+  const int want = tube ? 1 : 2, need = tube ? 2 : 1;
+  double acc[2] = {0.0, 0.0};
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+    if (ps.slot[s] < 0) continue;
+    const ShapeRec P = fshape[s], Q = tshape[ps.m_to[s]];
+    if (P.shape != want || Q.shape != want || P.ndirs < need || Q.ndirs < need) continue;
+    const double *dp = tube ? P.td : P.sd, *dq = tube ? Q.td : Q.sd;
+    double p0, p1, p2, y0, y1, y2, z0, z1, z2;
+    load_from(ps, s, p0, p1, p2);
+    map_loc(xf, p0, p1, p2, y0, y1, y2);
+    map_loc(xf, p0 + dp[0], p1 + dp[1], p2 + dp[2], z0, z1, z2);
+    double d0 = z0 - y0, d1 = z1 - y1, d2 = z2 - y2;
+    const double nrm = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+    d0 /= nrm; d1 /= nrm; d2 /= nrm;
+    double a = acos((d0 * dq[0] + d1 * dq[1]) + d2 * dq[2]);
+    if (a > pi / 2) a = pi - a;
+    const double wi = w[s];
+    acc[0] += wi * a;
+    acc[1] += wi;
+  }
+  block_reduce_store<2>(acc, partials);
+}
+
+// compute_transfer_error_covariance (cdcl .txx:388-404): sum over the matches of J(p) C J(p)^T, J the
+// Jacobian of the transform with respect to its parameters at the from-location (dense products in
+// the order of the fixed-size matrix classes)
+struct CovarArg { double c[144]; };
+template <int DOF>
+__global__ __launch_bounds__(kBlock) void k_transfer_cov(PairSrc ps, CovarArg C, double c0, double c1, double c2,
+                                                         double *partials) {
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+    if (ps.slot[s] < 0) continue;
+    double p0, p1, p2;
+    load_from(ps, s, p0, p1, p2);
+    const double l0 = p0 - c0, l1 = p1 - c1, l2 = p2 - c2;
+    double J[3][DOF];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < DOF; ++k) J[r][k] = 0.0;
+    if (DOF == 12) {  // cdcl_trans_affine.txx:141-161
+      const double l[3] = {l0, l1, l2};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) J[r][3 * r + k] = l[k];
+        J[r][9 + r] = 1.0;
+      }
+    } else {  // cdcl_trans_rigid3d.cxx:197-225: [-[l]x , I]
+      J[0][1] = l2; J[0][2] = -l1; J[1][0] = -l2; J[1][2] = l0; J[2][0] = l1; J[2][1] = -l0;
+      J[0][3] = 1.0; J[1][4] = 1.0; J[2][5] = 1.0;
+    }
+    double M[3][DOF];  // J C
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < DOF; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < DOF; ++k) v += J[r][k] * C.c[k * DOF + j];
+        M[r][j] = v;
+      }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < DOF; ++j) v += M[r][j] * J[e][j];
+        acc[3 * r + e] += v;
+      }
+  }
+  block_reduce_store<9>(acc, partials);
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused FORWARD estimate (cdcl / rrl estimate_LS of one list: cdcl .txx:1009-1093, rrl .txx:783-859):
 // normalisation statistics of the matches, residuals in normalised coordinates under the normalised
 // transform, scale, Beaton-Tukey weights, strength gain with its MAD scale, normal equations — one
@@ -2794,6 +2885,7 @@ void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
   if (c->slab) (void)hipFree(c->slab);
+  if (c->shp) (void)hipFree(c->shp);
   delete c;
 }
 
@@ -3401,6 +3493,66 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
     for (int b = a; b < o->dof; ++b) { out->AtA[a * o->dof + b] = h[FIN_OFF + t]; out->AtA[b * o->dof + a] = h[FIN_OFF + t]; ++t; }
   for (int a = 0; a < o->dof; ++a) out->Atb[a] = h[FIN_OFF + nt2 + a];
   return LRR_ICP_OK;
+}
+
+int lrr_icp_cloud_set_shapes(lrr_icp_cloud *c, const uint8_t *shape, const uint8_t *ndirs, const double *dirs6) {
+  if (!c || (c->n > 0 && (!shape || !ndirs || !dirs6))) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int64_t n = c->n;
+  std::vector<int> orig_of((size_t)std::max<int64_t>(n, 1));
+  if (n > 0) HIPCHK(ctx, hipMemcpy(orig_of.data(), c->orig_of, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+  std::vector<ShapeRec> recs((size_t)std::max<int64_t>(n, 1));
+  for (int64_t sidx = 0; sidx < n; ++sidx) {
+    const int i = orig_of[(size_t)sidx];
+    const double *a = dirs6 + 6 * (int64_t)i, *b = a + 3;
+    ShapeRec r;
+    r.shape = shape[i]; r.ndirs = ndirs[i];
+    for (int k = 0; k < 3; ++k) r.sd[k] = r.ndirs >= 1 ? a[k] : 0.0;
+    // vnl_cross_3d(directions_[0], directions_[1])
+    r.td[0] = r.ndirs >= 2 ? a[1] * b[2] - a[2] * b[1] : 0.0;
+    r.td[1] = r.ndirs >= 2 ? a[2] * b[0] - a[0] * b[2] : 0.0;
+    r.td[2] = r.ndirs >= 2 ? a[0] * b[1] - a[1] * b[0] : 0.0;
+    recs[(size_t)sidx] = r;
+  }
+  if (!c->shp) HIPCHK(ctx, hipMalloc(&c->shp, sizeof(ShapeRec) * recs.size()));
+  HIPCHK(ctx, hipMemcpy(c->shp, recs.data(), sizeof(ShapeRec) * recs.size(), hipMemcpyHostToDevice));
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_angles(lrr_icp_dir *d, const lrr_icp_xform *xf, int tube, double *sum_wa, double *sum_w) {
+  if (!d || !xf || !sum_wa || !sum_w) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  *sum_wa = 0.0; *sum_w = 0.0;
+  if (!d->from->shp || !d->to->shp) return fail(ctx, LRR_ICP_ERR_STATE, "angles: shapes and directions were not uploaded (lrr_icp_cloud_set_shapes)");
+  if (d->n == 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairSrc ps = pairs_of(d);
+  int nb = grid_for(ps.nsrc);
+  hipLaunchKernelGGL(k_angles, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, d->from->shp, d->to->shp, to_dev(xf), d->w, tube ? 1 : 0, ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  double r[2];
+  int rc = finish_reduce(ctx, nb, 2, r);
+  if (rc) return rc;
+  *sum_wa = r[0]; *sum_w = r[1];
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_transfer_covariance(lrr_icp_dir *d, int dof, const double jac_centre[3], const double *covar, double out9[9]) {
+  if (!d || !jac_centre || !covar || !out9 || (dof != 6 && dof != 12)) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  for (int k = 0; k < 9; ++k) out9[k] = 0.0;
+  if (d->n == 0) return LRR_ICP_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairSrc ps = pairs_of(d);
+  int nb = grid_for(ps.nsrc);
+  CovarArg C;
+  std::memset(&C, 0, sizeof C);
+  std::memcpy(C.c, covar, sizeof(double) * (size_t)dof * dof);
+  if (dof == 12) hipLaunchKernelGGL((k_transfer_cov<12>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, C, jac_centre[0], jac_centre[1], jac_centre[2], ctx->d_partials);
+  else hipLaunchKernelGGL((k_transfer_cov<6>), dim3(nb), dim3(kBlock), 0, ctx->stream, ps, C, jac_centre[0], jac_centre[1], jac_centre[2], ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  return finish_reduce(ctx, nb, 9, out9);
 }
 
 int lrr_icp_median_error(lrr_icp_dir *d, const lrr_icp_xform *xf, double *median) {

@@ -200,10 +200,11 @@ def test_symmetric_full_schedule_matches_oracle(E, ob, kind_name, dof):
     assert g.number_points(0) == c.number_points(0) and g.number_points(1) == c.number_points(1)
     assert abs(g.weighted_error(1) - c.weighted_error(1)) < 1e-8 * max(1.0, c.weighted_error(1))
     if kind_name == "RRL_SYMMETRIC":
-        assert abs(g.sheet_angles(0) - c.sheet_angles(0)) < 1e-9 and abs(g.tube_angles(0) - c.tube_angles(0)) < 1e-9
+        for d in (0, 1):  # the verifier's angle diagnostics, computed on the device
+            assert abs(g.sheet_angles(d) - c.sheet_angles(d)) < 1e-9 and abs(g.tube_angles(d) - c.tube_angles(d)) < 1e-9
         cg, cb = g.compute_transfer_error_covariance()
         oc, obk = c.compute_transfer_error_covariance()
-        assert rel(cg, oc) < 1e-5 and rel(cb, obk) < 1e-5
+        assert rel(cg, oc) < 1e-6 and rel(cb, obk) < 1e-6
         g.estimate_LS_backward(False)
         c.estimate_LS_backward(False)
         assert rel(g.get_transform(1)[3], c.get_transform(1)[3]) < 1e-5
