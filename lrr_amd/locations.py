@@ -21,7 +21,7 @@ def location_seed(seed: int, index: int) -> int:
     return (int(seed) * 1000003 + int(index) * 7919 + 1) & 0xFFFFFFFFFFFFFFFF
 
 
-def _run_block(pair, rois, inits, indices, seed, est=None):
+def _run_block(pair, rois, inits, indices, seed, est=None, diagnostics=True):
     """One estimator object re-used over `indices` (a host thread = one device context).  `est`: an
     estimator that already holds the two volumes (uploaded by an earlier block); returns it for the
     next one."""
@@ -42,18 +42,29 @@ def _run_block(pair, rois, inits, indices, seed, est=None):
         converged, it, p = est.run_counted(MAX_ITERATIONS)  # the caller's loop, in C++ (no GIL held)
         pairs += p
         A, t, c, _ = est.get_transform()
-        rows.append(multi_gpu.pack_result(i, converged, it, A, t, c, est.weighted_error(), est.RMS_error()))
+        row = multi_gpu.pack_result(i, converged, it, A, t, c, est.weighted_error(), est.RMS_error())
+        if diagnostics:
+            # what the caller asks of the estimator after convergence for its verifier
+            # (rrl/itkLocationRegistration.cxx:1828-1845): angles and errors of both directions, the
+            # backward estimate on the final matches (which re-centres the forward transform: the
+            # result row above is taken before it, like the caller's own copy of the transform)
+            est.sheet_angles(0); est.tube_angles(0)
+            est.estimate_LS_backward(False)
+            est.sheet_angles(1); est.tube_angles(1)
+            est.weighted_error(1)
+        rows.append(row)
     return rows, pairs, est
 
 
 def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1,
                        seed: int = 7, gather_device=None, workers: int = 1, device_index=None,
-                       estimators=None):
+                       estimators=None, diagnostics=True):
     """rois: list of (centre_fixed, centre_moving, moving_idx, fixed_idx) (synth.query_rois);
     inits: list of synth.Transform, the initial transform of every location.
     workers > 1: the rank's block is dealt round-robin to that many host threads, each with its own
     device context and estimator.  Every location is estimated by exactly one estimator started from
     its own initial transform: results do not depend on `workers`.
+    diagnostics: also run the post-convergence calls the reference's caller makes per location.
     estimators: a list (one slot per worker, None = not built yet) that keeps the estimator objects —
     and with them the two uploaded volumes — alive between calls; without it they are built and
     closed inside the call.
@@ -65,14 +76,14 @@ def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world
     while len(estimators) < max(1, workers):
         estimators.append(None)
     if workers <= 1 or len(mine) <= 1:
-        rows, pairs, estimators[0] = _run_block(pair, rois, inits, mine, seed, estimators[0])
+        rows, pairs, estimators[0] = _run_block(pair, rois, inits, mine, seed, estimators[0], diagnostics)
     else:
         from concurrent.futures import ThreadPoolExecutor
 
         def work(k):
             if device_index is not None:
                 E.set_device(device_index)  # contexts are per host thread
-            return _run_block(pair, rois, inits, mine[k::workers], seed, estimators[k])
+            return _run_block(pair, rois, inits, mine[k::workers], seed, estimators[k], diagnostics)
 
         with ThreadPoolExecutor(max_workers=workers) as pool:
             parts = list(pool.map(work, range(workers)))
