@@ -152,7 +152,10 @@ struct lrr_icp_cloud {
   int *orig_of = nullptr;       // canonical -> original index
   int *canon_of = nullptr;      // original -> canonical index
   GridPoint *gp = nullptr;      // n, sorted by grid cell (raster z,y,x): the search structure
-  ShapeRec *shp = nullptr;      // n, canonical order, own allocation: shapes and directions (post-convergence diagnostics); optional
+  ShapeRec *shp = nullptr;      // n, canonical order: shapes and directions (post-convergence diagnostics); space reserved in the slab,
+                                // filled by lrr_icp_cloud_set_shapes
+  bool has_shapes = false;
+  std::vector<int> h_orig_of;   // host copy of orig_of for later per-feature uploads
   double *str = nullptr;        // n, canonical order: strength_ alone (the passes that need nothing else of the from-record)
   GridPoint *cpt = nullptr;     // n, canonical order: location + indices of target `canon` in one 32-B read (previous-match bound)
   int *cell_start = nullptr;    // ncell + 1
@@ -2864,6 +2867,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
       {(void **)&c->gp, gp.data(), sizeof(GridPoint) * m, 0},
       {(void **)&c->cpt, cpt.data(), sizeof(GridPoint) * m, 0},
       {(void **)&c->str, strv.data(), sizeof(double) * m, 0},
+      {(void **)&c->shp, nullptr, sizeof(ShapeRec) * m, 0},
       {(void **)&c->orig_of, orig_of.data(), sizeof(int) * m, 0},
       {(void **)&c->canon_of, canon_of.data(), sizeof(int) * m, 0},
       {(void **)&c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), 0},
@@ -2873,10 +2877,11 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
   size_t total = 0;
   for (Part &pt : parts) { pt.off = total; total += (pt.bytes + 255) & ~(size_t)255; }
   std::vector<unsigned char> image(total, 0);
-  for (const Part &pt : parts) std::memcpy(image.data() + pt.off, pt.src, pt.bytes);
+  for (const Part &pt : parts) if (pt.src) std::memcpy(image.data() + pt.off, pt.src, pt.bytes);
   if (hipMalloc(&c->slab, total) != hipSuccess) return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
   if (hipMemcpy(c->slab, image.data(), total, hipMemcpyHostToDevice) != hipSuccess) return cleanup(LRR_ICP_ERR_HIP, "cloud_create: upload failed");
   for (const Part &pt : parts) *pt.dst = (unsigned char *)c->slab + pt.off;
+  c->h_orig_of.assign(orig_of.begin(), orig_of.end());
   *out = c;
   return LRR_ICP_OK;
 }
@@ -2885,7 +2890,6 @@ void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
   if (c->slab) (void)hipFree(c->slab);
-  if (c->shp) (void)hipFree(c->shp);
   delete c;
 }
 
@@ -3500,11 +3504,9 @@ int lrr_icp_cloud_set_shapes(lrr_icp_cloud *c, const uint8_t *shape, const uint8
   lrr_icp_ctx *ctx = c->ctx;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int64_t n = c->n;
-  std::vector<int> orig_of((size_t)std::max<int64_t>(n, 1));
-  if (n > 0) HIPCHK(ctx, hipMemcpy(orig_of.data(), c->orig_of, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
   std::vector<ShapeRec> recs((size_t)std::max<int64_t>(n, 1));
   for (int64_t sidx = 0; sidx < n; ++sidx) {
-    const int i = orig_of[(size_t)sidx];
+    const int i = c->h_orig_of[(size_t)sidx];
     const double *a = dirs6 + 6 * (int64_t)i, *b = a + 3;
     ShapeRec r;
     r.shape = shape[i]; r.ndirs = ndirs[i];
@@ -3515,8 +3517,8 @@ int lrr_icp_cloud_set_shapes(lrr_icp_cloud *c, const uint8_t *shape, const uint8
     r.td[2] = r.ndirs >= 2 ? a[0] * b[1] - a[1] * b[0] : 0.0;
     recs[(size_t)sidx] = r;
   }
-  if (!c->shp) HIPCHK(ctx, hipMalloc(&c->shp, sizeof(ShapeRec) * recs.size()));
   HIPCHK(ctx, hipMemcpy(c->shp, recs.data(), sizeof(ShapeRec) * recs.size(), hipMemcpyHostToDevice));
+  c->has_shapes = true;
   return LRR_ICP_OK;
 }
 
@@ -3524,7 +3526,7 @@ int lrr_icp_angles(lrr_icp_dir *d, const lrr_icp_xform *xf, int tube, double *su
   if (!d || !xf || !sum_wa || !sum_w) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = d->ctx;
   *sum_wa = 0.0; *sum_w = 0.0;
-  if (!d->from->shp || !d->to->shp) return fail(ctx, LRR_ICP_ERR_STATE, "angles: shapes and directions were not uploaded (lrr_icp_cloud_set_shapes)");
+  if (!d->from->has_shapes || !d->to->has_shapes) return fail(ctx, LRR_ICP_ERR_STATE, "angles: shapes and directions were not uploaded (lrr_icp_cloud_set_shapes)");
   if (d->n == 0) return LRR_ICP_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   PairSrc ps = pairs_of(d);
