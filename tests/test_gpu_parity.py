@@ -66,6 +66,41 @@ def test_nearest_degenerate_clouds(E, ob):
         cloud.close()
 
 
+def test_nearest_random_structures_with_ties(E):
+    """randomised small clouds on an integer lattice (many exactly equal distances and duplicate
+    points) and clustered clouds with far-away queries: grid and all-vs-all search both return the
+    LOWEST index among the nearest, as a linear scan in index order does"""
+    from hypothesis import given, settings, strategies as st
+
+    def ident_features(loc):
+        n = loc.shape[0]
+        return synth.FeatureSet(loc, np.tile(np.eye(3).ravel(), (n, 1)), np.ones(n), np.zeros(n, np.uint8), np.zeros((n, 6)))
+
+    @settings(max_examples=40, deadline=None, database=None, derandomize=True)
+    @given(st.integers(1, 400), st.integers(1, 300), st.integers(1, 6), st.integers(0, 2**31 - 1), st.booleans())
+    def run(n, nq, span, seed, clustered):
+        rng = np.random.default_rng(seed)
+        if clustered:
+            centres = rng.uniform(-50, 50, size=(3, 3))
+            loc = centres[rng.integers(0, 3, n)] + rng.normal(scale=0.3, size=(n, 3))
+            q = rng.uniform(-200, 200, size=(nq, 3))
+        else:
+            loc = rng.integers(0, span + 1, size=(n, 3)).astype(np.float64)  # lattice: ties and duplicates
+            q = rng.integers(-1, span + 2, size=(nq, 3)).astype(np.float64) + rng.choice([0.0, 0.5], size=(nq, 3))
+        d2 = ((q[:, None, :] - loc[None, :, :]) ** 2).sum(-1)  # exact in fp64 for these inputs (lattice case)
+        want = d2.argmin(1)  # numpy's argmin returns the first (lowest index) minimum
+        cloud = E.DeviceCloud(ident_features(loc))
+        got_g, got_b = cloud.nearest(q, E.NN_GRID), cloud.nearest(q, E.NN_BRUTE)
+        cloud.close()
+        assert np.array_equal(got_g, got_b)
+        if not clustered:
+            assert np.array_equal(got_g, want)
+        else:  # general position: the nearest is unique, whatever the summation order of d2
+            assert np.array_equal(got_g, want) or np.allclose(np.take_along_axis(d2, got_g[:, None], 1)[:, 0], d2.min(1), rtol=1e-12)
+
+    run()
+
+
 def test_asymmetric_projector_rejected(E):
     pair = synth.make_pair(10, 10, 3)
     pair.fixed.proj[0, 1] += 1e-3
