@@ -312,6 +312,38 @@ def test_transform_jump_keeps_matches_exact(E, ob):
     g.close()
 
 
+def test_match_ties_through_every_search_path(E, ob):
+    """lattice clouds with duplicate points under exact half-cell translations: every query has
+    several exactly equidistant targets.  The first search of a level (tile kernel), the later ones
+    (ball kernel seeded with the previous match, wave-per-query phase for the wide balls after a
+    jump) and the all-vs-all kernel must all pick the lowest index, like the oracle's linear scan."""
+    rng = np.random.default_rng(12)
+    nf, nm = 6000, 5000
+    floc = rng.integers(0, 12, size=(nf, 3)).astype(np.float64)  # 6000 points on 1728 lattice sites: duplicates
+    mloc = rng.integers(0, 12, size=(nm, 3)).astype(np.float64)
+
+    def feats(loc):
+        n = loc.shape[0]
+        return synth.FeatureSet(loc, np.tile(np.eye(3).ravel(), (n, 1)), np.ones(n), np.full(n, 2, np.uint8),
+                                np.tile(np.array([0, 0, 1.0, 1.0, 0, 0]), (n, 1)))
+    pair = synth.VolumePair(feats(floc), feats(mloc), synth.Transform(np.eye(3), np.zeros(3), np.zeros(3)), 12.0)
+    T0 = pair.planted
+    for method in ("grid", "brute"):
+        g = E.Estimator(E.CDCL_FORWARD, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=3,
+                        nn_method=E.NN_GRID if method == "grid" else E.NN_BRUTE)
+        c = ob.OracleEstimator(ob.CDCL_FORWARD, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=3)
+        for shift in ([0.5, 0.0, 0.0], [0.5, 0.5, 0.0], [0.5, 0.5, 0.5], [0.0, 0.0, 0.0], [4.5, -3.5, 2.5], [0.5, 0.5, 0.5]):
+            for e in (g, c):
+                e.set_transform(np.eye(3), np.array(shift), np.zeros(3))
+                e.set_number_points(nm)
+                e.find_closest_euclidean()
+            fg, tg, _ = g.matches(0)
+            fc, tc, _ = c.matches(0)
+            assert np.array_equal(fg, fc), (method, shift)
+            assert np.array_equal(tg, tc), (method, shift)
+        g.close()
+
+
 def test_small_and_ragged_inputs(E, ob):
     """fewer than 1000 points, unequal sizes, a single moving point"""
     for nm, nf in ((1, 40), (37, 900), (999, 1001)):
