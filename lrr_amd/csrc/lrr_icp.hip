@@ -1800,7 +1800,7 @@ __global__ __launch_bounds__(kSelThreads) void k_selw_final(SelPack jobs, double
 }
 
 // ---------------------------------------------------------------------------------------------
-// fused symmetric estimate: six kernels, no host round trip in between.  Scalars (scales,
+// fused symmetric estimate: nine kernels, no host round trip in between.  Scalars (scales,
 // normalisation statistics, MAD factors) are re-derived in each consumer kernel's prologue from
 // the producer's per-block partials, summed by every block in the same fixed order.
 // ---------------------------------------------------------------------------------------------
