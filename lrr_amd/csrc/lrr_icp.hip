@@ -157,6 +157,8 @@ struct lrr_icp_cloud {
   bool has_shapes = false;
   std::vector<int> h_orig_of;   // host copy of orig_of for later per-feature uploads
   double *str = nullptr;        // n, canonical order: strength_ alone (the passes that need nothing else of the from-record)
+  float4 *gpf = nullptr;        // n, raster order like gp: (x, y, z) in cell units relative to the grid origin as floats + canonical index bits:
+                                // the single-precision pre-filter of the ball search
   GridPoint *cpt = nullptr;     // n, canonical order: location + indices of target `canon` in one 32-B read (previous-match bound)
   int *cell_start = nullptr;    // ncell + 1
   int *fine_start = nullptr;    // ncell * fine + 1: every cell cut into `fine` slices along x (ball search)
@@ -184,6 +186,8 @@ struct lrr_icp_dir {
 
 namespace {
 
+inline float __int_as_float_host(int v) { float f; std::memcpy(&f, &v, sizeof f); return f; }
+
 int fail(lrr_icp_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg;
   return code;
@@ -208,6 +212,8 @@ struct GridView {
   const GridPoint *gp;   // points sorted by grid cell
   const int *cell_start;
   const int *fine_start;  // cells cut into `fine` x-slices; points of a cell are sorted by slice
+  const float4 *gpf;      // gp as floats in cell units + canonical index (pre-filter)
+  const GridPoint *cpt;   // points in canonical order (exact confirmation)
   double lox, loy, loz, h, inv_h, tol;
   int dx, dy, dz, n, fine;
 };
@@ -821,6 +827,12 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
   const float uy = (float)((yy - g.loy) * g.inv_h), uz = (float)((yz - g.loz) * g.inv_h);
   const float uxs = (float)((yx - g.lox) * inv_hx), finef = (float)g.fine;
   const float inv_hf = (float)g.inv_h * 1.000001f;
+  const float qfx = (float)((yx - g.lox) * g.inv_h), qfy = uy, qfz = uz;  // the query in cell units
+  float thr2;
+  {
+    const float tb = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + 3e-4f;
+    thr2 = tb * tb;
+  }
   int yi = ya, zi = za;  // (z,y) of row r0: advanced without integer division
   int row = (za * g.dy + ya) * fdx;
   const int row_wrap = (g.dy - nyr) * fdx;
@@ -859,19 +871,37 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
     }
     budget -= total;
     if (budget < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }  // m_to[s] keeps the previous match
+    // Single-precision pre-filter: a candidate is read as 16 B (location in cell units, canonical
+    // index) and its approximate distance compared with the best exact distance so far plus the
+    // error bound of the approximation (coordinates < 512 cells: |d~ - d| < 2e-4 cell).  Only a
+    // candidate that may beat or TIE the best is fetched in full and compared exactly, with the
+    // lexicographic (distance, lowest original index) rule; every other one is provably farther.
     for (int c0 = 0; c0 < total; c0 += kScanUnroll) {
-      GridPoint pt[kScanUnroll];
+      float4 pf[kScanUnroll];
 #pragma unroll
       for (int v = 0; v < kScanUnroll; ++v) {
         const int c = min(c0 + v, total - 1);
         int addr = c + dl[0];
 #pragma unroll
         for (int u = 1; u < kBallRows; ++u) addr += c >= pre[u] ? dl[u] : 0;
-        pt[v] = g.gp[addr];
+        pf[v] = g.gpf[addr];
       }
 #pragma unroll
-      for (int v = 0; v < kScanUnroll; ++v)
-        if (c0 + v < total) consider(b, dist2(yx, yy, yz, pt[v].x, pt[v].y, pt[v].z), pt[v].orig, pt[v].canon);
+      for (int v = 0; v < kScanUnroll; ++v) {
+        if (c0 + v >= total) continue;
+        const float ex = pf[v].x - qfx, ey = pf[v].y - qfy, ez = pf[v].z - qfz;
+        const float a2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+        if (a2 > thr2) continue;  // strictly farther than the best, whatever the rounding
+        const int cn = __float_as_int(pf[v].w);
+        if (cn == b.canon) continue;
+        const GridPoint pt = g.cpt[cn];
+        const double d2 = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
+        if (d2 < b.d || (d2 == b.d && pt.orig < b.orig)) {
+          b.d = d2; b.orig = pt.orig; b.canon = cn;
+          const float tb = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + 3e-4f;
+          thr2 = tb * tb;
+        }
+      }
     }
   }
   A.m_to[s] = b.canon;
@@ -2377,6 +2407,7 @@ XfD identity_xf() {
 GridView view_of(const lrr_icp_cloud *c) {
   GridView g;
   g.gp = c->gp; g.cell_start = c->cell_start; g.fine_start = c->fine_start; g.fine = c->fine;
+  g.gpf = c->gpf; g.cpt = c->cpt;
   g.lox = c->lo[0]; g.loy = c->lo[1]; g.loz = c->lo[2];
   g.h = c->h; g.inv_h = c->inv_h; g.tol = c->tol;
   g.dx = c->dim[0]; g.dy = c->dim[1]; g.dz = c->dim[2];
@@ -2848,6 +2879,14 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
     int pos = cursor[(size_t)slice[(size_t)i]]++;
     gp[(size_t)pos] = GridPoint{loc[3 * i], loc[3 * i + 1], loc[3 * i + 2], canon_of[(size_t)i], (int)i};
   }
+  std::vector<float4> gpf(m);
+  for (size_t k = 0; k < (size_t)n; ++k) {
+    const GridPoint &pt = gp[k];
+    float4 f;
+    f.x = (float)((pt.x - lo[0]) * c->inv_h); f.y = (float)((pt.y - lo[1]) * c->inv_h); f.z = (float)((pt.z - lo[2]) * c->inv_h);
+    f.w = __int_as_float_host(pt.canon);
+    gpf[k] = f;
+  }
   std::vector<GridPoint> cpt(m);
   std::vector<double> strv(m, 0.0);
   for (int64_t sidx = 0; sidx < n; ++sidx) strv[(size_t)sidx] = rec[(size_t)sidx * kRecStride + 9];
@@ -2866,6 +2905,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
       {(void **)&c->src, src.data(), sizeof(SrcPoint) * m, 0},
       {(void **)&c->gp, gp.data(), sizeof(GridPoint) * m, 0},
       {(void **)&c->cpt, cpt.data(), sizeof(GridPoint) * m, 0},
+      {(void **)&c->gpf, gpf.data(), sizeof(float4) * m, 0},
       {(void **)&c->str, strv.data(), sizeof(double) * m, 0},
       {(void **)&c->shp, nullptr, sizeof(ShapeRec) * m, 0},
       {(void **)&c->orig_of, orig_of.data(), sizeof(int) * m, 0},
