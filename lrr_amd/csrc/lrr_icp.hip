@@ -53,7 +53,7 @@ constexpr int kMaxBlocks = 2048;     // reduction grids: 8 blocks / CU on 256 CU
 constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 for dof 12)
 constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
 constexpr int kTile = 8;             // canonical order: tiles of kTile^3 grid cells
-constexpr int kScanUnroll = 4;       // candidate loads in flight per lane in the global-memory grid search
+constexpr int kScanUnroll = 8;       // candidate loads in flight per lane in the global-memory grid search
 constexpr int kEasyBudget = 48;      // candidate points a lane may scan in the thread-per-query global search
 constexpr int kRingMax = 8;          // rings walked by the wave-per-query phase before the brute-force fallback
 constexpr int kTileBudget = 48;      // candidates a lane may scan from LDS before handing its query over
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoin
 constexpr int kBallBlock = 64;      // one wavefront per block: the scheduler packs and refills SIMDs wave by wave
 constexpr int kBallRows = 9;        // (z,y) rows whose cell bounds a lane fetches in one round trip
 constexpr int kBallBudget = 64;     // candidates a lane may scan before handing its query over
-constexpr double kBallCells = 2.5;  // widest ball (in cells) the thread-per-query search takes
+constexpr double kBallCells = 3.0;  // widest ball (in cells) the thread-per-query search takes
 struct BallArgs {  // one direction of a ball search
   GridView g;
   const SrcPoint *src;
