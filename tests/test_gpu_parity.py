@@ -344,6 +344,35 @@ def test_match_ties_through_every_search_path(E, ob):
         g.close()
 
 
+def test_match_ties_at_the_largest_cell_coordinates(E, ob):
+    """a needle-shaped cloud (1000 x 0.25 x 0.25 mm) drives the search grid to its 512-cell limit
+    along x, where the single-precision pre-filter of the ball search is least accurate; the features
+    sit on a 0.25 mm lattice and the transform shifts by exactly half a spacing, so every query has
+    two or more exactly equidistant targets: the lowest index must win, as in the oracle"""
+    xs = np.arange(0.0, 1000.0 + 1e-9, 0.25)
+    lat = np.array([[x, y, z] for x in xs for y in (0.0, 0.25) for z in (0.0, 0.25)])
+    rng = np.random.default_rng(3)
+    floc = lat[rng.permutation(lat.shape[0])]
+    mloc = lat[rng.permutation(lat.shape[0])][:12000]
+
+    def feats(loc):
+        n = loc.shape[0]
+        return synth.FeatureSet(np.ascontiguousarray(loc), np.tile(np.eye(3).ravel(), (n, 1)), np.ones(n), np.zeros(n, np.uint8), np.zeros((n, 6)))
+    mv, fx = feats(mloc), feats(floc)
+    I, z = np.eye(3), np.zeros(3)
+    g = E.Estimator(E.CDCL_FORWARD, 12, mv, fx, I, z, z, seed=4)
+    c = ob.OracleEstimator(ob.CDCL_FORWARD, 12, mv, fx, I, z, z, seed=4)
+    for shift in ([0.125, 0.0, 0.0], [0.125, 0.125, 0.0], [0.125, 0.125, 0.125], [-0.125, 0.0, 0.125], [0.125, 0.0, 0.0]):
+        for e in (g, c):
+            e.set_transform(I, np.array(shift), z)
+            e.set_number_points(mloc.shape[0])
+            e.find_closest_euclidean()
+        fg, tg, _ = g.matches(0)
+        fc, tc, _ = c.matches(0)
+        assert np.array_equal(fg, fc) and np.array_equal(tg, tc), shift
+    g.close()
+
+
 def test_small_and_ragged_inputs(E, ob):
     """fewer than 1000 points, unequal sizes, a single moving point"""
     for nm, nf in ((1, 40), (37, 900), (999, 1001)):
