@@ -795,7 +795,12 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
   const SrcPoint *src = A.src;
   const int nsrc = A.nsrc;
   int budget = A.budget;
-  const int s = blockIdx.x * kBallBlock + threadIdx.x;
+  // workgroups go round robin over the 8 XCDs (each with its own L2): give every XCD one contiguous
+  // eighth of the canonical (spatially sorted) source range, so that its L2 holds one region of the
+  // target structures instead of a sample of all of them
+  const int per = (int)gridDim.x >> 3;  // the grid is a multiple of 8 blocks (ball_blocks_for)
+  const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int s = lblock * kBallBlock + threadIdx.x;
   if (s >= nsrc) return;
   const SrcPoint sp = src[s];
   const int prev = A.m_to[s];
@@ -2581,6 +2586,8 @@ OverArgs over_args(const HardArgs &h) {
   a.g = h.g; a.q = h.q; a.xf = h.xf; a.overflow = h.overflow; a.overflow_count = h.overflow_count; a.m_to = h.m_to;
   return a;
 }
+// blocks of the ball kernels: one wavefront each, rounded up to a multiple of 8 for the XCD mapping
+inline unsigned ball_blocks_for(int64_t n) { return (unsigned)((((n + kBallBlock - 1) / kBallBlock) + 7) / 8 * 8); }
 inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + 3) / 4)); }
 
 // all_have_prev: every handed-over query carries a previous match (ball-search state), so phase 2
@@ -3104,7 +3111,7 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     return launch_brute(ctx, L, st, d->to, P.g, P.q, L.d_active, P.x, (int)n_points, d->m_to);
   }
   if (P.steady) {
-    hipLaunchKernelGGL(k_match_ball, dim3((unsigned)((N + kBallBlock - 1) / kBallBlock)), dim3(kBallBlock), 0, st, ball_args(d, P, L));
+    hipLaunchKernelGGL(k_match_ball, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, ball_args(d, P, L));
   } else if (P.dense) {
     hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, P.g, d->from->src, d->from->chunks, P.kk, P.half, (int)N, (int)n_points, P.x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, L.d_hard, P.counts, kTileBudget);
   } else {
@@ -3155,7 +3162,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     if (Pf.steady && Pb.steady) {
       ProfScope prof(ctx, st, 2);
       BallArgs af = ball_args(f, Pf, ctx->lane[0]), ab = ball_args(b, Pb, ctx->lane[1]);
-      hipLaunchKernelGGL(k_match_ball2, dim3((unsigned)((std::max(Pf.N, Pb.N) + kBallBlock - 1) / kBallBlock), 2), dim3(kBallBlock), 0, st, af, ab);
+      hipLaunchKernelGGL(k_match_ball2, dim3(ball_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBallBlock), 0, st, af, ab);
       HIPCHK(ctx, hipGetLastError());
       HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);
       HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
