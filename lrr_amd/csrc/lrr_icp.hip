@@ -334,6 +334,11 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *parti
   }
 }
 
+// Workgroups are dealt round robin to the 8 XCDs, each with its own L2.  xcd_block turns block lb of a
+// grid of nb (a multiple of 8) into a logical block so that every XCD works on one contiguous eighth
+// of a canonical (spatially sorted) range and its L2 holds one region of the gathered records.
+__device__ __forceinline__ int xcd_block(int lb, int nb) { return (lb & 7) * (nb >> 3) + (lb >> 3); }
+
 // K block-wide totals at once (per-thread partial sums in, totals out, same value in every thread
 // and in every block: lanes by shuffle tree, then the 4 waves in index order).  The consumer kernels
 // of the fused estimate derive their scalars from the producers' partial tables with it: one memory
@@ -1269,7 +1274,7 @@ __global__ void k_assign(const int *slot, const double *r2, double scale, int ns
 // K4 (cdcl .txx:196-268)
 __global__ __launch_bounds__(kBlock) void k_errors(PairSrc ps, XfD xf, NormD nm, const double *w, double *partials) {
   double acc[3] = {0.0, 0.0, 0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+  for (int s = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
     if (ps.slot[s] < 0) continue;
     double r2 = pair_residual2(ps, s, xf, nm);
     double wi = w[s];
@@ -1859,7 +1864,7 @@ __global__ __launch_bounds__(kBlock) void k_f_residual(DirArgs F, DirArgs B, int
   const bool isF = (int)blockIdx.x < nbF;
   const DirArgs &D = isF ? F : B;
   const XfD &xf = isF ? xfF : xfB;
-  const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
+  const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
     // every load whose address does not depend on another is issued before the first test: two
@@ -1954,7 +1959,7 @@ __global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int 
                                                       double *SC, double *P4) {
   const bool isF = (int)blockIdx.x < nbF;
   const DirArgs &D = isF ? F : B;
-  const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
+  const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
   const int r0 = isF ? 0 : nbF, r1 = isF ? nbF : nbF + nbB;
   const int mode = isF ? o.mode_f : o.mode_b;
   double tot[4] = {0.0, 0.0, 0.0, 0.0};  // S, W of this list's residuals; radius sums of both clouds
@@ -2038,7 +2043,8 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
   constexpr int U = kAccBatch;
   const bool isF = (int)blockIdx.x < nbF;
   const DirArgs &D = isF ? F : B;
-  const int lb = isF ? blockIdx.x : blockIdx.x - nbF, nb = isF ? nbF : nbB;
+  const int nb = isF ? nbF : nbB, lb0 = isF ? blockIdx.x : blockIdx.x - nbF;
+  const int lb = (nb & 7) == 0 ? xcd_block(lb0, nb) : lb0;
   NormD nm = norm_from_scalars(SC, !isF);
   const bool clone = !o.rrl && !isF;
   const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
@@ -2377,9 +2383,9 @@ __global__ __launch_bounds__(kBlock) void k_fw_accumulate(DirArgs F, FwdOpts o, 
 // ---------------------------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------------------------
-inline int grid_for(int64_t n) {
-  int64_t b = (n + kBlock - 1) / kBlock;
-  if (b < 1) b = 1;
+inline int grid_for(int64_t n) {  // a multiple of 8 blocks: see xcd_block
+  int64_t b = ((n + kBlock - 1) / kBlock + 7) / 8 * 8;
+  if (b < 8) b = 8;
   return (int)std::min<int64_t>(b, kMaxBlocks);
 }
 inline int blocks_for(int64_t n) { return (int)std::max<int64_t>(1, (n + kBlock - 1) / kBlock); }
