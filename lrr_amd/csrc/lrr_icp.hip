@@ -2271,7 +2271,7 @@ __global__ __launch_bounds__(kBlock) void k_fw_residual(DirArgs F, FwdOpts o, Xf
   }
   const XfD T = o.normalize ? normalized_xf(xf, nm, o.rigid) : xf;
   double acc[2] = {0.0, 0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+  for (int s = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
     if (F.ps.slot[s] < 0) { F.key_s[s] = INFINITY; continue; }
     double p0, p1, p2, y0, y1, y2;
     load_from(F.ps, s, p0, p1, p2);
@@ -2337,7 +2337,8 @@ __global__ __launch_bounds__(kBlock) void k_fw_accumulate(DirArgs F, FwdOpts o, 
 #pragma unroll
   for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
   const int stride = gridDim.x * kBlock;
-  for (int s0 = blockIdx.x * kBlock + threadIdx.x; s0 < F.ps.nsrc; s0 += U * stride) {
+  const int lb = (gridDim.x & 7) == 0 ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  for (int s0 = lb * kBlock + threadIdx.x; s0 < F.ps.nsrc; s0 += U * stride) {
     int mt[U];
     double wi[U];
     bool on[U];
