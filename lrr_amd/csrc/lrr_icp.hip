@@ -795,37 +795,19 @@ struct BallArgs {  // one direction of a ball search
   int budget;
   double max_rad;
 };
-__device__ __forceinline__ void match_ball_body(const BallArgs &A) {
-  const GridView &g = A.g;
-  const SrcPoint *src = A.src;
-  const int nsrc = A.nsrc;
-  int budget = A.budget;
-  // workgroups go round robin over the 8 XCDs (each with its own L2): give every XCD one contiguous
-  // eighth of the canonical (spatially sorted) source range, so that its L2 holds one region of the
-  // target structures instead of a sample of all of them
-  const int per = (int)gridDim.x >> 3;  // the grid is a multiple of 8 blocks (ball_blocks_for)
-  const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  const int s = lblock * kBallBlock + threadIdx.x;
-  if (s >= nsrc) return;
-  const SrcPoint sp = src[s];
-  const int prev = A.m_to[s];
-  const int j = subset_perm_inv((int)sp.orig, nsrc, A.half, A.keys);
-  const bool active = j < A.n_points;
-  A.slot[s] = active ? j : -1;
-  if (!active) return;
-  A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-  if (prev < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }
-  double yx, yy, yz;
-  map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
-  Best b;
+// The ball search of one query (yx, yy, yz) whose previous match `prev` (a canonical target index) bounds
+// the distance: true = b holds the exact nearest neighbour; false = ball wider than max_rad or more
+// than `budget` candidates (the caller hands the query to the wave-per-query phase).
+__device__ __forceinline__ bool ball_search(const GridView &g, const GridPoint *to_pt, double yx, double yy, double yz,
+                                            int prev, int budget, double max_rad, Best &b) {
   {
-    const GridPoint q = A.to_pt[prev];  // one 32-B gather: location and original index of the previous match
+    const GridPoint q = to_pt[prev];  // one 32-B gather: location and original index of the previous match
     b.d = dist2(yx, yy, yz, q.x, q.y, q.z);
     b.orig = q.orig;
     b.canon = prev;
   }
   const double rad = sqrt(b.d) + 2.0 * g.tol;
-  if (!(rad <= A.max_rad)) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }  // outlier: a whole wavefront serves it better
+  if (!(rad <= max_rad)) return false;  // outlier: a whole wavefront serves it better
   const double inv_hx = g.inv_h * g.fine;
   const int fdx = g.dx * g.fine;  // x-slices per row
   const int xa0 = clampi((int)floor((yx - rad - g.lox) * inv_hx), 0, fdx - 1), xb0 = clampi((int)floor((yx + rad - g.lox) * inv_hx), 0, fdx - 1);
@@ -880,7 +862,7 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
       total += re[u] - rs[u];
     }
     budget -= total;
-    if (budget < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }  // m_to[s] keeps the previous match
+    if (budget < 0) return false;  // the caller hands the query over; m_to[s] keeps the previous match
     // Single-precision pre-filter: a candidate is read as 16 B (location in cell units, canonical
     // index) and its approximate distance compared with the best exact distance so far plus the
     // error bound of the approximation (coordinates < 512 cells: |d~ - d| < 2e-4 cell).  Only a
@@ -914,9 +896,34 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
       }
     }
   }
-  A.m_to[s] = b.canon;
+  return true;
 }
 
+__device__ __forceinline__ void match_ball_body(const BallArgs &A) {
+  const GridView &g = A.g;
+  const SrcPoint *src = A.src;
+  const int nsrc = A.nsrc;
+  // workgroups go round robin over the 8 XCDs (each with its own L2): give every XCD one contiguous
+  // eighth of the canonical (spatially sorted) source range, so that its L2 holds one region of the
+  // target structures instead of a sample of all of them
+  const int per = (int)gridDim.x >> 3;  // the grid is a multiple of 8 blocks (ball_blocks_for)
+  const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int s = lblock * kBallBlock + threadIdx.x;
+  if (s >= nsrc) return;
+  const SrcPoint sp = src[s];
+  const int prev = A.m_to[s];
+  const int j = subset_perm_inv((int)sp.orig, nsrc, A.half, A.keys);
+  const bool active = j < A.n_points;
+  A.slot[s] = active ? j : -1;
+  if (!active) return;
+  A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+  if (prev < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }
+  double yx, yy, yz;
+  map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
+  Best b;
+  if (ball_search(g, A.to_pt, yx, yy, yz, prev, A.budget, A.max_rad, b)) A.m_to[s] = b.canon;
+  else A.hard[atomicAdd(A.hard_count, 1)] = s;  // m_to[s] keeps the previous match: a bound for phase 2
+}
 __global__ __launch_bounds__(kBallBlock) void k_match_ball(BallArgs A) { match_ball_body(A); }
 // both directions of a symmetric estimator in one launch: blockIdx.y picks the direction
 __global__ __launch_bounds__(kBallBlock) void k_match_ball2(BallArgs A, BallArgs B) {
@@ -1118,6 +1125,10 @@ __device__ __forceinline__ void match_overflow_body(const OverArgs &A) {
   }
 }
 __global__ __launch_bounds__(kBlock) void k_match_overflow(OverArgs A) { match_overflow_body(A); }
+__global__ __launch_bounds__(kBlock) void k_match_overflow2(OverArgs A, OverArgs B) {
+  if (blockIdx.y == 0) match_overflow_body(A);
+  else match_overflow_body(B);
+}
 
 // slot assignment + active list for the all-vs-all matcher
 __global__ void k_slots_dense(const SrcPoint *src, Keys keys, int half, int nsrc, int n_points, int *slot,
@@ -2597,8 +2608,11 @@ OverArgs over_args(const HardArgs &h) {
 inline unsigned ball_blocks_for(int64_t n) { return (unsigned)((((n + kBallBlock - 1) / kBallBlock) + 7) / 8 * 8); }
 inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + 3) / 4)); }
 
-// all_have_prev: every handed-over query carries a previous match (ball-search state), so phase 2
-// settles all of them and phase 3 has nothing to do
+// all_have_prev: every handed-over query carries a previous match, so phase 2 settles all of them and
+// phase 3 has nothing to do.  That holds only when the WHOLE cloud was matched by the previous search
+// (n_points == N twice in a row): at a dense sub-full level the keyed subset changes with every
+// search, sources that were never matched enter phase 2 without a bound, walk the rings and may end
+// in the overflow list, which phase 3 must then serve.
 int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts, bool all_have_prev) {
   HardArgs h = hard_args(L, to, g, q, xf, m_to, counts);
   hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n)), dim3(kBlock), 0, st, h);
@@ -3126,7 +3140,7 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, P.counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady);
+  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady && n_points == N);
 }
 
 // one K1 submission on lane L and its stream
@@ -3175,7 +3189,13 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
       hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
       HIPCHK(ctx, hipGetLastError());
-      return LRR_ICP_OK;  // no phase 3: every query of this state carries a previous match, which phase 2 settles
+      // no phase 3 when both whole clouds were matched last time: every query then carries a previous
+      // match, which phase 2 settles.  At a dense sub-full level some sources have none (see
+      // launch_hard_phases) and may overflow the ring walk.
+      if (n_f == Pf.N && n_b == Pb.N) return LRR_ICP_OK;
+      hipLaunchKernelGGL(k_match_overflow2, dim3(128, 2), dim3(kBlock), 0, st, over_args(hf), over_args(hb));
+      HIPCHK(ctx, hipGetLastError());
+      return LRR_ICP_OK;
     }
     // (not reached: the test above mirrors match_prepare's) fall through to separate launches
     ProfScope prof(ctx, st, 2);

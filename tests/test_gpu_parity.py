@@ -312,6 +312,50 @@ def test_transform_jump_keeps_matches_exact(E, ob):
     g.close()
 
 
+def test_dense_subfull_level_with_unreachable_queries(E, ob):
+    """a dense level below the full cloud (N/4 <= n_points < N): every search draws a new keyed subset,
+    so the second search holds sources that were never matched.  With a fixed cloud of two far-apart
+    clusters, moving features mapped into the empty space between them lie more than the ring limit of
+    the wave-per-query phase from every target and must be served by the brute-force phase — on every
+    search path (first search of the level, later searches, pair of directions)."""
+    rng = np.random.default_rng(31)
+    n = 20000
+
+    def feats(loc):
+        m = loc.shape[0]
+        return synth.FeatureSet(np.ascontiguousarray(loc), np.tile(np.eye(3).ravel(), (m, 1)), rng.uniform(1, 50, m),
+                                np.zeros(m, np.uint8), np.zeros((m, 6)))
+    floc = np.concatenate([rng.normal(scale=3.0, size=(n // 2, 3)), rng.normal(scale=3.0, size=(n // 2, 3)) + 400.0])
+    mloc = np.concatenate([floc[: n // 2] + rng.normal(scale=0.2, size=(n // 2, 3)),
+                           rng.uniform(120.0, 280.0, size=(n // 2, 3))])  # half of them in the void between the clusters
+    mloc = mloc[rng.permutation(n)]
+    fx, mv = feats(floc), feats(mloc)
+    I, z = np.eye(3), np.zeros(3)
+    g = E.Estimator(E.CDCL_FORWARD, 12, mv, fx, I, z, z, seed=5)
+    c = ob.OracleEstimator(ob.CDCL_FORWARD, 12, mv, fx, I, z, z, seed=5)
+    for k in range(3):
+        for e in (g, c):
+            e.set_number_points(n // 2)
+            e.find_closest_euclidean()
+        fg, tg, _ = g.matches(0)
+        fc, tc, _ = c.matches(0)
+        assert np.array_equal(fg, fc), k
+        assert tg.min() >= 0 and np.array_equal(tg, tc), k
+    g.close()
+    # both directions of a symmetric estimator (merged launches of the later searches)
+    g = E.Estimator(E.RRL_SYMMETRIC, 12, mv, fx, I, z, z, moving_inside=mv, fixed_inside=fx, seed=6)
+    c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, mv, fx, I, z, z, moving_inside=mv, fixed_inside=fx, seed=6)
+    for k in range(3):
+        for e in (g, c):
+            e.set_number_points(n // 2)
+            e.find_closest_euclidean()
+        for d in (0, 1):
+            fg, tg, _ = g.matches(d)
+            fc, tc, _ = c.matches(d)
+            assert np.array_equal(fg, fc) and tg.min() >= 0 and np.array_equal(tg, tc), (k, d)
+    g.close()
+
+
 def test_match_ties_through_every_search_path(E, ob):
     """lattice clouds with duplicate points under exact half-cell translations: every query has
     several exactly equidistant targets.  The first search of a level (tile kernel), the later ones
