@@ -135,6 +135,94 @@ class device_cloud {
   lrr_icp_cloud *h_;
 };
 
+// C = svd(AtA).inverse(); covariance = C; theta = C Atb (cdcl .txx:1073-1083; rrl sym .txx:880-894)
+template <unsigned dof>
+inline void solve_normal_equations(typename cdcl_trans<3, dof>::sptr const &T, const double *AtA, const double *Atb,
+                                   bool estimate_parameters) {
+  vnl_matrix_fixed<double, dof, dof> invAA;
+  linalg::sym_inverse((int)dof, AtA, invAA.data_block());
+  T->set_covariance(invAA);
+  if (estimate_parameters) {
+    vnl_vector<double> p(dof, 0.0);
+    for (unsigned i = 0; i < dof; ++i) {
+      double s = 0.0;
+      for (unsigned k = 0; k < dof; ++k) s += invAA(i, k) * Atb[k];
+      p[i] = s;
+    }
+    T->set_parameterization(p);
+  }
+}
+
+// Host half of the symmetric estimate_LS once the device has returned the statistics and the normal
+// equations (rrl sym .txx:713-721, 880-912; cdcl sym .txx:470-478, 643-695): normalise both transforms
+// (the backward one with flipped centres and radii), solve, un-normalise, backward = inverse(forward).
+// F / B: the transforms in the forward and the backward ROLE (estimate_LS_backward swaps them).
+template <unsigned dof>
+inline void symmetric_apply_solution(typename cdcl_trans<3, dof>::sptr const &F, typename cdcl_trans<3, dof>::sptr const &B,
+                                     const lrr_icp_sym_out &r, bool normalize, bool estimate_parameters) {
+  vnl_vector_fixed<double, 3> cm(0.0), cf(0.0);
+  double rm = 0.0, rf = 0.0;
+  if (normalize) {
+    for (int d = 0; d < 3; ++d) { cm[d] = r.norm.cm[d]; cf[d] = r.norm.cf[d]; }
+    rm = r.norm.rm;
+    rf = r.norm.rf;
+    F->normalize(rm, rf, cm, cf);
+    B->normalize(rf, rm, cf, cm);  // flipped centres and radii
+  }
+  solve_normal_equations<dof>(F, r.AtA, r.Atb, estimate_parameters);
+  if (normalize) {
+    F->unnormalize(rm, rf, cm, cf);
+    B->unnormalize(rf, rm, cf, cm);
+  }
+}
+
+// Convergence test, oscillation counters and coarse-to-fine schedule of the symmetric classes
+// (rrl sym .txx:383-437; cdcl sym .txx:311-361).  step() takes the forward weighted error before and
+// after the iteration; grow(n) sets number_points of both lists and returns true at the finest level.
+struct symmetric_schedule {
+  unsigned int oscillation_count_;
+  double error_difference_, weighted_error_;
+  unsigned int number_matches_;
+  bool finest_level_;
+  symmetric_schedule() { reset(); weighted_error_ = 0.0; }
+  void reset() {
+    oscillation_count_ = 0;
+    error_difference_ = 0.0;
+    number_matches_ = 1000;
+    finest_level_ = false;
+  }
+  bool oscillated() const { return oscillation_count_ > 10; }
+  template <class Grow>
+  bool step(double weighted_error_before, double weighted_error_after, unsigned int iteration, bool rrl, Grow grow) {
+    double curr_error_difference = weighted_error_after - weighted_error_before;
+    double diff = (weighted_error_after - weighted_error_before) / weighted_error_after;
+    bool converged = std::fabs(diff) < 1e-4;
+    weighted_error_ = weighted_error_after;
+    if (!rrl || iteration > 0) {  // the rrl class guards the oscillation logic with iteration > 0 (:387)
+      if (!finest_level_ && (oscillation_count_ > 1 || (std::fabs(diff) < 0.01))) converged = true;
+      else if (!converged) {
+        if (weighted_error_after > 1.5) {
+          if (curr_error_difference * error_difference_ < 0.0) ++oscillation_count_;
+          else if (oscillation_count_ > 0) --oscillation_count_;
+          if (oscillated()) converged = true;
+        } else {
+          if (curr_error_difference > 0.0) ++oscillation_count_;
+          if (oscillation_count_ > 3) converged = true;
+        }
+      }
+    }
+    error_difference_ = curr_error_difference;
+    if (converged && !finest_level_) {
+      converged = false;
+      number_matches_ *= 2;
+      finest_level_ = grow(number_matches_);
+      oscillation_count_ = 0;
+      error_difference_ = 0.0;
+    }
+    return converged && finest_level_;
+  }
+};
+
 template <unsigned dof, class FeatureT, bool RRL> class icp_symmetric;
 
 // =============================================================================================
@@ -503,22 +591,10 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     double c[3] = {jac_trans->center_moving_[0], jac_trans->center_moving_[1], jac_trans->center_moving_[2]};
     check(lrr_icp_accumulate(dir_, (int)dof, c, &norm_, flags, AtA, Atb), "normal equations");
   }
-  // C = svd(AtA).inverse(); covariance = C; theta = C Atb (cdcl .txx:1073-1083)
   void solve_and_set(trans_sptr_type const &T, const double *AtA, const double *Atb, bool estimate_parameters) {
     for (unsigned i = 0; i < dof * dof; ++i) last_AtA_[i] = AtA[i];
     for (unsigned i = 0; i < dof; ++i) last_Atb_[i] = Atb[i];
-    vnl_matrix_fixed<double, dof, dof> invAA;
-    linalg::sym_inverse((int)dof, AtA, invAA.data_block());
-    T->set_covariance(invAA);
-    if (estimate_parameters) {
-      vnl_vector<double> p(dof, 0.0);
-      for (unsigned i = 0; i < dof; ++i) {
-        double s = 0.0;
-        for (unsigned k = 0; k < dof; ++k) s += invAA(i, k) * Atb[k];
-        p[i] = s;
-      }
-      T->set_parameterization(p);
-    }
+    solve_normal_equations<dof>(T, AtA, Atb, estimate_parameters);
   }
   // rigid increment bracket (cdcl .txx:455-484 and :490-496)
   trans_sptr_type begin_rigid_increment() {
@@ -589,8 +665,7 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
   icp_symmetric(vcl_vector<feature_sptr_type> const &moving, vcl_vector<feature_sptr_type> const &fixed,
                 trans_sptr_type const &trans, trans_sptr_type const &trans_inverse,
                 vcl_vector<feature_sptr_type> const &moving_inside, vcl_vector<feature_sptr_type> const &fixed_inside)
-      : normalize_matches_(true), oscillation_count_(0), error_difference_(0.0), weighted_error_(0.0),
-        number_matches_(1000), finest_level_(false) {
+      : normalize_matches_(true) {
     forward_ = new estimation_type(moving_inside, fixed, trans);
     backward_ = new estimation_type(fixed_inside, moving, trans_inverse);
     forward_->weight_by_strength(true);
@@ -603,8 +678,7 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
   icp_symmetric(vcl_vector<feature_sptr_type> const &moving, vcl_vector<feature_sptr_type> const &fixed,
                 trans_sptr_type const &trans, trans_sptr_type const &trans_inverse, location_type const &moving_x0,
                 location_type const &moving_x1, location_type const &fixed_x0, location_type const &fixed_x1)
-      : normalize_matches_(true), oscillation_count_(0), error_difference_(0.0), weighted_error_(0.0),
-        number_matches_(1000), finest_level_(false) {
+      : normalize_matches_(true) {
     vcl_vector<feature_sptr_type> fixed_inside = inside(fixed, fixed_x0, fixed_x1);
     vcl_vector<feature_sptr_type> moving_inside = inside(moving, moving_x0, moving_x1);
     forward_ = new estimation_type(moving_inside, fixed, trans);
@@ -652,34 +726,11 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     if (caller && display_points)
       display_points(caller, forward_->moving_[forward_->res_], forward_->fixed_[forward_->res_], forward_->matches(), forward_->trans_, iteration);
     double weighted_error_after = forward_->weighted_error();
-    double curr_error_difference = weighted_error_after - weighted_error_before;
-    double diff = (weighted_error_after - weighted_error_before) / weighted_error_after;
-    bool converged = std::fabs(diff) < 1e-4;
-    weighted_error_ = weighted_error_after;
-    if (!RRL || iteration > 0) {  // the rrl class guards the oscillation logic with iteration > 0 (:387)
-      if (!finest_level_ && (oscillation_count_ > 1 || (std::fabs(diff) < 0.01))) converged = true;
-      else if (!converged) {
-        if (weighted_error_after > 1.5) {
-          if (curr_error_difference * error_difference_ < 0.0) ++oscillation_count_;
-          else if (oscillation_count_ > 0) --oscillation_count_;
-          if (oscillated()) converged = true;
-        } else {
-          if (curr_error_difference > 0.0) ++oscillation_count_;
-          if (oscillation_count_ > 3) converged = true;
-        }
-      }
-    }
-    error_difference_ = curr_error_difference;
-    if (converged && !finest_level_) {
-      converged = false;
-      number_matches_ *= 2;
-      bool forward_at_max = forward_->set_number_points(number_matches_);
-      bool backward_at_max = backward_->set_number_points(number_matches_);
-      finest_level_ = forward_at_max && backward_at_max;
-      oscillation_count_ = 0;
-      error_difference_ = 0.0;
-    }
-    return converged && finest_level_;
+    return sched_.step(weighted_error_before, weighted_error_after, iteration, RRL, [this](unsigned n) {
+      bool forward_at_max = forward_->set_number_points(n);
+      bool backward_at_max = backward_->set_number_points(n);
+      return forward_at_max && backward_at_max;
+    });
   }
 
   // (rrl sym .txx:699-918; cdcl sym .txx:398-701).  The per-match work of both lists is ONE fused,
@@ -713,20 +764,9 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     B.last_scale_ = r.sigma_b;
     F.touch();
     B.touch();
-    location_type cm(0.0), cf(0.0);
-    double rm = 0.0, rf = 0.0;
-    if (normalize_matches_) {
-      for (int d = 0; d < 3; ++d) { cm[d] = r.norm.cm[d]; cf[d] = r.norm.cf[d]; }
-      rm = r.norm.rm;
-      rf = r.norm.rf;
-      F.trans_->normalize(rm, rf, cm, cf);
-      B.trans_->normalize(rf, rm, cf, cm);  // flipped centres and radii
-    }
-    F.solve_and_set(F.trans_, r.AtA, r.Atb, estimate_parameters);
-    if (normalize_matches_) {
-      F.trans_->unnormalize(rm, rf, cm, cf);
-      B.trans_->unnormalize(rf, rm, cf, cm);
-    }
+    for (unsigned i = 0; i < dof * dof; ++i) F.last_AtA_[i] = r.AtA[i];
+    for (unsigned i = 0; i < dof; ++i) F.last_Atb_[i] = r.Atb[i];
+    symmetric_apply_solution<dof>(F.trans_, B.trans_, r, normalize_matches_, estimate_parameters);
     if (rigid) F.end_rigid_increment(forward_global);
     if (estimate_parameters) B.trans_ = F.trans_->inverse();
   }
@@ -750,7 +790,7 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
   void weight_by_strength(bool flag) { forward_->weight_by_strength(flag); backward_->weight_by_strength(flag); }
   virtual void normalize_matches() { forward_->normalize_matches(); backward_->normalize_matches(); normalize_matches_ = true; }
   double RMS_error() { return forward_->RMS_error(); }
-  bool oscillated() { return oscillation_count_ > 10; }
+  bool oscillated() { return sched_.oscillated(); }
   double weighted_error() { return forward_->weighted_error(); }
   void compute_transfer_error_covariance() { forward_->compute_transfer_error_covariance(); backward_->compute_transfer_error_covariance(); }
   double sheet_angles() { return forward_->sheet_angles(); }
@@ -764,11 +804,11 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
   void inject_initial_scale(double fwd, double bwd) { forward_->inject_initial_scale(fwd); backward_->inject_initial_scale(bwd); }
   void set_number_points(unsigned n) {
     bool a = forward_->set_number_points(n), b = backward_->set_number_points(n);
-    number_matches_ = n;
-    finest_level_ = a && b;
+    sched_.number_matches_ = n;
+    sched_.finest_level_ = a && b;
   }
   void set_nn_method(int m) { forward_->set_nn_method(m); backward_->set_nn_method(m); }
-  bool finest_level() const { return finest_level_; }
+  bool finest_level() const { return sched_.finest_level_; }
   estimation_type &forward() { return *forward_; }
   estimation_type &backward() { return *backward_; }
 
@@ -791,19 +831,11 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     if (D.injected_scale_ > 0.0) { injected = D.injected_scale_; return LRR_ICP_SCALE_INJECTED; }
     return LRR_ICP_SCALE_MUSE;
   }
-  void reset_schedule() {
-    oscillation_count_ = 0;
-    error_difference_ = 0.0;
-    number_matches_ = 1000;
-    finest_level_ = false;
-  }
+  void reset_schedule() { sched_.reset(); }
 
   vbl_smart_ptr<estimation_type> forward_, backward_;
   bool normalize_matches_;
-  unsigned int oscillation_count_;
-  double error_difference_, weighted_error_;
-  unsigned int number_matches_;
-  bool finest_level_;
+  symmetric_schedule sched_;
 };
 
 }  // namespace lrr_amd

@@ -1,0 +1,323 @@
+// location_batch.h — many query locations of itk::LocationRegistration per device submission.
+//
+// The reference registers its query locations one after the other (rrl/itkLocationRegistration.cxx:2134-2138):
+// per location SetupEstimation (:1525-1707: FeaturesInROIs, set_features, set_transform) and then
+// `while (!converged && iteration < 70) converged = estimation->one_iteration(0, 0, iteration)` (:2418),
+// followed by ComputeDecisionMeasurements (:1816-1871) on the converged estimator.  One location is a few
+// thousand matches: far too little for an MI355X.  rrl_location_batch keeps the two volumes resident and
+// advances B locations in lockstep; every device phase of an iteration is ONE submission for all of them
+// (C-ABI lrr_icp_batch_*).  The host part of an iteration is the same code the one-at-a-time class runs
+// (symmetric_schedule, symmetric_apply_solution of icp_engine.h), so per-location results — match sets,
+// iteration counts, transforms — equal those of rrl_estimation_symmetric_ICP_matching_all<3,12> driven by
+// the caller's loop (tests/test_gpu_batch.py).
+#ifndef LRR_AMD_LOCATION_BATCH_H_
+#define LRR_AMD_LOCATION_BATCH_H_
+
+#include <algorithm>
+#include <vector>
+
+#include "lrr_amd/icp_engine.h"
+
+namespace lrr_amd {
+
+// one query location: what SetupEstimation derives from the keypoint match (rrl/itkLocationRegistration.cxx:1525-1643)
+struct location_query {
+  cdcl_trans<3, 12>::sptr transform;                       // initial transform (moving -> fixed); not modified
+  vnl_vector_fixed<double, 3> moving_x0, moving_x1;        // ROI of the moving volume
+  vnl_vector_fixed<double, 3> fixed_x0, fixed_x1;          // ROI of the fixed volume
+  uint64_t seed;                                           // seed of the subset permutations of this location
+  location_query() : moving_x0(0.0), moving_x1(0.0), fixed_x0(0.0), fixed_x1(0.0), seed(1) {}
+};
+
+// what the caller reads from the estimation object after its loop (rrl/itkLocationRegistration.cxx:2418-2510, 1816-1871)
+struct location_result {
+  bool enough_features;        // both ROI lists >= min_features (:1632); false: nothing else is set
+  bool converged, oscillated, valid_transform;
+  unsigned iterations;
+  int64_t n_moving_inside, n_fixed_inside, matched_pairs;
+  cdcl_trans<3, 12>::sptr forward, backward;   // transforms at the end of the loop (with their covariances);
+                                               // backward carries the covariance of estimate_LS_backward(false)
+  double initial_RMS, RMS_error;               // RMS_error() after iteration 0 (:2426) and at the end
+  double weighted_error, weighted_error_backward;
+  double sheet_angles, tube_angles, sheet_angles_backward, tube_angles_backward;  // radians
+  double measurements[8];      // ComputeDecisionMeasurements (:1816-1871); NaN without diagnostics
+  location_result()
+      : enough_features(false), converged(false), oscillated(false), valid_transform(true), iterations(0), n_moving_inside(0),
+        n_fixed_inside(0), matched_pairs(0), initial_RMS(-1.0), RMS_error(0.0), weighted_error(0.0), weighted_error_backward(0.0),
+        sheet_angles(0.0), tube_angles(0.0), sheet_angles_backward(0.0), tube_angles_backward(0.0) {
+    for (int k = 0; k < 8; ++k) measurements[k] = std::nan("");
+  }
+};
+
+// validTransform (rrl/itkLocationRegistration.cxx:2914-2926): singular values of A within [0.1, 10]
+inline bool valid_transform(cdcl_trans<3, 12>::sptr const &T) {
+  double U[9], s[3], V[9];
+  linalg::svd3(T->get_A().data_block(), U, s, V);
+  for (int d = 0; d < 3; ++d) if (s[d] > 10.0 || s[d] < 0.1) return false;
+  return true;
+}
+
+// ComputeTransferErrorCovariance (rrl/itkLocationRegistration.cxx:2793-2858): J C J^T sampled every `interval`
+// mm over [start, end]; largest trace and largest eigenvalue over the samples
+inline void sampled_transfer_error(cdcl_trans<3, 12>::sptr const &T, vnl_vector_fixed<double, 3> const &start,
+                                   vnl_vector_fixed<double, 3> const &end, double interval,
+                                   vnl_matrix_fixed<double, 3, 3> &covarianceJ, double &maxTrace, double &maxEval) {
+  vnl_matrix_fixed<double, 12, 12> covariance = T->get_covariance();
+  covarianceJ.fill(0.0);
+  maxTrace = 0.0;
+  maxEval = 0.0;
+  unsigned count = 0;
+  for (double k = start[2]; k <= end[2]; k += interval)
+    for (double j = start[1]; j <= end[1]; j += interval)
+      for (double i = start[0]; i <= end[0]; i += interval) {
+        vnl_vector_fixed<double, 3> point;
+        point[0] = i; point[1] = j; point[2] = k;
+        vnl_matrix_fixed<double, 3, 12> Jth = T->jacobian_wrt_par(point);
+        vnl_matrix_fixed<double, 3, 3> cur = Jth * covariance * Jth.transpose();
+        covarianceJ += cur;
+        double tr = cur(0, 0) + cur(1, 1) + cur(2, 2);
+        if (tr > maxTrace) maxTrace = tr;
+        double U[9], s[3], V[9];
+        linalg::svd3(cur.data_block(), U, s, V);  // symmetric positive semi-definite: singular values = eigenvalues
+        double ev = std::max(s[0], std::max(s[1], s[2]));
+        if (ev > maxEval) maxEval = ev;
+        ++count;
+      }
+  if (count) covarianceJ *= (1.0 / double(count));
+}
+
+template <class FeatureT = cdcl_feature_ICP<3> >
+class rrl_location_batch {
+ public:
+  typedef typename FeatureT::sptr feature_sptr_type;
+  typedef cdcl_trans<3, 12>::sptr trans_sptr_type;
+  static const unsigned dof = 12;
+
+  // uploads the two full volumes once (m_FeaturesMovingAll[0], m_FeaturesFixedAll[0]); they stay resident
+  rrl_location_batch(vcl_vector<feature_sptr_type> const &moving_all, vcl_vector<feature_sptr_type> const &fixed_all)
+      : batch_(nullptr), max_iterations_(70), min_features_(1000), diagnostics_(true), check_valid_(true),
+        voxel_spacing_(1.0), sample_interval_(5.0) {
+    moving_.upload(moving_all);
+    fixed_.upload(fixed_all);
+    check(lrr_icp_batch_create(device::ctx(), moving_.handle(), fixed_.handle(), &batch_), "batch create");
+  }
+  ~rrl_location_batch() { if (batch_) lrr_icp_batch_destroy(batch_); }
+  rrl_location_batch(const rrl_location_batch &) = delete;
+  rrl_location_batch &operator=(const rrl_location_batch &) = delete;
+
+  void set_max_iterations(unsigned n) { max_iterations_ = n; }   // 70 (:2413)
+  void set_min_features(unsigned n) { min_features_ = n; }       // 1000 (:1632)
+  void set_diagnostics(bool on) { diagnostics_ = on; }
+  void set_check_valid_transform(bool on) { check_valid_ = on; } // `if (!validTransform(...)) break;` (:2482)
+  void set_sampling(double voxel_spacing, double interval) { voxel_spacing_ = voxel_spacing; sample_interval_ = interval; }
+  lrr_icp_batch *handle() const { return batch_; }
+
+  // registers every query; results[i] belongs to queries[i]
+  void run(std::vector<location_query> const &queries, std::vector<location_result> &results) {
+    const size_t B = queries.size();
+    results.assign(B, location_result());
+    if (B == 0) return;
+    std::vector<double> mbox(6 * B), fbox(6 * B);
+    for (size_t b = 0; b < B; ++b)
+      for (int d = 0; d < 3; ++d) {
+        mbox[6 * b + d] = queries[b].moving_x0[d]; mbox[6 * b + 3 + d] = queries[b].moving_x1[d];
+        fbox[6 * b + d] = queries[b].fixed_x0[d]; fbox[6 * b + 3 + d] = queries[b].fixed_x1[d];
+      }
+    std::vector<int64_t> nm(B), nf(B);
+    check(lrr_icp_batch_set_rois(batch_, (int64_t)B, mbox.data(), fbox.data(), nm.data(), nf.data()), "batch ROI selection");
+
+    std::vector<state> st(B);
+    std::vector<lrr_icp_batch_loc> loc(B);
+    size_t running = 0;
+    for (size_t b = 0; b < B; ++b) {
+      state &s = st[b];
+      location_result &r = results[b];
+      r.n_moving_inside = nm[b];
+      r.n_fixed_inside = nf[b];
+      r.enough_features = !(nm[b] < (int64_t)min_features_ || nf[b] < (int64_t)min_features_);
+      s.running = r.enough_features && nm[b] > 0 && nf[b] > 0;
+      std::memset(&loc[b], 0, sizeof loc[b]);
+      if (!s.running) continue;
+      ++running;
+      // SetupEstimation: set_features + set_transform (:1635-1637; rrl sym .txx:268-315)
+      s.F = queries[b].transform->clone();
+      s.B = s.F->inverse();
+      s.N[0] = (unsigned)nm[b]; s.N[1] = (unsigned)nf[b];
+      for (int d = 0; d < 2; ++d) { s.number_points[d] = std::min(1000u, s.N[d]); s.scale_estimated[d] = false; }
+      s.rng[0] = queries[b].seed;
+      s.rng[1] = queries[b].seed ^ 0xD1B54A32D192ED03ULL;
+      s.sched.reset();
+      s.error_after = 0.0;  // weighted_error() of a list without matches
+      s.iteration = 0;
+    }
+
+    lrr_icp_batch_opts opts;
+    opts.normalize = 1; opts.strength_f = 1; opts.strength_b = 1; opts.swapped = 0;
+    std::vector<lrr_icp_sym_out> est(B);
+    std::vector<double> sums(8 * B);
+    // the caller's loop, all locations in lockstep: one_iteration of every running location
+    // (rrl sym .txx:341-438)
+    while (running > 0) {
+      for (size_t b = 0; b < B; ++b) {
+        state &s = st[b];
+        loc[b].active = s.running ? 1 : 0;
+        if (!s.running) continue;
+        s.error_before = s.error_after;  // forward_->weighted_error() before the search: the value after the last estimate
+        lrr_icp_perm_keys(&s.rng[0], loc[b].keys_fwd);
+        lrr_icp_perm_keys(&s.rng[1], loc[b].keys_bwd);
+        fill_loc(loc[b], s);
+        results[b].matched_pairs += (int64_t)s.number_points[0] + s.number_points[1];
+      }
+      check(lrr_icp_batch_match(batch_, loc.data()), "batch find_closest_euclidean");
+      check(lrr_icp_batch_estimate(batch_, loc.data(), &opts, est.data()), "batch estimate");
+      for (size_t b = 0; b < B; ++b) {
+        state &s = st[b];
+        if (!s.running) continue;
+        s.scale_estimated[0] = s.scale_estimated[1] = true;
+        symmetric_apply_solution<dof>(s.F, s.B, est[b], true, true);
+        s.B = s.F->inverse();
+        fill_loc(loc[b], s);
+      }
+      check(lrr_icp_batch_errors(batch_, loc.data(), sums.data()), "batch error metrics");
+      for (size_t b = 0; b < B; ++b) {
+        state &s = st[b];
+        if (!s.running) continue;
+        const double *e = &sums[6 * b];
+        s.error_after = e[2] != 0 ? e[1] / e[2] : e[1];  // weighted_error (rrl .txx:247-276)
+        s.rms = e[0];                                     // the rrl class returns the raw sum (rrl .txx:216-238)
+        const bool converged = s.sched.step(s.error_before, s.error_after, s.iteration, true, [&s](unsigned n) {
+          bool a = grow(s, 0, n), c = grow(s, 1, n);
+          return a && c;
+        });
+        if (s.iteration == 0) results[b].initial_RMS = s.rms;
+        ++s.iteration;
+        bool stop = converged || s.iteration >= max_iterations_;
+        if (!stop && check_valid_ && !valid_transform(s.F)) { results[b].valid_transform = false; stop = true; }
+        if (stop) {
+          s.running = false;
+          --running;
+          location_result &r = results[b];
+          r.converged = converged;
+          r.oscillated = s.sched.oscillated();
+          r.iterations = s.iteration;
+          r.weighted_error = s.error_after;
+          r.RMS_error = s.rms;
+          r.forward = s.F->clone();
+        }
+      }
+    }
+    if (diagnostics_) decision_measurements(queries, st, loc, results, est, sums);
+    for (size_t b = 0; b < B; ++b)
+      if (results[b].enough_features && st[b].B) results[b].backward = st[b].B;
+  }
+
+ private:
+  struct state {
+    trans_sptr_type F, B;
+    unsigned N[2], number_points[2];
+    bool scale_estimated[2];
+    uint64_t rng[2];
+    symmetric_schedule sched;
+    double error_before, error_after, rms;
+    unsigned iteration;
+    bool running;
+    state() : error_before(0.0), error_after(0.0), rms(0.0), iteration(0), running(false) {
+      N[0] = N[1] = number_points[0] = number_points[1] = 0;
+      scale_estimated[0] = scale_estimated[1] = false;
+      rng[0] = rng[1] = 0;
+    }
+  };
+  // set_number_points (cdcl .txx:94-108)
+  static bool grow(state &s, int d, unsigned n) {
+    if (n >= s.N[d]) { s.number_points[d] = s.N[d]; return true; }
+    s.number_points[d] = n;
+    return false;
+  }
+  static lrr_icp_xform xform_of(trans_sptr_type const &T) {
+    lrr_icp_xform x;
+    vnl_matrix_fixed<double, 3, 3> &A = T->get_A();
+    vnl_vector_fixed<double, 3> &t = T->get_translation();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) x.A[3 * r + c] = A(r, c); x.t[r] = t[r]; x.c[r] = T->center_moving_[r]; }
+    return x;
+  }
+  static void fill_loc(lrr_icp_batch_loc &L, state const &s) {
+    L.xf_fwd = xform_of(s.F);
+    L.xf_bwd = xform_of(s.B);
+    L.n_fwd = s.number_points[0];
+    L.n_bwd = s.number_points[1];
+    // first estimate after set_transform: MUSE; afterwards the RMS under the previous weights (rrl .txx:620-641)
+    L.scale_mode_f = s.scale_estimated[0] ? LRR_ICP_SCALE_RMS : LRR_ICP_SCALE_MUSE;
+    L.scale_mode_b = s.scale_estimated[1] ? LRR_ICP_SCALE_RMS : LRR_ICP_SCALE_MUSE;
+    L.injected_f = L.injected_b = 0.0;
+    // the affine normalize() zeroes the centre before the accumulation (cdcl_trans_affine.txx:252)
+    L.jac_centre[0] = L.jac_centre[1] = L.jac_centre[2] = 0.0;
+  }
+
+  // ComputeDecisionMeasurements (:1816-1871) of every location that ran: forward angles and error, then
+  // estimate_LS_backward(false) (sets the backward covariance, re-weights both lists), then the backward ones
+  void decision_measurements(std::vector<location_query> const &queries, std::vector<state> &st, std::vector<lrr_icp_batch_loc> &loc,
+                             std::vector<location_result> &results, std::vector<lrr_icp_sym_out> &est, std::vector<double> &sums) {
+    const size_t B = st.size();
+    bool any = false;
+    for (size_t b = 0; b < B; ++b) {
+      loc[b].active = (results[b].enough_features && st[b].iteration > 0) ? 1 : 0;
+      if (loc[b].active) { any = true; fill_loc(loc[b], st[b]); }
+    }
+    if (!any) return;
+    const double deg = 180.0 / 3.14159265358979323846;
+    check(lrr_icp_batch_angles(batch_, loc.data(), sums.data()), "batch angles");
+    for (size_t b = 0; b < B; ++b)
+      if (loc[b].active) {
+        const double *a = &sums[8 * b];
+        results[b].sheet_angles = a[0] / a[1];
+        results[b].tube_angles = a[2] / a[3];
+      }
+    // estimate_LS_backward(false): the lists swap roles (rrl sym .txx:921-934); no new parameters
+    lrr_icp_batch_opts opts;
+    opts.normalize = 1; opts.strength_f = 1; opts.strength_b = 1; opts.swapped = 1;
+    for (size_t b = 0; b < B; ++b)
+      if (loc[b].active) { loc[b].scale_mode_f = loc[b].scale_mode_b = LRR_ICP_SCALE_RMS; }
+    check(lrr_icp_batch_estimate(batch_, loc.data(), &opts, est.data()), "batch backward estimate");
+    for (size_t b = 0; b < B; ++b)
+      if (loc[b].active) {
+        symmetric_apply_solution<dof>(st[b].B, st[b].F, est[b], true, false);
+        fill_loc(loc[b], st[b]);
+      }
+    check(lrr_icp_batch_angles(batch_, loc.data(), sums.data()), "batch angles");
+    std::vector<double> esums(6 * B);
+    check(lrr_icp_batch_errors(batch_, loc.data(), esums.data()), "batch error metrics");
+    for (size_t b = 0; b < B; ++b) {
+      if (!loc[b].active) continue;
+      location_result &r = results[b];
+      const double *a = &sums[8 * b + 4], *e = &esums[6 * b + 3];
+      r.sheet_angles_backward = a[0] / a[1];
+      r.tube_angles_backward = a[2] / a[3];
+      r.weighted_error_backward = e[2] != 0 ? e[1] / e[2] : e[1];
+      // transfer-error covariance sampled over the two ROIs (:1832-1841, 2793-2858); the forward one uses the
+      // transform as the loop left it
+      vnl_matrix_fixed<double, 3, 3> cj;
+      double maxTrace = 0, maxEval = 0, maxTraceB = 0, maxEvalB = 0;
+      vnl_vector_fixed<double, 3> sp(voxel_spacing_);
+      sampled_transfer_error(r.forward, queries[b].moving_x0, queries[b].moving_x1 - sp, sample_interval_, cj, maxTrace, maxEval);
+      sampled_transfer_error(st[b].B, queries[b].fixed_x0, queries[b].fixed_x1 - sp, sample_interval_, cj, maxTraceB, maxEvalB);
+      const double sa = r.sheet_angles * deg, ta = r.tube_angles * deg, sab = r.sheet_angles_backward * deg, tab = r.tube_angles_backward * deg;
+      r.measurements[0] = std::max(r.weighted_error, r.weighted_error_backward);
+      r.measurements[1] = std::max(maxTrace, maxTraceB);
+      r.measurements[2] = std::max(sa, sab);
+      r.measurements[3] = std::max(ta, tab);
+      r.measurements[4] = std::min(r.weighted_error, r.weighted_error_backward);
+      r.measurements[5] = std::min(maxTrace, maxTraceB);
+      r.measurements[6] = std::min(sa, sab);
+      r.measurements[7] = std::min(ta, tab);
+    }
+  }
+
+  device_cloud<FeatureT> moving_, fixed_;
+  lrr_icp_batch *batch_;
+  unsigned max_iterations_, min_features_;
+  bool diagnostics_, check_valid_;
+  double voxel_spacing_, sample_interval_;
+};
+
+}  // namespace lrr_amd
+#endif

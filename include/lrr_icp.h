@@ -212,6 +212,51 @@ int  lrr_icp_estimate_forward(lrr_icp_dir *dir, const lrr_icp_xform *xf, const l
 /* matches_ on demand (callbacks, sheet/tube angles): from/to indices into the clouds, weights */
 int  lrr_icp_get_matches(lrr_icp_dir *dir, int64_t *from_idx, int64_t *to_idx, double *w);
 
+/* ---- batched query locations (config 5) -------------------------------------------------------------
+ * The caller's outer loop over query locations (rrl/itkLocationRegistration.cxx:2134-2138) runs one
+ * rrl_estimation_symmetric_ICP_matching_all<3,12> per location on the features of two 50 mm boxes.  A
+ * batch keeps the two full volumes resident and runs EVERY phase of an iteration for B locations in one
+ * submission; a location is two index lists into the volumes, selected on the device.  Per-location
+ * results equal those of the one-at-a-time calls above (dof 12, rrl flavour: per-list weighting,
+ * pre-multiplied projector, skip w < 1e-4). */
+typedef struct lrr_icp_batch lrr_icp_batch;
+int  lrr_icp_batch_create(lrr_icp_ctx *ctx, lrr_icp_cloud *moving_all, lrr_icp_cloud *fixed_all, lrr_icp_batch **out);
+void lrr_icp_batch_destroy(lrr_icp_batch *batch);
+int64_t lrr_icp_batch_size(const lrr_icp_batch *batch);
+/* FeaturesInROIs (rrl/itkLocationRegistration.cxx:1324-1360) for B locations at once, on the device:
+ * box b = {x0[3], x1[3]}; a feature is inside when x0[d] <= p[d] <= x1[d] for every d; the ROI list keeps
+ * the volume's original order.  Also set_features: matches and schedule state of every location are
+ * reset.  n_*_inside[b]: list sizes (the caller's >= 1000 test, :1632). */
+int  lrr_icp_batch_set_rois(lrr_icp_batch *batch, int64_t B, const double *moving_box, const double *fixed_box,
+                            int64_t *n_moving_inside, int64_t *n_fixed_inside);
+int  lrr_icp_batch_get_roi(lrr_icp_batch *batch, int64_t b, int dir, int64_t *idx);
+typedef struct {
+  lrr_icp_xform xf_fwd, xf_bwd;      /* forward (moving -> fixed) and backward transforms of the location */
+  uint32_t keys_fwd[4], keys_bwd[4]; /* subset permutations (lrr_icp_perm_keys) */
+  int64_t n_fwd, n_bwd;              /* number_points_ of the two lists */
+  int active;                        /* 0: the location is skipped by the call */
+  int scale_mode_f, scale_mode_b;    /* LRR_ICP_SCALE_* of the forward-role and backward-role list */
+  double injected_f, injected_b;
+  double jac_centre[3];              /* as lrr_icp_sym_opts.jac_centre */
+} lrr_icp_batch_loc;
+typedef struct {
+  int normalize, strength_f, strength_b;
+  int swapped;                       /* estimate_LS_backward: the backward list plays the forward role
+                                        (rrl/rrl_estimation_symmetric_ICP_matching_all.txx:921-934) */
+} lrr_icp_batch_opts;
+/* find_closest_euclidean of both lists of every active location (rrl sym .txx:327-331) */
+int  lrr_icp_batch_match(lrr_icp_batch *batch, const lrr_icp_batch_loc *loc);
+/* the device part of estimate_LS of every active location (as lrr_icp_estimate_symmetric); out[b] */
+int  lrr_icp_batch_estimate(lrr_icp_batch *batch, const lrr_icp_batch_loc *loc, const lrr_icp_batch_opts *opts,
+                            lrr_icp_sym_out *out);
+/* K4 of both lists of every active location: sums[b][dir] = {sum r2, sum sqrt(r2) w, sum w} */
+int  lrr_icp_batch_errors(lrr_icp_batch *batch, const lrr_icp_batch_loc *loc, double *sums);
+/* sheet / tube angles of both lists: sums[b][dir] = {sheet sum w a, sheet sum w, tube sum w a, tube sum w} */
+int  lrr_icp_batch_angles(lrr_icp_batch *batch, const lrr_icp_batch_loc *loc, double *sums);
+int64_t lrr_icp_batch_num_matches(const lrr_icp_batch *batch, int64_t b, int dir);
+/* matches_ of location b: from = index in the ROI list, to = index in the full volume */
+int  lrr_icp_batch_get_matches(lrr_icp_batch *batch, int64_t b, int dir, int64_t *from_idx, int64_t *to_idx, double *w);
+
 /* stand-alone exact nearest neighbour of host query points (tests, diagnostics) */
 int  lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int method, int64_t *idx);
 

@@ -15,6 +15,7 @@
 #include "lrr_amd/cdcl_estimation_symmetric_ICP_matching_all.h"
 #include "lrr_amd/rrl_estimation_ICP_matching_all.h"
 #include "lrr_amd/rrl_estimation_symmetric_ICP_matching_all.h"
+#include "lrr_amd/location_batch.h"
 
 extern "C" {
 typedef struct {
@@ -346,5 +347,65 @@ int lrr_est_get_matches(lrr_est *e, int dir, int64_t *f, int64_t *t, double *w) 
 int64_t lrr_est_get_number_points(lrr_est *e, int dir) { int64_t n = 0; guard([&] { n = E(e)->number_points(dir); }); return n; }
 int lrr_est_last_scale(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->last_scale(dir); }); }
 int lrr_est_last_normal_equations(lrr_est *e, double *AtA, double *Atb) { return guard([&] { E(e)->normal_equations(AtA, Atb); }); }
+
+
+// ---- many query locations per submission (include/lrr_amd/location_batch.h) ---------------------------
+// one row of doubles per location:
+//   0 converged, 1 iterations, 2..10 A, 11..13 t, 14..16 centre, 17 weighted_error, 18 RMS_error, 19 (caller's index),
+//   20 enough_features, 21 oscillated, 22 valid_transform, 23 n_moving_inside, 24 n_fixed_inside, 25 matched_pairs,
+//   26 initial_RMS, 27 weighted_error_backward, 28 sheet_angles, 29 tube_angles, 30 sheet_angles_backward,
+//   31 tube_angles_backward, 32..39 the 8 decision measurements, 40..54 backward A, t, centre,
+//   55..198 forward covariance (12 x 12), 199..342 backward covariance
+enum { LRR_EST_BATCH_ROW = 343 };
+typedef struct lrr_est_batch lrr_est_batch;
+typedef lrr_amd::rrl_location_batch<cdcl_feature_ICP<3> > batch_type;
+#define BT(b) (reinterpret_cast<batch_type *>(b))
+
+int lrr_est_batch_row_width() { return LRR_EST_BATCH_ROW; }
+
+lrr_est_batch *lrr_est_batch_create(const lrr_est_features *moving, const lrr_est_features *fixed) {
+  batch_type *out = nullptr;
+  int rc = guard([&] {
+    if (!moving || !fixed) throw std::runtime_error("lrr_est_batch_create: null argument");
+    out = new batch_type(make_features<cdcl_feature_ICP<3> >(moving), make_features<cdcl_feature_ICP<3> >(fixed));
+  });
+  return rc ? nullptr : reinterpret_cast<lrr_est_batch *>(out);
+}
+void lrr_est_batch_destroy(lrr_est_batch *b) { delete BT(b); }
+lrr_icp_batch *lrr_est_batch_handle(lrr_est_batch *b) { return BT(b)->handle(); }
+
+int lrr_est_batch_run(lrr_est_batch *bt, int64_t B, const double *A0, const double *t0, const double *c0, const double *moving_box,
+                      const double *fixed_box, const uint64_t *seeds, unsigned max_iterations, int diagnostics, int check_valid,
+                      double *rows) {
+  return guard([&] {
+    std::vector<lrr_amd::location_query> q((size_t)B);
+    for (int64_t b = 0; b < B; ++b) {
+      q[(size_t)b].transform = trans_factory<12>::make(A0 + 9 * b, t0 + 3 * b, c0 + 3 * b);
+      for (int d = 0; d < 3; ++d) {
+        q[(size_t)b].moving_x0[d] = moving_box[6 * b + d]; q[(size_t)b].moving_x1[d] = moving_box[6 * b + 3 + d];
+        q[(size_t)b].fixed_x0[d] = fixed_box[6 * b + d]; q[(size_t)b].fixed_x1[d] = fixed_box[6 * b + 3 + d];
+      }
+      q[(size_t)b].seed = seeds[b];
+    }
+    BT(bt)->set_max_iterations(max_iterations);
+    BT(bt)->set_diagnostics(diagnostics != 0);
+    BT(bt)->set_check_valid_transform(check_valid != 0);
+    std::vector<lrr_amd::location_result> res;
+    BT(bt)->run(q, res);
+    for (int64_t b = 0; b < B; ++b) {
+      double *r = rows + (size_t)b * LRR_EST_BATCH_ROW;
+      const lrr_amd::location_result &R = res[(size_t)b];
+      for (int k = 0; k < LRR_EST_BATCH_ROW; ++k) r[k] = 0.0;
+      r[0] = R.converged; r[1] = R.iterations; r[17] = R.weighted_error; r[18] = R.RMS_error; r[19] = (double)b;
+      r[20] = R.enough_features; r[21] = R.oscillated; r[22] = R.valid_transform;
+      r[23] = (double)R.n_moving_inside; r[24] = (double)R.n_fixed_inside; r[25] = (double)R.matched_pairs;
+      r[26] = R.initial_RMS; r[27] = R.weighted_error_backward;
+      r[28] = R.sheet_angles; r[29] = R.tube_angles; r[30] = R.sheet_angles_backward; r[31] = R.tube_angles_backward;
+      for (int k = 0; k < 8; ++k) r[32 + k] = R.measurements[k];
+      if (R.forward) read_trans<12>(R.forward, r + 2, r + 11, r + 14, r + 55);
+      if (R.backward) read_trans<12>(R.backward, r + 40, r + 49, r + 52, r + 199);
+    }
+  });
+}
 
 }  // extern "C"

@@ -160,6 +160,7 @@ struct lrr_icp_cloud {
   float4 *gpf = nullptr;        // n, raster order like gp: (x, y, z) in cell units relative to the grid origin as floats + canonical index bits:
                                 // the single-precision pre-filter of the ball search
   GridPoint *cpt = nullptr;     // n, canonical order: location + indices of target `canon` in one 32-B read (previous-match bound)
+  double *loc_orig = nullptr;   // n x 3, ORIGINAL order: the box test of the device-side ROI selection streams it (FeaturesInROIs walks the features in this order)
   int *cell_start = nullptr;    // ncell + 1
   int *fine_start = nullptr;    // ncell * fine + 1: every cell cut into `fine` slices along x (ball search)
   int fine = 1;
@@ -207,6 +208,17 @@ int fail(lrr_icp_ctx *ctx, int code, const std::string &msg) {
 struct XfD { double A[9], t[3], c[3]; };
 struct NormD { double cm[3], rm, cf[3], rf; };
 struct Keys { unsigned k[4]; };
+// per-location parameters of a batch of query locations, refreshed by the host before every phase
+struct BLoc {
+  XfD xf[2];        // [0] forward transform (moving -> fixed), [1] backward
+  Keys keys[2];     // subset permutations of the two lists
+  int n_points[2];  // active subset sizes
+  int active;       // 0: the location takes no part in this submission
+  int mode[2];      // LRR_ICP_SCALE_RMS / LRR_ICP_SCALE_INJECTED per role (F-list, B-list)
+  int pad_;
+  double inj[2];
+  double jac[3];    // center_moving_ of the forward transform as the accumulation sees it
+};
 
 struct GridView {
   const GridPoint *gp;   // points sorted by grid cell
@@ -433,10 +445,23 @@ struct QSrc {
   const SrcPoint *src;
   const double *raw;   // xyz triples when src == nullptr
   int want_orig;
+  // batched query locations: entry s of the batch segment is feature pidx[s] of the parent cloud and is
+  // mapped by the transform of its own location (bloc[loc_of[s]].xf[dir])
+  const int *pidx;
+  const BLoc *bloc;
+  const int *loc_of;
+  int dir;
 };
 __device__ __forceinline__ void query_point(const QSrc &q, int s, double &x, double &y, double &z) {
-  if (q.src) { SrcPoint p = q.src[s]; x = p.x; y = p.y; z = p.z; }
+  if (q.src) { SrcPoint p = q.src[q.pidx ? q.pidx[s] : s]; x = p.x; y = p.y; z = p.z; }
   else { x = q.raw[3 * (size_t)s]; y = q.raw[3 * (size_t)s + 1]; z = q.raw[3 * (size_t)s + 2]; }
+}
+// the query point mapped by the launch's transform, or by its own location's in a batch
+__device__ __forceinline__ void mapped_query(const QSrc &q, const XfD &xf, int s, double &yx, double &yy, double &yz) {
+  double x, y, z;
+  query_point(q, s, x, y, z);
+  if (q.bloc) map_loc(q.bloc[q.loc_of[s]].xf[q.dir], x, y, z, yx, yy, yz);
+  else map_loc(xf, x, y, z, yx, yy, yz);
 }
 __device__ __forceinline__ int result_index(const QSrc &q, const Best &b) {
   if (b.orig == 0x7fffffff) return 0;  // only reachable with non-finite input
@@ -998,9 +1023,8 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
   const int cnt = *A.hard_count;
   for (int o = wave; o < cnt; o += nwaves) {
     int s = hard[o];
-    double x, y_, z_, yx, yy, yz;
-    query_point(q, s, x, y_, z_);
-    map_loc(xf, x, y_, z_, yx, yy, yz);
+    double yx, yy, yz;
+    mapped_query(q, xf, s, yx, yy, yz);
     int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
     int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
     int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
@@ -1101,9 +1125,8 @@ __device__ __forceinline__ void match_overflow_body(const OverArgs &A) {
   int cnt = *A.overflow_count;
   for (int o = blockIdx.x; o < cnt; o += gridDim.x) {
     int s = overflow[o];
-    double x, y_, z_, yx, yy, yz;
-    query_point(q, s, x, y_, z_);
-    map_loc(xf, x, y_, z_, yx, yy, yz);
+    double yx, yy, yz;
+    mapped_query(q, xf, s, yx, yy, yz);
     Best b;
     b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
     for (int j = threadIdx.x; j < g.n; j += kBlock) {
@@ -2935,6 +2958,7 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
       {(void **)&c->cpt, cpt.data(), sizeof(GridPoint) * m, 0},
       {(void **)&c->gpf, gpf.data(), sizeof(float4) * m, 0},
       {(void **)&c->str, strv.data(), sizeof(double) * m, 0},
+      {(void **)&c->loc_orig, loc, sizeof(double) * 3 * (size_t)n, 0},
       {(void **)&c->shp, nullptr, sizeof(ShapeRec) * m, 0},
       {(void **)&c->orig_of, orig_of.data(), sizeof(int) * m, 0},
       {(void **)&c->canon_of, canon_of.data(), sizeof(int) * m, 0},
@@ -3097,7 +3121,7 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   }
   P.method = method == LRR_ICP_NN_AUTO ? LRR_ICP_NN_GRID : method;
   P.g = view_of(d->to);
-  P.q.src = d->from->src; P.q.raw = nullptr; P.q.want_orig = 0;
+  P.q.src = d->from->src; P.q.raw = nullptr; P.q.want_orig = 0; P.q.pidx = nullptr; P.q.bloc = nullptr; P.q.loc_of = nullptr; P.q.dir = 0;
   P.x = to_dev(xf);
   P.dense = !order && n_points * 4 >= N;  // fine levels: every source feature is looked at
   if ((rc = fresh_counts(ctx, L, st, &P.counts))) return rc;
@@ -3767,7 +3791,7 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
   if (!rc) {
     GridView g = view_of(cloud);
     QSrc q;
-    q.src = nullptr; q.raw = dq; q.want_orig = 1;
+    q.src = nullptr; q.raw = dq; q.want_orig = 1; q.pidx = nullptr; q.bloc = nullptr; q.loc_of = nullptr; q.dir = 0;
     Keys kk;
     std::memset(&kk, 0, sizeof kk);
     XfD x = identity_xf();
@@ -3789,3 +3813,5 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
 }
 
 }  // extern "C"
+
+#include "lrr_icp_batch.inc"

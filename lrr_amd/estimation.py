@@ -34,6 +34,9 @@ ICP_SYMBOLS = [
     "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_angles", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
     "lrr_icp_nearest",
+    "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
+    "lrr_icp_batch_match", "lrr_icp_batch_estimate", "lrr_icp_batch_errors", "lrr_icp_batch_angles",
+    "lrr_icp_batch_num_matches", "lrr_icp_batch_get_matches",
 ]
 
 
@@ -78,6 +81,10 @@ def hip_lib() -> C.CDLL:
         L.lrr_icp_subset_perm.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_uint32)]
         L.lrr_icp_subset_perm.restype = C.c_int64
         L.lrr_icp_nearest.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int, _ip]
+        L.lrr_icp_batch_num_matches.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        L.lrr_icp_batch_num_matches.restype = C.c_int64
+        L.lrr_icp_batch_get_matches.argtypes = [C.c_void_p, C.c_int64, C.c_int, _ip, _ip, _dp]
+        L.lrr_icp_batch_get_roi.argtypes = [C.c_void_p, C.c_int64, C.c_int, _ip]
         _hip = L
     return _hip
 
@@ -127,6 +134,13 @@ def est_lib() -> C.CDLL:
         L.lrr_est_get_number_points.argtypes = [C.c_void_p, C.c_int]
         L.lrr_est_get_number_points.restype = C.c_int64
         L.lrr_est_last_normal_equations.argtypes = [C.c_void_p, _dp, _dp]
+        L.lrr_est_batch_create.restype = C.c_void_p
+        L.lrr_est_batch_create.argtypes = [C.POINTER(_Features), C.POINTER(_Features)]
+        L.lrr_est_batch_destroy.argtypes = [C.c_void_p]
+        L.lrr_est_batch_handle.restype = C.c_void_p
+        L.lrr_est_batch_handle.argtypes = [C.c_void_p]
+        L.lrr_est_batch_run.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_uint64), C.c_uint,
+                                        C.c_int, C.c_int, _dp]
         _est = L
     return _est
 
@@ -368,3 +382,65 @@ class Estimator:
         AtA, Atb = np.empty((self.dof, self.dof)), np.empty(self.dof)
         self._ck(est_lib().lrr_est_last_normal_equations(self._h, _d(AtA), _d(Atb)))
         return AtA, Atb
+
+
+class LocationBatch:
+    """include/lrr_amd/location_batch.h: the two volumes resident on the device, many query locations
+    (ROI boxes + initial transforms) registered per call, every device phase one submission for all."""
+
+    # row layout of lrr_est_batch_run (lrr_est_capi.cpp)
+    COL = dict(converged=0, iterations=1, A=slice(2, 11), t=slice(11, 14), c=slice(14, 17), weighted_error=17, rms=18, index=19,
+               enough_features=20, oscillated=21, valid=22, n_moving_inside=23, n_fixed_inside=24, matched_pairs=25,
+               initial_rms=26, weighted_error_backward=27, sheet_angles=28, tube_angles=29, sheet_angles_backward=30,
+               tube_angles_backward=31, measurements=slice(32, 40), backward=slice(40, 55), covariance=slice(55, 199),
+               covariance_backward=slice(199, 343))
+
+    def __init__(self, moving, fixed):
+        L = est_lib()
+        keep = []
+        fm, ff = _features(moving, keep), _features(fixed, keep)
+        self._h = L.lrr_est_batch_create(C.byref(fm), C.byref(ff))
+        if not self._h:
+            raise RuntimeError("lrr_est_batch_create: " + L.lrr_est_last_error().decode())
+        self.width = L.lrr_est_batch_row_width()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            est_lib().lrr_est_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def run(self, A0, t0, c0, moving_box, fixed_box, seeds, max_iterations=70, diagnostics=True, check_valid=False):
+        """A0 (B,3,3), t0 (B,3), c0 (B,3): initial transforms; *_box (B,6): x0, x1 of the ROIs; seeds (B,).
+        Returns one row of `width` doubles per location (COL)."""
+        A0 = np.ascontiguousarray(A0, dtype=np.float64).reshape(-1, 9)
+        B = A0.shape[0]
+        t0 = np.ascontiguousarray(t0, dtype=np.float64).reshape(B, 3)
+        c0 = np.ascontiguousarray(c0, dtype=np.float64).reshape(B, 3)
+        mb = np.ascontiguousarray(moving_box, dtype=np.float64).reshape(B, 6)
+        fb = np.ascontiguousarray(fixed_box, dtype=np.float64).reshape(B, 6)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(B)
+        rows = np.zeros((B, self.width))
+        if est_lib().lrr_est_batch_run(self._h, B, _d(A0), _d(t0), _d(c0), _d(mb), _d(fb),
+                                       sd.ctypes.data_as(C.POINTER(C.c_uint64)), int(max_iterations), int(diagnostics),
+                                       int(check_valid), _d(rows)) != 0:
+            raise RuntimeError(est_lib().lrr_est_last_error().decode())
+        return rows
+
+    def matches(self, b, direction=0):
+        """matches_ of location b after run(): from = index in the ROI list, to = index in the full volume"""
+        L, h = hip_lib(), est_lib().lrr_est_batch_handle(self._h)
+        n = L.lrr_icp_batch_num_matches(h, b, direction)
+        f, t = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        w = np.empty(n, dtype=np.float64)
+        if L.lrr_icp_batch_get_matches(h, b, direction, f.ctypes.data_as(_ip), t.ctypes.data_as(_ip), _d(w)) != 0:
+            raise RuntimeError("lrr_icp_batch_get_matches failed")
+        return f, t, w
+
+    def roi(self, b, direction, n):
+        L, h = hip_lib(), est_lib().lrr_est_batch_handle(self._h)
+        idx = np.empty(n, dtype=np.int64)
+        if L.lrr_icp_batch_get_roi(h, b, direction, idx.ctypes.data_as(_ip)) != 0:
+            raise RuntimeError("lrr_icp_batch_get_roi failed")
+        return idx

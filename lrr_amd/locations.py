@@ -1,11 +1,18 @@
 """Config 5: many independent query locations against one volume pair, sharded over GPUs.
 
 Mirrors the outer loop of ``rrl/itkLocationRegistration.cxx:2134-2138`` for the estimation part
-only: for every query location the features inside the 50 mm ROIs become the active sets of ONE
-re-used ``rrl_estimation_symmetric_ICP_matching_all<3,12>`` object (``set_features`` +
-``set_transform``, ``itkLocationRegistration.cxx:1635-1637``), which is iterated until it reports
-convergence or 70 iterations (``:2418``).  Ranks take static blocks of the locations
-(``multi_gpu.shard``) and one all_gather returns every location's result to every rank.
+only: for every query location the features inside the 50 mm ROIs become the active sets of a
+``rrl_estimation_symmetric_ICP_matching_all<3,12>`` estimate (``set_features`` + ``set_transform``,
+``itkLocationRegistration.cxx:1635-1637``), iterated until it reports convergence or 70 iterations
+(``:2418``), followed by the caller's decision measurements (``:1816-1871``).  Ranks take static
+blocks of the locations (``multi_gpu.shard``) and one all_gather returns every location's result
+row to every rank.
+
+``register_locations`` runs a rank's block through the batched engine
+(``include/lrr_amd/location_batch.h``: both volumes resident, ROI selection on the device, every
+device phase of an iteration one submission for all locations of the block);
+``register_locations_sequential`` is the one-estimator-object-at-a-time form the reference's caller
+has, kept as the comparison the tests and the bench quote.
 """
 from __future__ import annotations
 
@@ -19,6 +26,46 @@ MAX_ITERATIONS = 70  # rrl/itkLocationRegistration.cxx:2413-2418
 
 def location_seed(seed: int, index: int) -> int:
     return (int(seed) * 1000003 + int(index) * 7919 + 1) & 0xFFFFFFFFFFFFFFFF
+
+
+def roi_boxes(rois, half=25.0):
+    """(B, 6) boxes [x0, x1] of the moving and the fixed ROI of every query (synth.query_rois): the cube of
+    half-width `half` around the query centre (rrl/itkLocationRegistration.cxx:1531-1549)"""
+    cf = np.array([r[0] for r in rois], dtype=np.float64).reshape(-1, 3)
+    cm = np.array([r[1] for r in rois], dtype=np.float64).reshape(-1, 3)
+    return np.concatenate([cm - half, cm + half], axis=1), np.concatenate([cf - half, cf + half], axis=1)
+
+
+def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1, seed: int = 7,
+                       gather_device=None, half: float = 25.0, batch=None, diagnostics=True, max_batch: int = 1024):
+    """Batched form.  rois: synth.query_rois output (only the centres are used: the ROI lists are selected
+    on the device); inits: the initial transform of every location; batch: an estimation.LocationBatch
+    that already holds the two volumes (kept by the caller across calls), else one is built and closed.
+    Returns (rows of LocationBatch.width doubles for ALL locations, ordered by location index, matched
+    pairs processed by this rank)."""
+    mine = list(multi_gpu.shard(len(rois), rank, world))
+    own = batch is None
+    if own:
+        batch = E.LocationBatch(pair.moving, pair.fixed)
+    width = batch.width
+    mbox, fbox = roi_boxes(rois, half)
+    rows = []
+    for k0 in range(0, len(mine), max_batch):
+        idx = np.array(mine[k0:k0 + max_batch], dtype=np.int64)
+        A0 = np.stack([inits[i].A for i in idx]); t0 = np.stack([inits[i].t for i in idx]); c0 = np.stack([inits[i].c for i in idx])
+        # the subset permutations of a location depend only on (seed, location): results do not depend on
+        # which rank or batch handles it
+        seeds = np.array([location_seed(seed, int(i)) for i in idx], dtype=np.uint64)
+        r = batch.run(A0, t0, c0, mbox[idx], fbox[idx], seeds, max_iterations=MAX_ITERATIONS, diagnostics=diagnostics)
+        r[:, 19] = idx
+        rows.append(r)
+    if own:
+        batch.close()
+    local = np.concatenate(rows) if rows else np.zeros((0, width))
+    pairs = int(local[:, E.LocationBatch.COL["matched_pairs"]].sum()) if local.shape[0] else 0
+    if world == 1:  # also a single-rank call made inside a multi-rank job (bench warm-up): no collective
+        return local, pairs
+    return multi_gpu.gather_results(local, len(rois), device=gather_device), pairs
 
 
 def _run_block(pair, rois, inits, indices, seed, est=None, diagnostics=True):
@@ -56,10 +103,11 @@ def _run_block(pair, rois, inits, indices, seed, est=None, diagnostics=True):
     return rows, pairs, est
 
 
-def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1,
-                       seed: int = 7, gather_device=None, workers: int = 1, device_index=None,
-                       estimators=None, diagnostics=True):
-    """rois: list of (centre_fixed, centre_moving, moving_idx, fixed_idx) (synth.query_rois);
+def register_locations_sequential(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1,
+                                  seed: int = 7, gather_device=None, workers: int = 1, device_index=None,
+                                  estimators=None, diagnostics=True):
+    """One estimator object re-used over the locations, as the reference's caller does.
+    rois: list of (centre_fixed, centre_moving, moving_idx, fixed_idx) (synth.query_rois);
     inits: list of synth.Transform, the initial transform of every location.
     workers > 1: the rank's block is dealt round-robin to that many host threads, each with its own
     device context and estimator.  Every location is estimated by exactly one estimator started from

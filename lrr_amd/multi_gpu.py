@@ -4,8 +4,9 @@ The path shards at the granularity of query locations (the outer loop of
 ``rrl/itkLocationRegistration.cxx:2134-2138``): every location is a self-contained symmetric
 ICP estimate against the same two volumes.  Each rank (one process per GPU) takes a static
 block of the locations, runs them with no inter-GPU traffic, and ONE collective at the end
-gathers the results (converged flag, iteration count, 12 parameters + centre, final errors:
-~0.2 KB per location, latency-bound on xGMI).  ``torch.distributed`` is plumbing: backend
+gathers the results (one row per location: converged flag, iteration count, 12 parameters + centre,
+12 x 12 covariances of both directions, final errors, angles and the verifier's 8 decision
+measurements: 2.7 KB per location, 0.7 MB for 256 locations — latency-bound on xGMI).  ``torch.distributed`` is plumbing: backend
 "nccl" is RCCL on ROCm, "gloo" on CPU for the tests.
 """
 from __future__ import annotations
@@ -14,7 +15,7 @@ from typing import Callable, List, Sequence
 
 import numpy as np
 
-RESULT_WIDTH = 20  # converged, iterations, A(9), t(3), c(3), weighted_error, rms, location index
+RESULT_WIDTH = 20  # converged, iterations, A(9), t(3), c(3), weighted_error, rms, location index: the leading columns of every row layout
 
 
 def shard(n_items: int, rank: int, world: int) -> range:
@@ -49,7 +50,8 @@ def gather_results(local: np.ndarray, n_locations: int, device=None) -> np.ndarr
         return local
     world = dist.get_world_size()
     cap = (n_locations + world - 1) // world
-    buf = torch.full((cap, RESULT_WIDTH), float("nan"), dtype=torch.float64, device=device)
+    width = local.shape[1]  # every rank packs the same row layout; column 19 is the location index
+    buf = torch.full((cap, width), float("nan"), dtype=torch.float64, device=device)
     if local.shape[0]:
         buf[: local.shape[0]] = torch.from_numpy(local).to(buf.device)
     out = [torch.empty_like(buf) for _ in range(world)]

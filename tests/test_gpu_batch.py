@@ -1,0 +1,184 @@
+"""GPU tests of the batched query-location engine (lrr_icp_batch_*, include/lrr_amd/location_batch.h):
+B locations advanced in lockstep, every device phase one submission.  Per location the results must equal
+those of the one-at-a-time class (rrl_estimation_symmetric_ICP_matching_all<3,12> driven by the caller's
+loop, rrl/itkLocationRegistration.cxx:2418) — match sets and iteration counts exactly, floating point to
+summation-order rounding — and, through it, the CPU oracle's."""
+import numpy as np
+import pytest
+
+from lrr_amd import synth
+from tests.common import rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from lrr_amd import estimation
+    estimation.hip_lib()
+    estimation.set_device(0)
+    return estimation
+
+
+@pytest.fixture(scope="module")
+def ob():
+    from oracle import binding
+    binding.build()
+    return binding
+
+
+def _setup(n, nloc, seed, half):
+    from lrr_amd import locations
+    pair = synth.make_pair(n, n, seed, kind="affine")
+    rois = synth.query_rois(pair, nloc, seed, half=half)
+    inits = [synth.perturbed(pair.planted, 100 + i) for i in range(len(rois))]
+    mbox, fbox = locations.roi_boxes(rois, half)
+    seeds = np.array([locations.location_seed(19, i) for i in range(len(rois))], dtype=np.uint64)
+    return pair, rois, inits, mbox, fbox, seeds
+
+
+def test_device_roi_selection_equals_numpy(E):
+    """FeaturesInROIs on the device: every location's two ROI lists equal numpy's box test, in the
+    volume's original order; boxes that hold nothing, everything, and features exactly on a face"""
+    pair, rois, inits, mbox, fbox, seeds = _setup(30000, 5, 20250, 40.0)
+    # extra boxes: empty, whole volume, a face through a feature (inclusive on both ends)
+    p = pair.moving.loc[123]
+    extra_m = np.array([[-10, -10, -10, -5, -5, -5], [-1e9, -1e9, -1e9, 1e9, 1e9, 1e9], [p[0], p[1] - 30, p[2] - 30, p[0] + 30, p[1], p[2] + 30]])
+    q = pair.fixed.loc[77]
+    extra_f = np.array([[400, 400, 400, 500, 500, 500], [-1e9, -1e9, -1e9, 1e9, 1e9, 1e9], [q[0] - 30, q[1], q[2] - 30, q[0], q[1] + 30, q[2] + 30]])
+    mbox, fbox = np.concatenate([mbox, extra_m]), np.concatenate([fbox, extra_f])
+    B = mbox.shape[0]
+    bt = E.LocationBatch(pair.moving, pair.fixed)
+    A0 = np.stack([pair.planted.A] * B); t0 = np.stack([pair.planted.t] * B); c0 = np.stack([pair.planted.c] * B)
+    rows = bt.run(A0, t0, c0, mbox, fbox, np.arange(B, dtype=np.uint64) + 1, max_iterations=1, diagnostics=False)
+    C = bt.COL
+    for b in range(B):
+        want_m = pair.moving.in_box(mbox[b, :3], mbox[b, 3:])
+        want_f = pair.fixed.in_box(fbox[b, :3], fbox[b, 3:])
+        assert int(rows[b, C["n_moving_inside"]]) == want_m.size and int(rows[b, C["n_fixed_inside"]]) == want_f.size, b
+        assert np.array_equal(bt.roi(b, 0, want_m.size), want_m), b
+        assert np.array_equal(bt.roi(b, 1, want_f.size), want_f), b
+        assert bool(rows[b, C["enough_features"]]) == (want_m.size >= 1000 and want_f.size >= 1000)
+    assert 123 in bt.roi(B - 1, 0, int(rows[B - 1, C["n_moving_inside"]]))  # the feature on the face is inside
+    assert int(rows[B - 3, C["iterations"]]) == 0 and not rows[B - 3, C["enough_features"]]  # the empty location never ran
+    bt.close()
+
+
+def test_batch_equals_one_at_a_time_and_oracle(E, ob):
+    """config 5 in miniature: 6 locations x 40k-feature volumes.  Batch rows against the sequential class
+    path per location (exact flags / iteration counts / final match sets, transforms to rounding), and the
+    sequential path's oracle twin for two of them."""
+    from lrr_amd import locations
+    pair, rois, inits, mbox, fbox, seeds = _setup(40000, 6, 20247, 50.0)
+    B = len(rois)
+    assert B == 6
+    bt = E.LocationBatch(pair.moving, pair.fixed)
+    A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
+    rows = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=locations.MAX_ITERATIONS, diagnostics=False)
+    C = bt.COL
+    for b, (_, _, mi, fi) in enumerate(rois):
+        m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[b]
+        g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in,
+                        seed=int(seeds[b]))
+        conv, its, npairs = g.run_counted(locations.MAX_ITERATIONS)
+        assert bool(rows[b, C["converged"]]) == conv and int(rows[b, C["iterations"]]) == its, b
+        assert int(rows[b, C["matched_pairs"]]) == npairs
+        A, t, c, cov = g.get_transform()
+        assert rel(rows[b, C["A"]].reshape(3, 3), A) < 1e-9 and rel(rows[b, C["t"]], t) < 1e-9, b
+        assert np.allclose(rows[b, C["c"]], c, rtol=1e-12, atol=1e-9)
+        assert rel(rows[b, C["covariance"]].reshape(12, 12), cov) < 1e-6
+        assert abs(rows[b, C["weighted_error"]] - g.weighted_error()) <= 1e-9 * max(1.0, g.weighted_error())
+        assert abs(rows[b, C["rms"]] - g.RMS_error()) <= 1e-9 * max(1.0, g.RMS_error())
+        for d in (0, 1):
+            fb, tb, wb = bt.matches(b, d)
+            fg, tg, wg = g.matches(d)
+            assert np.array_equal(fb, fg) and np.array_equal(tb, tg), (b, d)
+            assert np.allclose(wb, wg, rtol=1e-8, atol=1e-12 * np.abs(wg).max()), (b, d)
+        g.close()
+        if b < 2:
+            o = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in,
+                                   fixed_inside=f_in, seed=int(seeds[b]))
+            oconv, oits = o.run(locations.MAX_ITERATIONS)
+            assert bool(rows[b, C["converged"]]) == oconv and int(rows[b, C["iterations"]]) == oits
+            Ao, to, _, _ = o.get_transform()
+            assert rel(rows[b, C["A"]].reshape(3, 3), Ao) < 1e-6 and rel(rows[b, C["t"]], to) < 1e-6
+            for d in (0, 1):
+                assert np.array_equal(bt.matches(b, d)[1], o.matches(d)[1]), (b, d)
+    # a second run on the same object (other order of the locations, fewer of them): rows move with their location
+    perm = np.array([4, 0, 2])
+    rows2 = bt.run(A0[perm], t0[perm], c0[perm], mbox[perm], fbox[perm], seeds[perm], max_iterations=locations.MAX_ITERATIONS,
+                   diagnostics=False)
+    skip = C["index"]
+    for k, b in enumerate(perm):
+        a, r = np.delete(rows2[k], skip), np.delete(rows[b], skip)
+        assert np.array_equal(a, r, equal_nan=True), (k, b)  # bit-equal: the batch composition does not change a location's arithmetic
+    bt.close()
+
+
+def test_batch_decision_measurements(E, ob):
+    """the post-convergence calls of the caller's verifier (rrl/itkLocationRegistration.cxx:1816-1871):
+    forward angles / error, estimate_LS_backward(false), backward angles / error / covariance — batch
+    against the one-at-a-time class and the oracle"""
+    from lrr_amd import locations
+    pair, rois, inits, mbox, fbox, seeds = _setup(40000, 3, 20248, 50.0)
+    bt = E.LocationBatch(pair.moving, pair.fixed)
+    A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
+    rows = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=locations.MAX_ITERATIONS, diagnostics=True)
+    C = bt.COL
+    for b, (_, _, mi, fi) in enumerate(rois):
+        m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[b]
+        for factory in (E.Estimator, ob.OracleEstimator):
+            kind = E.RRL_SYMMETRIC if factory is E.Estimator else ob.RRL_SYMMETRIC
+            g = factory(kind, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in, seed=int(seeds[b]))
+            g.run(locations.MAX_ITERATIONS) if factory is ob.OracleEstimator else g.run_counted(locations.MAX_ITERATIONS)
+            sa, ta, we = g.sheet_angles(0), g.tube_angles(0), g.weighted_error(0)
+            g.estimate_LS_backward(False)
+            sab, tab, web = g.sheet_angles(1), g.tube_angles(1), g.weighted_error(1)
+            Ab, tb, cb, covb = g.get_transform(1)
+            tol = 1e-8
+            for name, v in (("sheet_angles", sa), ("tube_angles", ta), ("weighted_error", we), ("sheet_angles_backward", sab),
+                            ("tube_angles_backward", tab), ("weighted_error_backward", web)):
+                assert abs(rows[b, C[name]] - v) <= tol * max(1.0, abs(v)), (b, name)
+            bw = rows[b, C["backward"]]
+            # same map (the backward estimate re-centres the transform: compare what it does to points)
+            x = pair.fixed.loc[:50]
+            Tb = synth.Transform(bw[:9].reshape(3, 3), bw[9:12], bw[12:15])
+            assert np.abs(Tb.map(x) - synth.Transform(Ab, tb, cb).map(x)).max() < 1e-6
+            assert rel(rows[b, C["covariance_backward"]].reshape(12, 12), covb) < 1e-5
+            if hasattr(g, "close"):
+                g.close()
+        m = rows[b, C["measurements"]]
+        deg = 180.0 / np.pi
+        assert np.isclose(m[0], max(rows[b, C["weighted_error"]], rows[b, C["weighted_error_backward"]]))
+        assert np.isclose(m[2], deg * max(rows[b, C["sheet_angles"]], rows[b, C["sheet_angles_backward"]]))
+        assert np.isclose(m[7], deg * min(rows[b, C["tube_angles"]], rows[b, C["tube_angles_backward"]]))
+        assert m[1] >= m[5] > 0.0
+        # the sampled transfer-error trace, recomputed in numpy from the returned covariance
+        cov = rows[b, C["covariance"]].reshape(12, 12)
+        cen = rows[b, C["c"]]
+        best = 0.0
+        for k in np.arange(mbox[b, 2], mbox[b, 5] - 1.0 + 1e-12, 5.0):
+            for j in np.arange(mbox[b, 1], mbox[b, 4] - 1.0 + 1e-12, 5.0):
+                for i in np.arange(mbox[b, 0], mbox[b, 3] - 1.0 + 1e-12, 5.0):
+                    l = np.array([i, j, k]) - cen
+                    J = np.zeros((3, 12))
+                    for r in range(3):
+                        J[r, 3 * r:3 * r + 3] = l
+                        J[r, 9 + r] = 1.0
+                    best = max(best, np.trace(J @ cov @ J.T))
+        assert np.isclose(max(m[1], m[5]), best, rtol=1e-6) or np.isclose(min(m[1], m[5]), best, rtol=1e-6)
+    bt.close()
+
+
+def test_batch_is_deterministic(E):
+    """two runs of the same batch are bit-equal (no floating-point atomics, fixed reduction orders)"""
+    from lrr_amd import locations
+    pair, rois, inits, mbox, fbox, seeds = _setup(40000, 4, 20249, 50.0)
+    bt = E.LocationBatch(pair.moving, pair.fixed)
+    A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
+    r1 = bt.run(A0, t0, c0, mbox, fbox, seeds, diagnostics=True)
+    r2 = bt.run(A0, t0, c0, mbox, fbox, seeds, diagnostics=True)
+    assert np.array_equal(r1, r2)
+    bt.close()

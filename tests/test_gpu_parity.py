@@ -493,14 +493,15 @@ def test_full_size_200k_schedule_against_oracle(E, ob, kind_name):
 
 
 def test_locations_driver_against_oracle(E, ob):
-    """config 5 driver (lrr_amd/locations.py): every location's final transform and iteration
-    count equal the oracle's run of the same location"""
+    """config 5 driver (lrr_amd/locations.py), batched and one-at-a-time form: every location's final
+    transform and iteration count equal the oracle's run of the same location"""
     from lrr_amd import locations, multi_gpu
     pair = synth.make_pair(40000, 40000, 20247, kind="affine")
     rois = synth.query_rois(pair, 4, 20247, half=50.0)
     inits = [synth.perturbed(pair.planted, 100 + i) for i in range(len(rois))]
-    rows, pairs = locations.register_locations(pair, rois, inits, seed=19)
-    assert rows.shape == (4, multi_gpu.RESULT_WIDTH) and pairs > 0
+    rows_b, pairs_b = locations.register_locations(pair, rois, inits, seed=19, half=50.0)
+    rows, pairs = locations.register_locations_sequential(pair, rois, inits, seed=19)
+    assert rows.shape == (4, multi_gpu.RESULT_WIDTH) and pairs > 0 and pairs_b == pairs
     for i, (_, _, mi, fi) in enumerate(rois):
         m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[i]
         # every location has its own subset seed, so a fresh oracle estimator per location is equivalent
@@ -508,8 +509,9 @@ def test_locations_driver_against_oracle(E, ob):
                                moving_inside=m_in, fixed_inside=f_in, seed=locations.location_seed(19, i))
         conv, its = c.run(locations.MAX_ITERATIONS)
         A, t, cc, _ = c.get_transform()
-        assert int(rows[i, 19]) == i and bool(rows[i, 0]) == conv and int(rows[i, 1]) == its
-        assert rel(rows[i, 2:11].reshape(3, 3), A) < 1e-6 and rel(rows[i, 11:14], t) < 1e-6
+        for r in (rows, rows_b):
+            assert int(r[i, 19]) == i and bool(r[i, 0]) == conv and int(r[i, 1]) == its
+            assert rel(r[i, 2:11].reshape(3, 3), A) < 1e-6 and rel(r[i, 11:14], t) < 1e-6
     # the partition over threads / ranks does not change any location's result
-    rows2, _ = locations.register_locations(pair, rois, inits, seed=19, workers=3, device_index=0)
+    rows2, _ = locations.register_locations_sequential(pair, rois, inits, seed=19, workers=3, device_index=0)
     assert np.array_equal(rows, rows2)
