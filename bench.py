@@ -47,7 +47,10 @@ def parse():
     ap.add_argument("--workload", choices=["c3", "locations"], default="c3",
                     help="c3: the BASELINE metric (default); locations: config 5, independent query locations sharded over the ranks")
     ap.add_argument("--locations", type=int, default=256)
-    ap.add_argument("--workers", type=int, default=4, help="host threads (device contexts) per rank in the locations workload")
+    ap.add_argument("--workers", type=int, default=4, help="host threads (device contexts) per rank in the sequential locations workload")
+    ap.add_argument("--locations-mode", choices=["batch", "sequential"], default="batch",
+                    help="batch: all locations of a rank advance in lockstep, one submission per phase; sequential: one estimator object at a time (the reference caller's form)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region; the median is reported")
     return ap.parse_args()
 
 
@@ -87,31 +90,47 @@ def pmc_traffic(args):
 
 def bench_locations(args, rank, local_rank, world):
     """config 5: `--locations` query locations x one 200k volume pair, static blocks per rank
-    (32 per GPU at 256/8), one all_gather of the final transforms.  Strong scaling: total work fixed."""
+    (32 per GPU at 256/8), one all_gather of the result rows.  Strong scaling: total work fixed.
+    A step = one query location registered to convergence plus the caller's decision measurements."""
     import torch
     import torch.distributed as dist
 
+    from lrr_amd import estimation as E
     from lrr_amd import locations, synth
     pair = synth.make_pair(args.n, args.n, 20245, kind="affine")  # same volumes on every rank
     rois = synth.query_rois(pair, args.locations, 20245, half=25.0)
     inits = [synth.perturbed(pair.planted, 1000 + i) for i in range(len(rois))]
     dev = (torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")) if world > 1 else None
-    ests = []  # the estimators (and the two uploaded volumes) live across the calls: inputs resident before timing
-    locations.register_locations(pair, rois[: max(1, args.workers)], inits, 0, 1, workers=args.workers,
-                                 device_index=local_rank, estimators=ests)  # warm-up: libraries, kernels, uploads
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rows, pairs = locations.register_locations(pair, rois, inits, rank, world, gather_device=dev,
-                                               workers=args.workers, device_index=local_rank, estimators=ests)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    for e in ests:
-        if e is not None:
-            e.close()
+    sequential = args.locations_mode == "sequential"
+    reps = max(1, args.reps)
+    times, pairs, rows = [], 0, None
+    if sequential:
+        ests = []  # the estimators (and the two uploaded volumes) live across the calls: inputs resident before timing
+        locations.register_locations_sequential(pair, rois[: max(1, args.workers)], inits, 0, 1, workers=args.workers,
+                                                device_index=local_rank, estimators=ests)  # warm-up
+        run = lambda: locations.register_locations_sequential(pair, rois, inits, rank, world, gather_device=dev, workers=args.workers,
+                                                              device_index=local_rank, estimators=ests)
+    else:
+        batch = E.LocationBatch(pair.moving, pair.fixed)  # the two volumes resident before timing
+        locations.register_locations(pair, rois[:4], inits, 0, 1, batch=batch)  # warm-up: libraries, kernels, buffers
+        run = lambda: locations.register_locations(pair, rois, inits, rank, world, gather_device=dev, batch=batch)
+    for _ in range(reps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rows, pairs = run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        times.append(time.perf_counter() - t0)
+    if sequential:
+        for e in ests:
+            if e is not None:
+                e.close()
+    else:
+        batch.close()
+    dt = float(np.median(times))
     tt = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=dev if dev is not None else "cuda")
     if world > 1:
         dist.all_reduce(tt[0:1], op=dist.ReduceOp.MAX)
@@ -123,10 +142,14 @@ def bench_locations(args, rank, local_rank, world):
             "steps": len(rois), "warmup": 1, "ms_per_step": 1e3 * dt / max(len(rois), 1), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{len(rois)} query locations (50 mm ROIs) x {args.n}-feature volume pair, "
-                                   "symmetric ICP to convergence per location (<= 70 iterations)",
-                       "parallelism": f"{world} rank(s) x {args.workers} host thread(s), static blocks of locations, one all_gather"},
+                                   "symmetric ICP to convergence per location (<= 70 iterations) + decision measurements",
+                       "mode": args.locations_mode,
+                       "parallelism": (f"{world} rank(s), static blocks of locations, one batch per rank, one all_gather" if not sequential else
+                                       f"{world} rank(s) x {args.workers} host thread(s), static blocks of locations, one all_gather")},
             "locations_per_s": len(rois) / dt, "converged": int(rows[:, 0].sum()),
-            "mean_iterations": float(rows[:, 1].mean()), "roofline": None, "cpu_baseline": None}))
+            "mean_iterations": float(rows[:, 1].mean()), "max_iterations": int(rows[:, 1].max()),
+            "repetitions": reps, "seconds_all": times, "row_bytes": int(rows.shape[1] * 8),
+            "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

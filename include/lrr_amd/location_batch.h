@@ -14,6 +14,8 @@
 #define LRR_AMD_LOCATION_BATCH_H_
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <vector>
 
 #include "lrr_amd/icp_engine.h"
@@ -58,7 +60,8 @@ inline bool valid_transform(cdcl_trans<3, 12>::sptr const &T) {
 }
 
 // ComputeTransferErrorCovariance (rrl/itkLocationRegistration.cxx:2793-2858): J C J^T sampled every `interval`
-// mm over [start, end]; largest trace and largest eigenvalue over the samples
+// mm over [start, end]; mean covariance, largest trace and largest eigenvalue over the samples (the dense
+// products of the reference, ~2 us per sample: for tests and callers that want all three)
 inline void sampled_transfer_error(cdcl_trans<3, 12>::sptr const &T, vnl_vector_fixed<double, 3> const &start,
                                    vnl_vector_fixed<double, 3> const &end, double interval,
                                    vnl_matrix_fixed<double, 3, 3> &covarianceJ, double &maxTrace, double &maxEval) {
@@ -84,6 +87,34 @@ inline void sampled_transfer_error(cdcl_trans<3, 12>::sptr const &T, vnl_vector_
         ++count;
       }
   if (count) covarianceJ *= (1.0 / double(count));
+}
+
+// maxTrace of the same sampling — the only output the decision measurements use (:1832-1858) — without the
+// dense products: with the affine Jacobian (row r = (x - c) at columns 3r..3r+2, 1 at column 9+r,
+// cdcl_trans_affine.txx:141-161) trace(J C J^T) = l^T M l + 2 b.l + c0, l = x - c, M = sum_r C[3r.., 3r..],
+// b = sum_r C[3r.., 9+r], c0 = sum_r C[9+r, 9+r]: 12 multiply-adds per sample instead of ~700
+inline double sampled_transfer_max_trace(cdcl_trans<3, 12>::sptr const &T, vnl_vector_fixed<double, 3> const &start,
+                                         vnl_vector_fixed<double, 3> const &end, double interval) {
+  vnl_matrix_fixed<double, 12, 12> const &C = T->get_covariance();
+  double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, bv[3] = {0, 0, 0}, c0 = 0.0;
+  for (unsigned r = 0; r < 3; ++r) {
+    for (unsigned a = 0; a < 3; ++a) {
+      for (unsigned b = 0; b < 3; ++b) M[a][b] += C(3 * r + a, 3 * r + b);
+      bv[a] += 0.5 * (C(3 * r + a, 9 + r) + C(9 + r, 3 * r + a));
+    }
+    c0 += C(9 + r, 9 + r);
+  }
+  const vnl_vector_fixed<double, 3> cen = T->center_moving_;
+  double maxTrace = 0.0;
+  for (double k = start[2]; k <= end[2]; k += interval)
+    for (double j = start[1]; j <= end[1]; j += interval)
+      for (double i = start[0]; i <= end[0]; i += interval) {
+        const double l[3] = {i - cen[0], j - cen[1], k - cen[2]};
+        double tr = c0;
+        for (int a = 0; a < 3; ++a) tr += l[a] * ((M[a][0] * l[0] + M[a][1] * l[1]) + M[a][2] * l[2]) + 2.0 * bv[a] * l[a];
+        if (tr > maxTrace) maxTrace = tr;
+      }
+  return maxTrace;
 }
 
 template <class FeatureT = cdcl_feature_ICP<3> >
@@ -117,6 +148,7 @@ class rrl_location_batch {
     const size_t B = queries.size();
     results.assign(B, location_result());
     if (B == 0) return;
+    phase_timer tm(std::getenv("LRR_BATCH_TIMING") != nullptr);
     std::vector<double> mbox(6 * B), fbox(6 * B);
     for (size_t b = 0; b < B; ++b)
       for (int d = 0; d < 3; ++d) {
@@ -125,6 +157,7 @@ class rrl_location_batch {
       }
     std::vector<int64_t> nm(B), nf(B);
     check(lrr_icp_batch_set_rois(batch_, (int64_t)B, mbox.data(), fbox.data(), nm.data(), nf.data()), "batch ROI selection");
+    tm.lap("roi");
 
     std::vector<state> st(B);
     std::vector<lrr_icp_batch_loc> loc(B);
@@ -168,17 +201,23 @@ class rrl_location_batch {
         fill_loc(loc[b], s);
         results[b].matched_pairs += (int64_t)s.number_points[0] + s.number_points[1];
       }
+      tm.lap("host");
       check(lrr_icp_batch_match(batch_, loc.data()), "batch find_closest_euclidean");
+      tm.lap("match");
       check(lrr_icp_batch_estimate(batch_, loc.data(), &opts, est.data()), "batch estimate");
-      for (size_t b = 0; b < B; ++b) {
-        state &s = st[b];
+      tm.lap("estimate");
+      // the host half of estimate_LS
+      for (long b = 0; b < (long)B; ++b) {
+        state &s = st[(size_t)b];
         if (!s.running) continue;
         s.scale_estimated[0] = s.scale_estimated[1] = true;
-        symmetric_apply_solution<dof>(s.F, s.B, est[b], true, true);
+        forward_update(s.F, est[(size_t)b]);
         s.B = s.F->inverse();
-        fill_loc(loc[b], s);
+        fill_loc(loc[(size_t)b], s);
       }
+      tm.lap("solve");
       check(lrr_icp_batch_errors(batch_, loc.data(), sums.data()), "batch error metrics");
+      tm.lap("errors");
       for (size_t b = 0; b < B; ++b) {
         state &s = st[b];
         if (!s.running) continue;
@@ -206,12 +245,36 @@ class rrl_location_batch {
         }
       }
     }
+    tm.lap("host");
     if (diagnostics_) decision_measurements(queries, st, loc, results, est, sums);
+    tm.lap("diagnostics");
+    tm.report(B);
     for (size_t b = 0; b < B; ++b)
       if (results[b].enough_features && st[b].B) results[b].backward = st[b].B;
   }
 
  private:
+  // wall-clock per phase of run(), printed when LRR_BATCH_TIMING is set (tuning aid)
+  struct phase_timer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    std::vector<std::pair<std::string, double> > acc;
+    explicit phase_timer(bool enable) : on(enable), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *name) {
+      if (!on) return;
+      auto now = std::chrono::steady_clock::now();
+      double ms = std::chrono::duration<double, std::milli>(now - t).count();
+      t = now;
+      for (auto &a : acc) if (a.first == name) { a.second += ms; return; }
+      acc.push_back(std::make_pair(std::string(name), ms));
+    }
+    void report(size_t B) {
+      if (!on) return;
+      std::fprintf(stderr, "[lrr batch] %zu locations:", B);
+      for (auto &a : acc) std::fprintf(stderr, " %s %.2f ms", a.first.c_str(), a.second);
+      std::fprintf(stderr, "\n");
+    }
+  };
   struct state {
     trans_sptr_type F, B;
     unsigned N[2], number_points[2];
@@ -251,6 +314,30 @@ class rrl_location_batch {
     L.injected_f = L.injected_b = 0.0;
     // the affine normalize() zeroes the centre before the accumulation (cdcl_trans_affine.txx:252)
     L.jac_centre[0] = L.jac_centre[1] = L.jac_centre[2] = 0.0;
+  }
+
+  // symmetric_apply_solution(F, B, r, normalize = true, estimate_parameters = true) for the affine forward
+  // transform, without the work whose results it overwrites: normalize() only zeroes the centre (its A, t and
+  // covariance are replaced by the solution), the backward transform is replaced by inverse(forward) right
+  // after.  What remains: C = inverse(AtA), theta = C Atb (normalised coordinates), then unnormalize()
+  // (cdcl_trans_affine.txx:259-286): A <- (rf/rm) A, t <- rf t + cf, covar <- D C D with the diagonal
+  // D = (rf/rm x 9, rf x 3), centre <- cm.  Same operations in the same order: bit-identical results.
+  static void forward_update(trans_sptr_type const &F, const lrr_icp_sym_out &r) {
+    double C[144];
+    linalg::sym_inverse(12, r.AtA, C);
+    const double rm = r.norm.rm, rf = r.norm.rf, f = rf / rm;
+    vnl_vector<double> p(12, 0.0);
+    for (unsigned i = 0; i < 12; ++i) {
+      double s = 0.0;
+      for (unsigned k = 0; k < 12; ++k) s += C[i * 12 + k] * r.Atb[k];
+      p[i] = i < 9 ? s * f : rf * s + r.norm.cf[i - 9];
+    }
+    F->set_parameterization(p);
+    vnl_matrix_fixed<double, 12, 12> cov;
+    for (unsigned i = 0; i < 12; ++i)
+      for (unsigned j = 0; j < 12; ++j) cov(i, j) = ((i < 9 ? f : rf) * C[i * 12 + j]) * (j < 9 ? f : rf);
+    F->set_covariance(cov);
+    for (int d = 0; d < 3; ++d) F->center_moving_[d] = r.norm.cm[d];
   }
 
   // ComputeDecisionMeasurements (:1816-1871) of every location that ran: forward angles and error, then
@@ -295,11 +382,9 @@ class rrl_location_batch {
       r.weighted_error_backward = e[2] != 0 ? e[1] / e[2] : e[1];
       // transfer-error covariance sampled over the two ROIs (:1832-1841, 2793-2858); the forward one uses the
       // transform as the loop left it
-      vnl_matrix_fixed<double, 3, 3> cj;
-      double maxTrace = 0, maxEval = 0, maxTraceB = 0, maxEvalB = 0;
       vnl_vector_fixed<double, 3> sp(voxel_spacing_);
-      sampled_transfer_error(r.forward, queries[b].moving_x0, queries[b].moving_x1 - sp, sample_interval_, cj, maxTrace, maxEval);
-      sampled_transfer_error(st[b].B, queries[b].fixed_x0, queries[b].fixed_x1 - sp, sample_interval_, cj, maxTraceB, maxEvalB);
+      const double maxTrace = sampled_transfer_max_trace(r.forward, queries[b].moving_x0, queries[b].moving_x1 - sp, sample_interval_);
+      const double maxTraceB = sampled_transfer_max_trace(st[b].B, queries[b].fixed_x0, queries[b].fixed_x1 - sp, sample_interval_);
       const double sa = r.sheet_angles * deg, ta = r.tube_angles * deg, sab = r.sheet_angles_backward * deg, tab = r.tube_angles_backward * deg;
       r.measurements[0] = std::max(r.weighted_error, r.weighted_error_backward);
       r.measurements[1] = std::max(maxTrace, maxTraceB);
