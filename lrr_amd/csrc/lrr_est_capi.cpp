@@ -16,6 +16,7 @@
 #include "lrr_amd/rrl_estimation_ICP_matching_all.h"
 #include "lrr_amd/rrl_estimation_symmetric_ICP_matching_all.h"
 #include "lrr_amd/location_batch.h"
+#include "lrr_amd/vtp_features.h"
 
 extern "C" {
 typedef struct {
@@ -404,6 +405,49 @@ int lrr_est_batch_run(lrr_est_batch *bt, int64_t B, const double *A0, const doub
       for (int k = 0; k < 8; ++k) r[32 + k] = R.measurements[k];
       if (R.forward) read_trans<12>(R.forward, r + 2, r + 11, r + 14, r + 55);
       if (R.backward) read_trans<12>(R.backward, r + 40, r + 49, r + 52, r + 199);
+    }
+  });
+}
+
+
+// ---- feature files (include/lrr_amd/vtp_features.h) -----------------------------------------------------
+typedef struct lrr_vtp lrr_vtp;
+#define VT(v) (reinterpret_cast<lrr_amd::vtp_arrays *>(v))
+
+lrr_vtp *lrr_vtp_open(const char *path) {
+  lrr_amd::vtp_arrays *a = new lrr_amd::vtp_arrays;
+  int rc = guard([&] { lrr_amd::read_vtp(path, *a); });
+  if (rc) { delete a; return nullptr; }
+  return reinterpret_cast<lrr_vtp *>(a);
+}
+void lrr_vtp_close(lrr_vtp *v) { delete VT(v); }
+int64_t lrr_vtp_count(lrr_vtp *v) { return (int64_t)VT(v)->n; }
+// the arrays as stored (widened to double); present[k] = 0 when array k is absent from the file
+int lrr_vtp_arrays(lrr_vtp *v, double *points, double *proj, double *strengths, double *shapes, double *normals, double *binormals,
+                   int *present) {
+  return guard([&] {
+    const lrr_amd::vtp_arrays &a = *VT(v);
+    const std::vector<double> *src[6] = {&a.points, &a.errorProjectors, &a.strengths, &a.shapes, &a.normals, &a.binormals};
+    double *dst[6] = {points, proj, strengths, shapes, normals, binormals};
+    for (int k = 0; k < 6; ++k) {
+      if (present) present[k] = src[k]->empty() ? 0 : 1;
+      if (dst[k] && !src[k]->empty()) std::memcpy(dst[k], src[k]->data(), sizeof(double) * src[k]->size());
+    }
+  });
+}
+// the features vtkPolyDataToFeaturesICPFilter builds from the file: dirs9 = up to three directions_ per feature
+int lrr_vtp_features(lrr_vtp *v, double *loc, double *proj, double *strength, uint8_t *shape, uint8_t *ndirs, double *dirs9) {
+  return guard([&] {
+    std::vector<cdcl_feature_ICP<3>::sptr> f = lrr_amd::features_from_vtp<cdcl_feature_ICP<3> >(*VT(v));
+    for (size_t i = 0; i < f.size(); ++i) {
+      for (int d = 0; d < 3; ++d) loc[3 * i + d] = f[i]->location_[d];
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) proj[9 * i + 3 * r + c] = f[i]->error_projector_(r, c);
+      strength[i] = (double)f[i]->strength_;
+      shape[i] = (uint8_t)f[i]->shape_;
+      ndirs[i] = (uint8_t)f[i]->directions_.size();
+      for (int k = 0; k < 9; ++k) dirs9[9 * i + k] = 0.0;
+      for (size_t k = 0; k < f[i]->directions_.size() && k < 3; ++k)
+        for (int d = 0; d < 3; ++d) dirs9[9 * i + 3 * k + d] = f[i]->directions_[k][d];
     }
   });
 }

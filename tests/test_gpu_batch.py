@@ -182,3 +182,107 @@ def test_batch_is_deterministic(E):
     r2 = bt.run(A0, t0, c0, mbox, fbox, seeds, diagnostics=True)
     assert np.array_equal(r1, r2)
     bt.close()
+
+
+def _rank_worker(rank, world, port, out_dir):
+    """one rank of a 2-rank job on ONE GPU (gloo rendezvous and gather on the CPU; the ranks share cuda:0)"""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lrr_amd import estimation, locations
+        estimation.set_device(0)
+        pair = synth.make_pair(40000, 40000, 20251, kind="affine")
+        rois = synth.query_rois(pair, 7, 20251, half=50.0)
+        inits = [synth.perturbed(pair.planted, 300 + i) for i in range(len(rois))]
+        rows, pairs = locations.register_locations(pair, rois, inits, rank, world, seed=23, half=50.0)
+        np.save(os.path.join(out_dir, f"rows_{rank}.npy"), rows)
+        np.save(os.path.join(out_dir, f"pairs_{rank}.npy"), np.array([pairs]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_register_locations_equals_one_rank(E, tmp_path):
+    """the real N > 1 locations path: two ranks shard 7 locations (4 + 3), run their batches and gather the
+    result rows; every rank ends with exactly the rows a single rank computes (oracle-free property)"""
+    import socket
+    import torch.multiprocessing as mp
+    from lrr_amd import locations
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    pair = synth.make_pair(40000, 40000, 20251, kind="affine")
+    rois = synth.query_rois(pair, 7, 20251, half=50.0)
+    inits = [synth.perturbed(pair.planted, 300 + i) for i in range(len(rois))]
+    want, pairs = locations.register_locations(pair, rois, inits, seed=23, half=50.0)
+    r0, r1 = np.load(tmp_path / "rows_0.npy"), np.load(tmp_path / "rows_1.npy")
+    assert r0.shape == want.shape == (7, E.LocationBatch(pair.moving.subset(np.arange(10)), pair.fixed.subset(np.arange(10))).width)
+    assert np.array_equal(r0, want, equal_nan=True) and np.array_equal(r1, want, equal_nan=True)
+    assert int(np.load(tmp_path / "pairs_0.npy")[0]) + int(np.load(tmp_path / "pairs_1.npy")[0]) == pairs
+    assert np.array_equal(want[:, 19], np.arange(7))
+
+
+def test_config4_path_on_feature_files(E, ob, tmp_path):
+    """config 4 rehearsal: the example CT pair is a download link (not in the image), so the same path runs on a
+    synthetic pair written as feature FILES in the reference's layout: tools/run_config4.py reads the two .vtk
+    (VTK XML PolyData) files, selects the ROIs on the device, registers every location and the rows are checked
+    against the CPU oracle fed with the same files.  With LRR_CONFIG4_DIR set the real pair is run the same way."""
+    import os
+    import subprocess
+    import sys
+    from lrr_amd import locations, vtp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    real = os.environ.get("LRR_CONFIG4_DIR")
+    if real:
+        datadir, fixed, moving = real, "4893/4978whole", "4717/4722whole"
+        extra = []
+    else:
+        datadir, fixed, moving = str(tmp_path), "4893/4978whole", "4717/4722whole"
+        pair = synth.make_pair(30000, 30000, 20252, kind="affine")
+        os.makedirs(tmp_path / "4893"), os.makedirs(tmp_path / "4717")
+        vtp.write_vtp(tmp_path / (fixed + "_00.vtk"), vtp.disk_arrays(pair.fixed), fmt="appended-raw")
+        vtp.write_vtp(tmp_path / (moving + "_00.vtk"), vtp.disk_arrays(pair.moving), fmt="appended-base64", compress=True)
+        rois = synth.query_rois(pair, 3, 20252, half=40.0)
+        np.savetxt(tmp_path / (fixed + "nodules.txt"), np.array([r[0] for r in rois]))
+        T0 = synth.perturbed(pair.planted, 9)
+        # the tool takes transforms with centre 0: x -> A x + (t - A c)
+        np.savetxt(tmp_path / "init.txt", np.concatenate([T0.A.ravel(), T0.t - T0.A @ T0.c])[None])
+        extra = ["--init", str(tmp_path / "init.txt"), "--roi", "80"]
+    out = tmp_path / "rows.npy"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_config4.py"), datadir, "--fixed", fixed, "--moving", moving,
+                        "--out", str(out)] + extra, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    if "not run: data absent" in r.stdout:
+        pytest.skip("config 4 not run: data absent")
+    rows = np.load(out)
+    C = E.LocationBatch.COL
+    fx, mv = vtp.read_features(os.path.join(datadir, fixed + "_00.vtk")), vtp.read_features(os.path.join(datadir, moving + "_00.vtk"))
+    checked = 0
+    for b in range(min(rows.shape[0], 3)):
+        if not rows[b, C["enough_features"]]:
+            continue
+        line = [json_line for json_line in r.stdout.splitlines() if json_line.startswith('{"location": %d,' % b)][0]
+        import json
+        rec = json.loads(line)
+        half = 40.0 if not real else 25.0
+        cf = np.array(rec["centre"])
+        if real:
+            A0, t0 = np.eye(3), np.zeros(3)
+        else:
+            p = np.loadtxt(tmp_path / "init.txt")
+            A0, t0 = p[:9].reshape(3, 3), p[9:]
+        cm = np.linalg.inv(A0) @ (cf - t0)
+        fi, mi = fx.in_box(cf - half, cf + half), mv.in_box(cm - half, cm + half)
+        assert fi.size == rec["n_fixed_inside"] and mi.size == rec["n_moving_inside"]
+        o = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, mv, fx, A0, t0, np.zeros(3), moving_inside=mv.subset(mi), fixed_inside=fx.subset(fi),
+                               seed=locations.location_seed(7, b))
+        conv, its = o.run(locations.MAX_ITERATIONS)
+        Ao, to, _, _ = o.get_transform()
+        assert rec["converged"] == conv and rec["iterations"] == its
+        assert rel(np.array(rec["A"]).reshape(3, 3), Ao) < 1e-6 and rel(np.array(rec["t"]), to) < 1e-6
+        checked += 1
+    assert checked > 0
