@@ -207,6 +207,7 @@ def main():
         timer.synchronize()
 
     timer.match_profile(enable=True, reset=True)
+    timer.cert_stats(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -215,6 +216,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     match_ms, match_launches = timer.match_profile(enable=False, reset=False)
+    cert_seen, cert_searched = timer.cert_stats()
 
     A, t, c, _ = est.get_transform()
     row = multi_gpu.pack_result(rank, True, it, A, t, c, est.weighted_error(), est.RMS_error())
@@ -263,6 +265,8 @@ def main():
                          "traffic_GBs": (traffic / (k1_ms * 1e-3) / 1e9) if (traffic and k1_ms > 0) else None,
                          "traffic_frac": (traffic / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k1_ms > 0) else None,
                          "kernel_ms": k1_ms, "launches": match_launches,
+                         "certificate": {"queries": cert_seen, "searched": cert_searched,
+                                         "skipped_frac": (1.0 - cert_searched / cert_seen) if cert_seen else None},
                          "algorithmic_bytes_per_launch": k1_bytes,
                          "iteration_achieved_GBs": value / world * ITER_BYTES_PER_PAIR / 1e9,
                          "iteration_frac": value / world * ITER_BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBS},

@@ -63,6 +63,11 @@ int  lrr_icp_timer_stop(lrr_icp_ctx *ctx, double *elapsed_ms);
  * every K1 launch when profiling is enabled) */
 int  lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_t *launches, int reset);
 
+/* K1 at the finest level skips the search of a source whose previous match is provably still its unique
+ * nearest neighbour (second-nearest bound + triangle inequality, k_match_cert in lrr_icp.hip): sources seen by
+ * that kernel and sources it had to search since the last reset */
+int  lrr_icp_cert_stats(lrr_icp_ctx *ctx, int64_t *queries, int64_t *searched, int reset);
+
 /* ---- feature clouds ---------------------------------------------------------------------
  * Replaces the vcl_vector<feature_sptr> the estimators hold plus build_kd_trees()
  * (cdcl/cdcl_estimation_ICP_matching_all.txx:113-135) / set_voronoi_maps()

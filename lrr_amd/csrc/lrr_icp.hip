@@ -130,6 +130,7 @@ struct lrr_icp_ctx {
   // completion word of the reduce kernels (mapped host memory) and their last-block counter
   unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr, seq = 0;
   int *d_done = nullptr;
+  unsigned long long *d_cert_stats = nullptr;  // {queries, searched} of the certificate kernel
   // K1 scratch: one set per submission lane.  Lane 0 runs on `stream`; lane 1 has its own stream so
   // that the two directions of a symmetric estimator search concurrently (lrr_icp_match_pair).
   K1Lane lane[2];
@@ -183,6 +184,15 @@ struct lrr_icp_dir {
   int from_is_copy = 0;
   unsigned *flag = nullptr; int64_t flag_cap = 0;  // per target: stamp of the last call that matched it
   unsigned flag_gen = 0;
+  // K1 certificate state (k_match_cert): per-source lower bound of the second-nearest distance under the
+  // transform of the last search, valid when have_bounds
+  float *d2lb = nullptr;
+  bool have_bounds = false;
+  lrr_icp_xform prev_xf;
+  // list positions not materialised by the last search (finest level): slot[s] = perm^-1(orig) under these keys
+  bool slot_lazy = false;
+  unsigned slot_keys[4] = {0, 0, 0, 0};
+  int slot_half = 1;
 };
 
 namespace {
@@ -819,19 +829,31 @@ struct BallArgs {  // one direction of a ball search
   int *hard, *hard_count;
   int budget;
   double max_rad;
+  // second-nearest bounds (the certificate of the next search, see k_match_cert): d2lb[s] = a lower bound of
+  // the distance from the mapped source to every target other than its match; xf_prev = the transform of
+  // the previous search (certificate kernel only)
+  float *d2lb;
+  XfD xf_prev;
+  int *list, *list_count;  // sources the certificate kernel could not settle
 };
+constexpr float kBallMarginCells = 0.01f;  // the ball is searched this much wider than the best distance (in cells):
+                                           // what lies beyond is provably farther than best + margin
 // The ball search of one query (yx, yy, yz) whose previous match `prev` (a canonical target index) bounds
 // the distance: true = b holds the exact nearest neighbour; false = ball wider than max_rad or more
 // than `budget` candidates (the caller hands the query to the wave-per-query phase).
+// `second` returns the smallest exact squared distance among the OTHER targets the search evaluated; every
+// target it did not evaluate is farther than the final best distance + kBallMarginCells * h (all pruning
+// bounds carry that margin), so min(sqrt(second), sqrt(b.d) + margin) bounds the second-nearest distance.
 __device__ __forceinline__ bool ball_search(const GridView &g, const GridPoint *to_pt, double yx, double yy, double yz,
-                                            int prev, int budget, double max_rad, Best &b) {
+                                            int prev, int budget, double max_rad, Best &b, double &second) {
+  second = INFINITY;
   {
     const GridPoint q = to_pt[prev];  // one 32-B gather: location and original index of the previous match
     b.d = dist2(yx, yy, yz, q.x, q.y, q.z);
     b.orig = q.orig;
     b.canon = prev;
   }
-  const double rad = sqrt(b.d) + 2.0 * g.tol;
+  const double rad = sqrt(b.d) + 2.0 * g.tol + (double)kBallMarginCells * g.h;
   if (!(rad <= max_rad)) return false;  // outlier: a whole wavefront serves it better
   const double inv_hx = g.inv_h * g.fine;
   const int fdx = g.dx * g.fine;  // x-slices per row
@@ -847,14 +869,14 @@ __device__ __forceinline__ bool ball_search(const GridView &g, const GridPoint *
   const float qfx = (float)((yx - g.lox) * g.inv_h), qfy = uy, qfz = uz;  // the query in cell units
   float thr2;
   {
-    const float tb = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + 3e-4f;
+    const float tb = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + (3e-4f + kBallMarginCells);
     thr2 = tb * tb;
   }
   int yi = ya, zi = za;  // (z,y) of row r0: advanced without integer division
   int row = (za * g.dy + ya) * fdx;
   const int row_wrap = (g.dy - nyr) * fdx;
   for (int r0 = 0; r0 < nrows; r0 += kBallRows) {
-    const float rc = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + 1e-3f;
+    const float rc = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + (1e-3f + kBallMarginCells);
     const float rc2 = rc * rc;
     int rs[kBallRows], re[kBallRows];
 #pragma unroll
@@ -914,14 +936,89 @@ __device__ __forceinline__ bool ball_search(const GridView &g, const GridPoint *
         const GridPoint pt = g.cpt[cn];
         const double d2 = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
         if (d2 < b.d || (d2 == b.d && pt.orig < b.orig)) {
+          second = fmin(second, b.d);  // the old best is now one of the others
           b.d = d2; b.orig = pt.orig; b.canon = cn;
-          const float tb = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + 3e-4f;
+          const float tb = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + (3e-4f + kBallMarginCells);
           thr2 = tb * tb;
+        } else {
+          second = fmin(second, d2);
         }
       }
     }
   }
   return true;
+}
+
+// lower bound (rounded down, as float) of the distance from the query to every target other than its match
+__device__ __forceinline__ float second_bound(double best_d2, double second_d2, double h) {
+  const double lb = fmin(sqrt(second_d2), sqrt(best_d2) + (double)kBallMarginCells * h) * (1.0 - 1e-7);
+  return __double2float_rd(lb);
+}
+
+// K1 at the finest level once bounds exist: the CERTIFICATE kernel.  Between two ICP iterations the mapped
+// source moves by u = |T'(x) - T(x)|, tiny near convergence.  Every target other than the previous match p
+// was at least L away from T(x) (L = d2lb[s]), so it is at least L - u away from T'(x); if
+// |T'(x) - q_p| + u < L the previous match is still the unique nearest neighbour (triangle inequality,
+// strict: no tie case) and the search is skipped: one streamed source record, one gathered target point.
+// L - u is the bound for the next search.  The sources that fail — well under a percent near convergence —
+// are listed and searched by k_match_list (thread per listed source, same ball search), so this kernel
+// stays a streaming pass at full occupancy.  Slots are not rewritten here: at the finest level every source
+// stays active and its list position is re-derived from the permutation keys when matches are exported
+// (k_export).
+constexpr int kCertBlock = 256;
+__device__ __forceinline__ void match_cert_body(const BallArgs &A) {
+  const int per = (int)gridDim.x >> 3;
+  const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int s = lblock * kCertBlock + threadIdx.x;
+  if (s >= A.nsrc) return;
+  const SrcPoint sp = A.src[s];
+  const int prev = A.m_to[s];
+  const float L = A.d2lb[s];
+  A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+  if (prev >= 0 && L > 0.0f) {
+    const GridPoint q = A.to_pt[prev];
+    double yx, yy, yz, ox, oy, oz;
+    map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
+    map_loc(A.xf_prev, sp.x, sp.y, sp.z, ox, oy, oz);
+    const double u = sqrt(dist2(yx, yy, yz, ox, oy, oz));
+    const double d1 = sqrt(dist2(yx, yy, yz, q.x, q.y, q.z));
+    if ((d1 + u) * (1.0 + 1e-7) < (double)L) {
+      A.d2lb[s] = __double2float_rd(((double)L - u) * (1.0 - 1e-7));
+      return;
+    }
+  }
+  A.list[atomicAdd(A.list_count, 1)] = s;
+}
+__global__ __launch_bounds__(kCertBlock) void k_match_cert(BallArgs A) { match_cert_body(A); }
+__global__ __launch_bounds__(kCertBlock) void k_match_cert2(BallArgs A, BallArgs B) {
+  if (blockIdx.y == 0) match_cert_body(A);
+  else match_cert_body(B);
+}
+
+// the sources the certificate kernel listed: thread per list entry, ball search around the previous match
+__device__ __forceinline__ void match_list_body(const BallArgs &A) {
+  const int e = blockIdx.x * kBallBlock + threadIdx.x;
+  if (e >= *A.list_count) return;
+  const int s = A.list[e];
+  const SrcPoint sp = A.src[s];
+  const int prev = A.m_to[s];
+  if (prev < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; A.d2lb[s] = 0.0f; return; }
+  double yx, yy, yz;
+  map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
+  Best b;
+  double second;
+  if (ball_search(A.g, A.to_pt, yx, yy, yz, prev, A.budget, A.max_rad, b, second)) {
+    A.m_to[s] = b.canon;
+    A.d2lb[s] = second_bound(b.d, second, A.g.h);
+  } else {
+    A.hard[atomicAdd(A.hard_count, 1)] = s;
+    A.d2lb[s] = 0.0f;
+  }
+}
+__global__ __launch_bounds__(kBallBlock) void k_match_list(BallArgs A) { match_list_body(A); }
+__global__ __launch_bounds__(kBallBlock) void k_match_list2(BallArgs A, BallArgs B) {
+  if (blockIdx.y == 0) match_list_body(A);
+  else match_list_body(B);
 }
 
 __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
@@ -942,12 +1039,18 @@ __device__ __forceinline__ void match_ball_body(const BallArgs &A) {
   A.slot[s] = active ? j : -1;
   if (!active) return;
   A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-  if (prev < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; return; }
+  if (prev < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; A.d2lb[s] = 0.0f; return; }
   double yx, yy, yz;
   map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
   Best b;
-  if (ball_search(g, A.to_pt, yx, yy, yz, prev, A.budget, A.max_rad, b)) A.m_to[s] = b.canon;
-  else A.hard[atomicAdd(A.hard_count, 1)] = s;  // m_to[s] keeps the previous match: a bound for phase 2
+  double second;
+  if (ball_search(g, A.to_pt, yx, yy, yz, prev, A.budget, A.max_rad, b, second)) {
+    A.m_to[s] = b.canon;
+    A.d2lb[s] = second_bound(b.d, second, g.h);
+  } else {
+    A.hard[atomicAdd(A.hard_count, 1)] = s;  // m_to[s] keeps the previous match: a bound for phase 2
+    A.d2lb[s] = 0.0f;                        // phase 2 leaves no bound: the next search of s is a full one
+  }
 }
 __global__ __launch_bounds__(kBallBlock) void k_match_ball(BallArgs A) { match_ball_body(A); }
 // both directions of a symmetric estimator in one launch: blockIdx.y picks the direction
@@ -967,7 +1070,7 @@ __global__ __launch_bounds__(kBallBlock) void k_match_ball2(BallArgs A, BallArgs
 // with the interior-face stopping rule.  Same exact nearest neighbour either way.
 __device__ __forceinline__ void wave_scan_runs(const GridView &g, int (*seg_s)[64], int (*seg_pre)[64], int wv,
                                                int lane, int s0, int e0, double yx, double yy, double yz,
-                                               Best &b) {
+                                               Best &b, int skip_canon, double &second) {
   int c0 = e0 - s0, incl = c0;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -981,6 +1084,7 @@ __device__ __forceinline__ void wave_scan_runs(const GridView &g, int (*seg_s)[6
   __builtin_amdgcn_wave_barrier();
   Best l;  // this lane's best in the chunk
   l.d = INFINITY; l.orig = 0x7fffffff; l.canon = 0;
+  double l2 = INFINITY;  // ... and the distance of its runner-up (second-nearest bound of the certificate)
   for (int c = lane; c < total; c += 64) {
     int lo = 0, hi = 64;  // last run whose exclusive prefix is <= c
 #pragma unroll
@@ -989,16 +1093,21 @@ __device__ __forceinline__ void wave_scan_runs(const GridView &g, int (*seg_s)[6
       if (seg_pre[wv][mid] <= c) lo = mid; else hi = mid;
     }
     GridPoint pt = g.gp[seg_s[wv][lo] + (c - seg_pre[wv][lo])];
-    consider(l, dist2(yx, yy, yz, pt.x, pt.y, pt.z), pt.orig, pt.canon);
+    if (pt.canon == skip_canon) continue;  // the point the search was seeded with (already in b)
+    const double d2 = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
+    if (d2 < l.d || (d2 == l.d && pt.orig < l.orig)) { l2 = fmin(l2, l.d); l.d = d2; l.orig = pt.orig; l.canon = pt.canon; }
+    else l2 = fmin(l2, d2);
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
-    double d2 = __shfl_xor(l.d, off, 64);
+    double d2 = __shfl_xor(l.d, off, 64), s2 = __shfl_xor(l2, off, 64);
     int o2 = __shfl_xor(l.orig, off, 64), c2 = __shfl_xor(l.canon, off, 64);
-    consider(l, d2, o2, c2);
+    if (d2 < l.d || (d2 == l.d && o2 < l.orig)) { l2 = fmin(fmin(l2, s2), l.d); l.d = d2; l.orig = o2; l.canon = c2; }
+    else l2 = fmin(fmin(l2, s2), d2);
   }
-  consider(b, l.d, l.orig, l.canon);
+  if (l.d < b.d || (l.d == b.d && l.orig < b.orig)) { second = fmin(fmin(second, l2), b.d); b = l; }
+  else second = fmin(fmin(second, l2), l.d);
 }
 
 struct HardArgs {  // one direction of the wave-per-query phase
@@ -1009,6 +1118,9 @@ struct HardArgs {  // one direction of the wave-per-query phase
   int use_prev;
   const GridPoint *to_pt;  // target points in canonical order
   int *m_to, *overflow, *overflow_count;
+  float *d2lb;  // second-nearest bounds of the queries settled through their previous match (may be null)
+  unsigned long long *stats;  // certificate statistics (lrr_icp_cert_stats): {sources seen, sources listed}; null = none
+  unsigned long long seen;
 };
 __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
   __shared__ int seg_s[kBlock / 64][64], seg_pre[kBlock / 64][64];
@@ -1021,6 +1133,10 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
   int *m_to = A.m_to, *overflow = A.overflow, *overflow_count = A.overflow_count;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
   const int cnt = *A.hard_count;
+  if (A.stats && blockIdx.x == 0 && threadIdx.x == 0) {  // hard_count[2]: what the certificate kernel listed
+    atomicAdd(&A.stats[0], A.seen);
+    atomicAdd(&A.stats[1], (unsigned long long)A.hard_count[2]);
+  }
   for (int o = wave; o < cnt; o += nwaves) {
     int s = hard[o];
     double yx, yy, yz;
@@ -1032,35 +1148,41 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
     b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
     bool done = false;
     int prev = use_prev ? m_to[s] : -1;
+    double second = INFINITY;  // smallest distance^2 among the other targets seen (prev branch: certificate bound)
     if (prev >= 0) {
       const GridPoint pq = A.to_pt[prev];
       b.d = dist2(yx, yy, yz, pq.x, pq.y, pq.z);
       b.orig = pq.orig;
       b.canon = prev;
-      double rad = sqrt(b.d) + 2.0 * g.tol;
+      // the ball is searched kBallMarginCells wider than the best distance: what is left out is provably
+      // farther than best + margin (second_bound)
+      const double margin = (double)kBallMarginCells * g.h;
+      double rad = sqrt(b.d) + 2.0 * g.tol + margin;
       int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
       int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
       int nyb = yb - ya + 1, nitems = (zb - za + 1) * nyb;
       {  // the rows of the ball, 64 at a time: exact whatever its size, so a query with a previous match never overflows
         for (int base = 0; base < nitems; base += 64) {
           int t = base + lane, s0 = 0, e0 = 0;
+          const double bm = sqrt(b.d) + margin, bm2 = bm * bm;
           if (t < nitems) {
             int z = za + t / nyb, y = ya + t % nyb;
             double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
             double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
             double dyz2 = gz_ * gz_ + gy_ * gy_;
-            if (dyz2 <= b.d) {
-              double rx = sqrt(b.d - dyz2) + 2.0 * g.tol;
+            if (dyz2 <= bm2) {
+              double rx = sqrt(bm2 - dyz2) + 2.0 * g.tol;
               int xa = clampi((int)floor((yx - rx - g.lox) * g.inv_h), 0, g.dx - 1);
               int xb = clampi((int)floor((yx + rx - g.lox) * g.inv_h), 0, g.dx - 1);
               int row = (z * g.dy + y) * g.dx;
               s0 = g.cell_start[row + xa]; e0 = g.cell_start[row + xb + 1];
             }
           }
-          wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b);
+          wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b, prev, second);
         }
         done = true;
       }
+      if (lane == 0 && A.d2lb) A.d2lb[s] = second_bound(b.d, second, g.h);
     }
     for (int r = 0; r <= kRingMax && !done; ++r) {
       const int side = 2 * r + 1, nitems = 2 * side * side;
@@ -1096,7 +1218,7 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
             }
           }
         }
-        wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b);
+        wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b, -1, second);
       }
       done = ring_settled(ring_bound(g, cx, cy, cz, r, yx, yy, yz), g.tol, b.d);
     }
@@ -1434,11 +1556,14 @@ __global__ void k_copy_w(const double *src, double *dst, int n) {
 }
 
 // matches_ in the reference's list order: (original from index, original to index, weight)
+// lazy: the last search ran at the finest level without materialising list positions (k_match_cert):
+// every source is active and its position is perm^-1(original index) under that search's keys
 __global__ void k_export(const int *slot, const int *m_to, const double *w, const int *from_orig,
-                         const int *to_orig, int nsrc, long long *out_from, long long *out_to, double *out_w) {
+                         const int *to_orig, int nsrc, long long *out_from, long long *out_to, double *out_w,
+                         int lazy, Keys keys, int half) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsrc) return;
-  int j = slot[s];
+  int j = lazy ? subset_perm_inv(from_orig[s], nsrc, half, keys) : slot[s];
   if (j < 0) return;
   out_from[j] = from_orig[s];
   out_to[j] = to_orig[m_to[s]];
@@ -2560,10 +2685,13 @@ int ensure_dir_capacity(lrr_icp_dir *d) {
   lrr_icp_ctx *ctx = d->ctx;
   int64_t need = std::max<int64_t>(d->from->n, 1);
   if (need <= d->cap) return LRR_ICP_OK;
-  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc};
+  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->d2lb};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   d->slot = d->m_to = nullptr; d->w = d->wc = d->r2 = d->key_g = d->key_s = d->from_loc = d->q_loc = nullptr;
+  d->d2lb = nullptr;
+  d->have_bounds = false;
   d->cap = 0;
+  HIPCHK(ctx, hipMalloc(&d->d2lb, sizeof(float) * need));
   HIPCHK(ctx, hipMalloc(&d->slot, sizeof(int) * need));
   HIPCHK(ctx, hipMalloc(&d->m_to, sizeof(int) * need));
   HIPCHK(ctx, hipMalloc(&d->w, sizeof(double) * need));
@@ -2613,8 +2741,11 @@ int fresh_counts(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, int **counts) {
 
 // phases 2 and 3 of the grid search; both read their list length on the device and fall through
 // when it is 0
-HardArgs hard_args(K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int *m_to, int *counts) {
+HardArgs hard_args(K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int *m_to, int *counts,
+                   float *d2lb = nullptr) {
   HardArgs a;
+  a.d2lb = d2lb;
+  a.stats = nullptr; a.seen = 0;
   a.g = g; a.q = q; a.xf = xf;
   a.hard = L.d_hard; a.hard_count = counts;
   a.use_prev = q.src ? 1 : 0;
@@ -2636,8 +2767,10 @@ inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(1024, std:
 // (n_points == N twice in a row): at a dense sub-full level the keyed subset changes with every
 // search, sources that were never matched enter phase 2 without a bound, walk the rings and may end
 // in the overflow list, which phase 3 must then serve.
-int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts, bool all_have_prev) {
-  HardArgs h = hard_args(L, to, g, q, xf, m_to, counts);
+int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts, bool all_have_prev,
+                       float *d2lb = nullptr, bool cert = false) {
+  HardArgs h = hard_args(L, to, g, q, xf, m_to, counts, d2lb);
+  if (cert && ctx->prof) { h.stats = ctx->d_cert_stats; h.seen = (unsigned long long)n; }
   hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n)), dim3(kBlock), 0, st, h);
   HIPCHK(ctx, hipGetLastError());
   if (all_have_prev) return LRR_ICP_OK;
@@ -2750,6 +2883,8 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_seq_dev, ctx->h_seq, 0)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_done, sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMemset(ctx->d_done, 0, sizeof(int))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_cert_stats, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e);
+  if ((e = hipMemset(ctx->d_cert_stats, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selstate, sizeof(SelState) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selhist, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
   if ((e = hipMemset(ctx->d_selhist, 0, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
@@ -2785,6 +2920,7 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->h_fused) (void)hipHostFree(ctx->h_fused);
   if (ctx->h_seq) (void)hipHostFree(ctx->h_seq);
   if (ctx->d_done) (void)hipFree(ctx->d_done);
+  if (ctx->d_cert_stats) (void)hipFree(ctx->d_cert_stats);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -2825,6 +2961,18 @@ int lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_
     for (auto &ev : ctx->pe) HIPCHK(ctx, hipEventCreate(&ev));
   }
   ctx->prof = enable != 0;
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_cert_stats(lrr_icp_ctx *ctx, int64_t *queries, int64_t *searched, int reset) {
+  if (!ctx) return LRR_ICP_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long v[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpy(v, ctx->d_cert_stats, sizeof v, hipMemcpyDeviceToHost));
+  if (queries) *queries = (int64_t)v[0];
+  if (searched) *searched = (int64_t)v[1];
+  if (reset) HIPCHK(ctx, hipMemset(ctx->d_cert_stats, 0, sizeof v));
   return LRR_ICP_OK;
 }
 
@@ -3008,7 +3156,7 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
 void lrr_icp_dir_destroy(lrr_icp_dir *d) {
   if (!d) return;
   if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
-  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->flag};
+  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->flag, d->d2lb};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete d;
 }
@@ -3021,6 +3169,8 @@ int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
   d->from = from;
   d->n = 0;
   d->prev_n = -1;
+  d->have_bounds = false;
+  d->slot_lazy = false;
   d->from_is_copy = 0;
   int rc = ensure_dir_capacity(d);
   if (rc) return rc;
@@ -3069,6 +3219,8 @@ struct MatchPrep {
   int *counts = nullptr;
   int64_t N = 0;
   bool dense = false, steady = false, use_keys = false, empty = false;
+  bool cert = false;      // finest level with second-nearest bounds from the previous search: certificate kernel
+  lrr_icp_xform prev_xf;  // transform of that search
   int method = LRR_ICP_NN_GRID;
 };
 
@@ -3128,6 +3280,15 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   // a level's later iterations: every active source carries its previous match -> ball search
   P.steady = P.method == LRR_ICP_NN_GRID && P.dense && d->prev_n == n_points;
   if (P.method == LRR_ICP_NN_GRID) d->prev_n = P.dense ? n_points : -1;
+  // bounds are per source and refer to the transform of the search that wrote them: usable only when that
+  // search covered every source (n_points == N twice in a row)
+  static const bool no_cert = std::getenv("LRR_ICP_NO_CERT") != nullptr;
+  P.cert = P.steady && n_points == N && d->have_bounds && !no_cert;
+  P.prev_xf = d->prev_xf;
+  d->have_bounds = P.steady && n_points == N;  // the ball kernels (with or without certificate) leave bounds
+  d->prev_xf = *xf;
+  d->slot_lazy = P.cert;
+  if (P.cert) { for (int r = 0; r < 4; ++r) d->slot_keys[r] = P.kk.k[r]; d->slot_half = P.half; }
   return LRR_ICP_OK;
 }
 
@@ -3137,8 +3298,12 @@ static BallArgs ball_args(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L) {
   a.xf = P.x; a.to_pt = d->to->cpt;
   a.slot = d->slot; a.m_to = d->m_to; a.w = d->w; a.hard = L.d_hard; a.hard_count = P.counts;
   a.budget = kBallBudget; a.max_rad = kBallCells * P.g.h;
+  a.d2lb = d->d2lb;
+  a.xf_prev = to_dev(&P.prev_xf);
+  a.list = L.d_active; a.list_count = P.counts + 2;
   return a;
 }
+inline unsigned cert_blocks_for(int64_t n) { return (unsigned)((((n + kCertBlock - 1) / kCertBlock) + 7) / 8 * 8); }
 
 // the launches of one prepared submission on stream st
 static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream_t st) {
@@ -3155,7 +3320,12 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     HIPCHK(ctx, hipGetLastError());
     return launch_brute(ctx, L, st, d->to, P.g, P.q, L.d_active, P.x, (int)n_points, d->m_to);
   }
-  if (P.steady) {
+  if (P.cert) {
+    BallArgs a = ball_args(d, P, L);
+    hipLaunchKernelGGL(k_match_cert, dim3(cert_blocks_for(N)), dim3(kCertBlock), 0, st, a);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_match_list, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, a);
+  } else if (P.steady) {
     hipLaunchKernelGGL(k_match_ball, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, ball_args(d, P, L));
   } else if (P.dense) {
     hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, P.g, d->from->src, d->from->chunks, P.kk, P.half, (int)N, (int)n_points, P.x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, L.d_hard, P.counts, kTileBudget);
@@ -3164,7 +3334,7 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, P.counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady && n_points == N);
+  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady && n_points == N, d->d2lb, P.cert);
 }
 
 // one K1 submission on lane L and its stream
@@ -3207,10 +3377,22 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     if (Pf.steady && Pb.steady) {
       ProfScope prof(ctx, st, 2);
       BallArgs af = ball_args(f, Pf, ctx->lane[0]), ab = ball_args(b, Pb, ctx->lane[1]);
-      hipLaunchKernelGGL(k_match_ball2, dim3(ball_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBallBlock), 0, st, af, ab);
+      if (Pf.cert && Pb.cert) {
+        hipLaunchKernelGGL(k_match_cert2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(k_match_list2, dim3(ball_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBallBlock), 0, st, af, ab);
+      } else {
+        // one of the two has no bounds yet: both take the plain ball search (which writes real slots)
+        f->slot_lazy = b->slot_lazy = false;
+        hipLaunchKernelGGL(k_match_ball2, dim3(ball_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBallBlock), 0, st, af, ab);
+      }
       HIPCHK(ctx, hipGetLastError());
-      HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);
-      HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
+      HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts, f->d2lb);
+      HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts, b->d2lb);
+      if (Pf.cert && Pb.cert && ctx->prof) {
+        hf.stats = hb.stats = ctx->d_cert_stats;
+        hf.seen = (unsigned long long)Pf.N; hb.seen = (unsigned long long)Pb.N;
+      }
       hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
       HIPCHK(ctx, hipGetLastError());
       // no phase 3 when both whole clouds were matched last time: every query then carries a previous
@@ -3759,7 +3941,10 @@ int lrr_icp_get_matches(lrr_icp_dir *d, int64_t *from_idx, int64_t *to_idx, doub
     rc = fail(ctx, LRR_ICP_ERR_HIP, "get_matches: hipMalloc failed");
   if (!rc) {
     int nsrc = (int)d->from->n;
-    hipLaunchKernelGGL(k_export, dim3(blocks_for(nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->m_to, d->w, d->from->orig_of, d->to->orig_of, nsrc, df, dt, dw);
+    Keys kk;
+    for (int r = 0; r < 4; ++r) kk.k[r] = d->slot_keys[r];
+    hipLaunchKernelGGL(k_export, dim3(blocks_for(nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->m_to, d->w, d->from->orig_of, d->to->orig_of, nsrc, df, dt, dw,
+                       d->slot_lazy ? 1 : 0, kk, d->slot_half);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "get_matches: export failed");
   }
   static_assert(sizeof(long long) == sizeof(int64_t), "int64 layout");

@@ -25,7 +25,7 @@ _ip = C.POINTER(C.c_int64)
 # every symbol include/lrr_icp.h declares
 ICP_SYMBOLS = [
     "lrr_icp_create", "lrr_icp_destroy", "lrr_icp_last_error", "lrr_icp_synchronize",
-    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile",
+    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile", "lrr_icp_cert_stats",
     "lrr_icp_cloud_create", "lrr_icp_cloud_destroy", "lrr_icp_cloud_size",
     "lrr_icp_dir_create", "lrr_icp_dir_destroy", "lrr_icp_dir_set_from", "lrr_icp_dir_num_matches",
     "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
@@ -73,6 +73,7 @@ def hip_lib() -> C.CDLL:
         L.lrr_icp_timer_start.argtypes = [C.c_void_p]
         L.lrr_icp_timer_stop.argtypes = [C.c_void_p, _dp]
         L.lrr_icp_match_profile.argtypes = [C.c_void_p, C.c_int, _dp, _ip, C.c_int]
+        L.lrr_icp_cert_stats.argtypes = [C.c_void_p, _ip, _ip, C.c_int]
         L.lrr_icp_cloud_create.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, C.c_int, C.POINTER(C.c_void_p)]
         L.lrr_icp_cloud_destroy.argtypes = [C.c_void_p]
         L.lrr_icp_cloud_size.argtypes = [C.c_void_p]
@@ -198,6 +199,13 @@ class DeviceTimer:
 
     def synchronize(self):
         self.L.lrr_icp_synchronize(self.ctx)
+
+    def cert_stats(self, reset=False):
+        """(sources seen by the K1 certificate kernel, sources it had to search) since the last reset"""
+        q, f = C.c_int64(0), C.c_int64(0)
+        if self.L.lrr_icp_cert_stats(self.ctx, C.byref(q), C.byref(f), int(reset)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+        return q.value, f.value
 
 
 class DeviceCloud:
