@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--n", type=int, default=N_FEATURES, help="features per volume (default: BASELINE size)")
     ap.add_argument("--nn", choices=["grid", "brute"], default="grid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=60)
+    ap.add_argument("--cpu-iters", type=int, default=24, help="finest-level oracle iterations of the single-thread CPU baseline")
+    ap.add_argument("--no-schedule", action="store_true", help="skip the faithful 1000 -> N schedule run")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on fewer GPUs)")
     ap.add_argument("--workload", choices=["c3", "locations"], default="c3",
@@ -54,38 +55,130 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(pair, T0, n, iters):
-    """The CPU oracle (reference restatement; kd-tree NN like the reference's rsdl_kd_tree path),
-    1 thread as the reference is single-threaded (rrl sym .txx:760), on a bounded sample of the
-    same workload: `iters` finest-level symmetric iterations."""
+def _oracle_iterations(pair, T0, n, iters, nn_backend, out, k):
     from oracle import binding as ob
     e = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
-                           moving_inside=pair.moving, fixed_inside=pair.fixed, seed=7, nn_backend=ob.NN_KDTREE)
+                           moving_inside=pair.moving, fixed_inside=pair.fixed, seed=7 + k, nn_backend=nn_backend)
     e.set_number_points(10**9)  # finest level directly
     e.one_iteration(0)          # warm-up (includes the MUSE scale)
     t0 = time.perf_counter()
     for it in range(iters):
         e.one_iteration(it + 1)
-    dt = time.perf_counter() - t0
+    out[k] = (time.perf_counter() - t0, t0)
+    e.close()
+
+
+def cpu_baseline(pair, T0, n, iters):
+    """The CPU oracle (reference restatement) on bounded samples of the same workload, on the GPU box's host cores:
+    * value: finest-level symmetric iterations with the kd-tree matcher (the cdcl classes' rsdl_kd_tree path),
+      1 thread — the reference is single-threaded (rrl sym .txx:760);
+    * all_cores: the same iterations run concurrently on independent copies of the problem, one per core (ctypes
+      releases the GIL): the all-core throughput of independent estimates;
+    * brute: the all-vs-all matcher alone on a sample of the queries, extrapolated to one iteration's matching.
+    The production rrl class uses neither: it looks matches up in a precomputed 1 mm Voronoi volume (O(1) per
+    query; not restated)."""
+    import threading
+
+    from oracle import binding as ob
+    res = {}
+    _oracle_iterations(pair, T0, n, iters, ob.NN_KDTREE, res, 0)
+    dt = res[0][0]
     pairs = iters * 2 * n
-    return {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-            "ms_per_iteration": 1e3 * dt / iters,
-            "sample": f"{iters} finest-level symmetric iterations of the same {n}x{n} workload "
-                      f"(C oracle, kd-tree NN, {dt:.1f} s)"}
+    out = {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+           "matcher": "kd-tree (exact, as rsdl_kd_tree of the cdcl classes; the rrl classes' Voronoi-volume lookup is not restated)",
+           "ms_per_iteration": 1e3 * dt / iters,
+           "sample": f"{iters} finest-level symmetric iterations of the same {n}x{n} workload "
+                     f"(C oracle, kd-tree NN, {dt:.1f} s)"}
+    # all cores: independent problems side by side
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box gives one GPU's share of the host: 16 cores
+    it2 = max(2, iters // 4)
+    res, th = {}, []
+    t0 = time.perf_counter()
+    for k in range(cores):
+        th.append(threading.Thread(target=_oracle_iterations, args=(pair, T0, n, it2, ob.NN_KDTREE, res, k)))
+        th[-1].start()
+    for t in th:
+        t.join()
+    span = max(r[1] + r[0] for r in res.values()) - min(r[1] for r in res.values())  # timed regions only
+    out["all_cores"] = {"value": cores * it2 * 2 * n / span, "unit": "pairs/s", "cores": cores,
+                        "sample": f"{cores} independent copies of the workload, {it2} finest-level iterations each, one thread per copy ({span:.1f} s)"}
+    # brute force: the matcher alone, sampled
+    nq = 1500
+    q = pair.planted.map(pair.moving.loc[:nq])
+    t0 = time.perf_counter()
+    ob.nn(pair.fixed.loc, q, ob.NN_BRUTE)
+    tb = time.perf_counter() - t0
+    out["brute"] = {"value": nq / tb, "unit": "matched pairs/s (matching only)", "cores": 1,
+                    "ms_per_iteration_matching_extrapolated": 1e3 * tb / nq * 2 * n,
+                    "sample": f"all-vs-all nearest neighbour of {nq} of the {n} queries against {n} targets ({tb:.2f} s), "
+                              "extrapolated linearly to the 2 x n queries of an iteration"}
+    return out
 
 
-def pmc_traffic(args):
-    """HBM bytes per K1 launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the
-    gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE as is).  Counters cannot be collected from inside
-    this process; the value is the one measured on this code at the BASELINE size with the grid
-    matcher (profiles/pmc_traffic.json), null for any other configuration."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def code_stamp():
+    """sha256 (16 hex) of the kernel sources: ties committed PMC measurements to the code they were taken on
+    (.git does not travel to the GPU box)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("lrr_icp.hip", "lrr_icp_batch.inc"):
+        with open(os.path.join(ROOT, "lrr_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_file(args, name):
+    """A committed PMC measurement (profiles/<name>), or None when it was not taken on THIS code (code_stamp) or
+    at another configuration: counters cannot be collected from inside this process."""
+    path = os.path.join(ROOT, "profiles", name)
     if args.nn != "grid" or args.n != N_FEATURES or not os.path.exists(path):
         return None
     try:
-        return float(json.load(open(path))["traffic_bytes_per_launch"])
+        d = json.load(open(path))
     except Exception:
         return None
+    return d if d.get("code_sha") == code_stamp() else None
+
+
+def schedule_run(E, pair, T0, nn, timer):
+    """The faithful run: 1000 -> 2000 -> ... -> N points, every level to its convergence test, then the finest level
+    to convergence (<= 70 iterations, the caller's limit).  Per iteration: wall time and K1 time (HIP events)."""
+    import torch
+    est = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                      moving_inside=pair.moving, fixed_inside=pair.fixed, seed=7, nn_method=nn)
+    n = pair.moving.n
+    rows, conv, it = [], False, 0
+    timer.match_profile(enable=True, reset=True)
+    timer.synchronize()
+    t_all = time.perf_counter()
+    while not conv and it < 70:
+        npts = est.number_points(0)
+        t0 = time.perf_counter()
+        conv = est.one_iteration(it)
+        timer.synchronize()
+        wall = time.perf_counter() - t0
+        k1, launches = timer.match_profile(enable=True, reset=True)
+        rows.append((npts, 1e3 * wall, k1 / max(launches, 1)))
+        it += 1
+    total = time.perf_counter() - t_all
+    timer.match_profile(enable=False, reset=True)
+    est.close()
+    npts = np.array([r[0] for r in rows]); wall = np.array([r[1] for r in rows]); k1 = np.array([r[2] for r in rows])
+    first = np.r_[True, npts[1:] != npts[:-1]]
+    coarse, finest = npts * 4 < n, npts == n
+    def mean(mask, v):
+        return float(v[mask].mean()) if mask.any() else None
+    return {"iterations": it, "converged": bool(conv), "total_ms": 1e3 * total, "levels": int(first.sum()),
+            "matched_pairs": int(2 * npts.sum()),
+            "k1_ms_per_direction": {"coarse_levels": mean(coarse, k1), "dense_levels_first_search": mean(~coarse & first, k1),
+                                    "dense_levels_later_searches": mean(~coarse & ~first & ~finest, k1),
+                                    "finest_level_first_search": mean(finest & first, k1),
+                                    "finest_level_later_searches": mean(finest & ~first, k1)},
+            "iteration_ms": {"coarse_levels": mean(coarse, wall), "finest_level": mean(finest, wall)},
+            "per_iteration": [{"n_points": int(a), "ms": round(float(b), 4), "k1_ms_per_direction": round(float(c), 5)} for a, b, c in rows]}
 
 
 def bench_locations(args, rank, local_rank, world):
@@ -206,15 +299,20 @@ def main():
         torch.cuda.synchronize()
         timer.synchronize()
 
+    # the timed region: K steps between barriers, repeated `reps` times; the MEDIAN repetition is reported
+    reps = max(1, args.reps)
+    times = []
     timer.match_profile(enable=True, reset=True)
     timer.cert_stats(reset=True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        est.one_iteration(it)
-        it += 1
-    barrier()
-    dt = time.perf_counter() - t0
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            est.one_iteration(it)
+            it += 1
+        barrier()
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
     match_ms, match_launches = timer.match_profile(enable=False, reset=False)
     cert_seen, cert_searched = timer.cert_stats()
 
@@ -236,7 +334,9 @@ def main():
         n_dir = n_pairs_step // 2
         k1_bytes = n_dir * K1_BYTES_PER_PAIR_FIXED + 24.0 * n  # per launch: n_dir queries vs one n-point cloud
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        traffic = pmc_traffic(args)  # measured HBM bytes per launch (PMC), for the bandwidth actually drawn
+        pt, pu = pmc_file(args, "pmc_traffic.json"), pmc_file(args, "pmc_utilisation.json")
+        traffic = float(pt["traffic_bytes_per_launch"]) if pt else None  # measured HBM bytes per launch (PMC), null when not taken on this code
+        valu_frac = float(pu["valu_frac"]) if pu else None
         out = {
             "metric": "ICP matched-feature-pairs/sec",
             "value": value,
@@ -255,11 +355,13 @@ def main():
                                    f"{n_pairs_step} matched pairs per step per GPU",
                        "nn": args.nn, "schedule_iterations_before_timing": schedule_iters,
                        "parallelism": f"{world} independent problem(s), one per GPU; one all_gather of the final transforms"},
+            "repetitions": reps, "seconds_all": times, "code_sha": code_stamp(),
             "roofline": {"bound": "hbm",
-                         "kernel": ("K1 find_closest_euclidean = k_match_ball2 + k_match_hard2: every phase "
-                                    "handles the forward and the backward search in one launch (lrr_icp_match_pair); "
-                                    "kernel_ms = HIP-event time of the pair / 2 = one direction"
+                         "kernel": ("K1 find_closest_euclidean at the finest level = k_match_cert2 (certificate pass) + k_match_list2 + "
+                                    "k_match_hard2: every phase handles the forward and the backward search in one launch "
+                                    "(lrr_icp_match_pair); kernel_ms = HIP-event time of the pair / 2 = one direction"
                                     if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
+                         "valu_frac": valu_frac,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_GBs": (traffic / (k1_ms * 1e-3) / 1e9) if (traffic and k1_ms > 0) else None,
@@ -273,6 +375,8 @@ def main():
             "upload_s": upload_s,
             "final_weighted_error": float(rows[0, 17]),
         }
+        if world == 1 and not args.no_schedule:
+            out["schedule"] = schedule_run(E, pair, T0, nn, timer)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pair, T0, n, args.cpu_iters)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()

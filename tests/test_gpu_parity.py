@@ -356,6 +356,56 @@ def test_dense_subfull_level_with_unreachable_queries(E, ob):
     g.close()
 
 
+def test_certificate_skips_only_provable_matches(E, ob):
+    """K1 at the finest level keeps the previous match of a source without searching when a second-nearest bound
+    proves it is still the unique nearest neighbour.  Sequences of searches whose transform moves by 0, 1e-7, 1e-4,
+    1e-2 and 0.3 mm (rotation included), on a noisy cloud pair and on a lattice pair full of exact ties (a tie can
+    never be certified): every search equals the oracle's, and the certificate did skip most searches of the small
+    steps."""
+    timer = E.DeviceTimer()
+    rng = np.random.default_rng(8)
+
+    def run(mv, fx, steps, expect_skips):
+        I, z = np.eye(3), np.zeros(3)
+        g = E.Estimator(E.RRL_SYMMETRIC, 12, mv, fx, I, z, z, moving_inside=mv, fixed_inside=fx, seed=9)
+        c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, mv, fx, I, z, z, moving_inside=mv, fixed_inside=fx, seed=9)
+        timer.match_profile(enable=True, reset=True)
+        timer.cert_stats(reset=True)
+        T = synth.Transform(synth.rotation_xyz(0.01, -0.02, 0.015), np.array([0.3, -0.2, 0.1]), np.array([5.0, 5.0, 5.0]))
+        for k, step in enumerate(steps):
+            d = rng.normal(size=3)
+            d *= step / np.linalg.norm(d)
+            T = synth.Transform(synth.rotation_xyz(step * 1e-3, 0, -step * 2e-3) @ T.A, T.t + d, T.c)
+            for e in (g, c):
+                e.set_transform(T.A, T.t, T.c)
+                e.set_number_points(10**9)
+                e.find_closest_euclidean()
+            for dr in (0, 1):
+                fg, tg, _ = g.matches(dr)
+                fc, tc, _ = c.matches(dr)
+                assert np.array_equal(fg, fc) and np.array_equal(tg, tc), (k, step, dr)
+        seen, searched = timer.cert_stats()
+        timer.match_profile(enable=False)
+        g.close()
+        assert seen > 0
+        if expect_skips:
+            assert searched < 0.5 * seen, (seen, searched)
+        return seen, searched
+
+    pair = synth.make_pair(30000, 30000, 404, kind="affine")
+    run(pair.moving, pair.fixed, [0.0, 0.0, 0.0, 1e-7, 1e-7, 1e-4, 1e-4, 1e-2, 1e-2, 0.3, 0.3, 0.0, 1e-7], True)
+    # lattice with duplicates: every query has exactly equidistant targets or a duplicate runner-up
+    floc = rng.integers(0, 14, size=(9000, 3)).astype(np.float64)
+    mloc = rng.integers(0, 14, size=(8000, 3)).astype(np.float64) + 0.5
+
+    def feats(loc):
+        n = loc.shape[0]
+        return synth.FeatureSet(loc, np.tile(np.eye(3).ravel(), (n, 1)), np.ones(n), np.full(n, 2, np.uint8),
+                                np.tile(np.array([0, 0, 1.0, 1.0, 0, 0]), (n, 1)))
+    seen, searched = run(feats(mloc), feats(floc), [0.0, 0.0, 0.0, 1e-9, 0.0, 0.25, 0.0, 0.0], False)
+    assert searched > 0.9 * seen * 5 / 8  # ties are never certified (the first two searches do not run the kernel)
+
+
 def test_match_ties_through_every_search_path(E, ob):
     """lattice clouds with duplicate points under exact half-cell translations: every query has
     several exactly equidistant targets.  The first search of a level (tile kernel), the later ones
