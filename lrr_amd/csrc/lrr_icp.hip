@@ -193,6 +193,10 @@ struct lrr_icp_dir {
   bool slot_lazy = false;
   unsigned slot_keys[4] = {0, 0, 0, 0};
   int slot_half = 1;
+  // the counter of the sources the last certificate kernel listed (device), and its value as the estimate that
+  // followed read it back (-1: unknown): a short list goes straight to the wave-per-query kernel
+  const int *cert_list_count = nullptr;
+  int last_list_count = -1;
 };
 
 namespace {
@@ -391,15 +395,22 @@ __device__ __forceinline__ void block_sum_all(double (&v)[K]) {
 // synchronisation, no copy in between.
 // The block that finishes last then stores the submission's sequence number in a mapped host word:
 // the host polls that word (half the latency of a stream synchronisation, measured 6.9 vs 12.6 us).
+// cnt_a / cnt_b (may be null): two device counters forwarded behind the K results (how many sources the last K1
+// certificate kernels listed: the host sizes the next search with them)
 __global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, int nblocks, int K, double *out,
                                                         const double *fwd, int head, double *host, int *done,
-                                                        volatile unsigned long long *host_seq, unsigned long long seq) {
+                                                        volatile unsigned long long *host_seq, unsigned long long seq,
+                                                        const int *cnt_a = nullptr, const int *cnt_b = nullptr) {
   int k = blockIdx.x;
   double s = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * K + k];
   s = wave_sum(s);
   if (threadIdx.x == 0) { out[k] = s; host[head + k] = s; }
   if (k == 0) for (int t = threadIdx.x; t < head; t += 64) host[t] = fwd[t];
+  if (k == 0 && threadIdx.x == 0) {
+    host[head + K] = cnt_a ? (double)*cnt_a : -1.0;
+    host[head + K + 1] = cnt_b ? (double)*cnt_b : -1.0;
+  }
   __threadfence_system();  // this block's host stores are visible before it is counted
   if (threadIdx.x == 0 && atomicAdd(done, 1) == K - 1) {
     *done = 0;  // ready for the next submission (same stream: nothing runs in between)
@@ -966,6 +977,7 @@ __device__ __forceinline__ float second_bound(double best_d2, double second_d2, 
 // stays active and its list position is re-derived from the permutation keys when matches are exported
 // (k_export).
 constexpr int kCertBlock = 256;
+constexpr int kShortList = 4096;  // listed sources up to which the wave-per-query kernel alone serves the list
 __device__ __forceinline__ void match_cert_body(const BallArgs &A) {
   const int per = (int)gridDim.x >> 3;
   const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -1121,6 +1133,7 @@ struct HardArgs {  // one direction of the wave-per-query phase
   float *d2lb;  // second-nearest bounds of the queries settled through their previous match (may be null)
   unsigned long long *stats;  // certificate statistics (lrr_icp_cert_stats): {sources seen, sources listed}; null = none
   unsigned long long seen;
+  const int *listed;          // the certificate kernel's list counter
 };
 __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
   __shared__ int seg_s[kBlock / 64][64], seg_pre[kBlock / 64][64];
@@ -1133,9 +1146,9 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
   int *m_to = A.m_to, *overflow = A.overflow, *overflow_count = A.overflow_count;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
   const int cnt = *A.hard_count;
-  if (A.stats && blockIdx.x == 0 && threadIdx.x == 0) {  // hard_count[2]: what the certificate kernel listed
+  if (A.stats && blockIdx.x == 0 && threadIdx.x == 0) {
     atomicAdd(&A.stats[0], A.seen);
-    atomicAdd(&A.stats[1], (unsigned long long)A.hard_count[2]);
+    atomicAdd(&A.stats[1], (unsigned long long)*A.listed);
   }
   for (int o = wave; o < cnt; o += nwaves) {
     int s = hard[o];
@@ -2745,7 +2758,7 @@ HardArgs hard_args(K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const 
                    float *d2lb = nullptr) {
   HardArgs a;
   a.d2lb = d2lb;
-  a.stats = nullptr; a.seen = 0;
+  a.stats = nullptr; a.seen = 0; a.listed = counts + 2;
   a.g = g; a.q = q; a.xf = xf;
   a.hard = L.d_hard; a.hard_count = counts;
   a.use_prev = q.src ? 1 : 0;
@@ -2768,9 +2781,10 @@ inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(1024, std:
 // search, sources that were never matched enter phase 2 without a bound, walk the rings and may end
 // in the overflow list, which phase 3 must then serve.
 int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts, bool all_have_prev,
-                       float *d2lb = nullptr, bool cert = false) {
+                       float *d2lb = nullptr, bool cert = false, bool short_list = false) {
   HardArgs h = hard_args(L, to, g, q, xf, m_to, counts, d2lb);
   if (cert && ctx->prof) { h.stats = ctx->d_cert_stats; h.seen = (unsigned long long)n; }
+  if (short_list) { h.hard = L.d_active; h.hard_count = counts + 2; }  // the certificate kernel's list itself
   hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n)), dim3(kBlock), 0, st, h);
   HIPCHK(ctx, hipGetLastError());
   if (all_have_prev) return LRR_ICP_OK;
@@ -3220,6 +3234,7 @@ struct MatchPrep {
   int64_t N = 0;
   bool dense = false, steady = false, use_keys = false, empty = false;
   bool cert = false;      // finest level with second-nearest bounds from the previous search: certificate kernel
+  bool short_list = false;  // ... whose list was short last time: the listed sources go straight to the wave-per-query kernel
   lrr_icp_xform prev_xf;  // transform of that search
   int method = LRR_ICP_NN_GRID;
 };
@@ -3289,6 +3304,9 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   d->prev_xf = *xf;
   d->slot_lazy = P.cert;
   if (P.cert) { for (int r = 0; r < 4; ++r) d->slot_keys[r] = P.kk.k[r]; d->slot_half = P.half; }
+  P.short_list = P.cert && d->last_list_count >= 0 && d->last_list_count <= kShortList;
+  d->cert_list_count = P.cert ? P.counts + 2 : nullptr;
+  d->last_list_count = -1;
   return LRR_ICP_OK;
 }
 
@@ -3324,7 +3342,7 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     BallArgs a = ball_args(d, P, L);
     hipLaunchKernelGGL(k_match_cert, dim3(cert_blocks_for(N)), dim3(kCertBlock), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_match_list, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, a);
+    if (!P.short_list) hipLaunchKernelGGL(k_match_list, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, a);
   } else if (P.steady) {
     hipLaunchKernelGGL(k_match_ball, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, ball_args(d, P, L));
   } else if (P.dense) {
@@ -3334,7 +3352,7 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, P.counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady && n_points == N, d->d2lb, P.cert);
+  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady && n_points == N, d->d2lb, P.cert, P.short_list);
 }
 
 // one K1 submission on lane L and its stream
@@ -3380,7 +3398,10 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       if (Pf.cert && Pb.cert) {
         hipLaunchKernelGGL(k_match_cert2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
         HIPCHK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(k_match_list2, dim3(ball_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBallBlock), 0, st, af, ab);
+        if (!(Pf.short_list && Pb.short_list)) {
+          Pf.short_list = Pb.short_list = false;
+          hipLaunchKernelGGL(k_match_list2, dim3(ball_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBallBlock), 0, st, af, ab);
+        }
       } else {
         // one of the two has no bounds yet: both take the plain ball search (which writes real slots)
         f->slot_lazy = b->slot_lazy = false;
@@ -3392,6 +3413,10 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       if (Pf.cert && Pb.cert && ctx->prof) {
         hf.stats = hb.stats = ctx->d_cert_stats;
         hf.seen = (unsigned long long)Pf.N; hb.seen = (unsigned long long)Pb.N;
+      }
+      if (Pf.cert && Pb.cert && Pf.short_list && Pb.short_list) {  // the certificate kernel's lists themselves
+        hf.hard = ctx->lane[0].d_active; hf.hard_count = Pf.counts + 2;
+        hb.hard = ctx->lane[1].d_active; hb.hard_count = Pb.counts + 2;
       }
       hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
       HIPCHK(ctx, hipGetLastError());
@@ -3762,10 +3787,14 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   else hipLaunchKernelGGL((k_f_accumulate<6, false>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   HIPCHK(ctx, hipGetLastError());
   const unsigned long long seq = ++ctx->seq;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq,
+                     F->cert_list_count, B->cert_list_count);
   HIPCHK(ctx, hipGetLastError());
   { int rc = wait_results(ctx, seq); if (rc) return rc; }
   const double *h = ctx->h_fused;
+  if (F->cert_list_count) F->last_list_count = (int)h[FIN_OFF + K];
+  if (B->cert_list_count) B->last_list_count = (int)h[FIN_OFF + K + 1];
+  F->cert_list_count = B->cert_list_count = nullptr;  // the counter slots are recycled
   for (int k = 0; k < 3; ++k) { out->norm.cm[k] = h[SC_CM + k]; out->norm.cf[k] = h[SC_CF + k]; }
   out->norm.rm = h[SC_RM]; out->norm.rf = h[SC_RF];
   out->sigma_f = h[SC_SIGF]; out->sigma_b = h[SC_SIGB];
@@ -3910,10 +3939,13 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   else hipLaunchKernelGGL((k_fw_accumulate<6>), dim3(nbA), dim3(kBlock), 0, st, aF, fo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   HIPCHK(ctx, hipGetLastError());
   const unsigned long long seq = ++ctx->seq;
-  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbA, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbA, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq,
+                     F->cert_list_count, (const int *)nullptr);
   HIPCHK(ctx, hipGetLastError());
   { int rc = wait_results(ctx, seq); if (rc) return rc; }
   const double *h = ctx->h_fused;
+  if (F->cert_list_count) F->last_list_count = (int)h[FIN_OFF + K];
+  F->cert_list_count = nullptr;
   for (int k = 0; k < 3; ++k) { out->norm.cm[k] = h[SC_CM + k]; out->norm.cf[k] = h[SC_CF + k]; }
   out->norm.rm = h[SC_RM]; out->norm.rf = h[SC_RF];
   out->sigma_f = h[SC_SIGF]; out->sigma_b = 0.0;
