@@ -50,6 +50,8 @@ namespace {
 
 constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kMaxBlocks = 2048;     // reduction grids: 8 blocks / CU on 256 CUs (one dependent gather chain per thread)
+constexpr int kWide = 1024;          // block size of the fused estimate's streaming passes: at most kWideBlocks of them, so a
+constexpr int kWideBlocks = 256;     // consumer's prologue sums <= 256 rows of producer partials (one block per CU, 16 waves each)
 constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 for dof 12)
 constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
 constexpr int kTile = 8;             // canonical order: tiles of kTile^3 grid cells
@@ -322,9 +324,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // (the normal equations: 90): a shuffle tree per value costs 12 cross-lane operations each, so the
 // wave transposes 16 values at a time through LDS instead — lane (part, k) adds value k of 16
 // lanes in lane order, two shuffles join the four parts — then the 4 waves in index order.
-template <int K>
+template <int K, int NW = kBlock / 64>
 __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *partials) {
-  __shared__ double red[kBlock / 64][K];
+  __shared__ double red[NW][K];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if constexpr (K <= 8) {
 #pragma unroll
@@ -334,7 +336,7 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *parti
     }
   } else {
     constexpr int C = 16;
-    __shared__ double tr[kBlock / 64][C][65];  // [value][lane], rows padded against bank conflicts
+    __shared__ double tr[NW][C][65];  // [value][lane], rows padded against bank conflicts
     const int kk = lane & 15, part = lane >> 4;
 #pragma unroll
     for (int c0 = 0; c0 < K; c0 += C) {
@@ -352,10 +354,10 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *parti
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < K; k += kBlock) {
+  for (int k = threadIdx.x; k < K; k += NW * 64) {
     double s = red[0][k];
 #pragma unroll
-    for (int w2 = 1; w2 < kBlock / 64; ++w2) s += red[w2][k];
+    for (int w2 = 1; w2 < NW; ++w2) s += red[w2][k];
     partials[(size_t)blockIdx.x * K + k] = s;
   }
 }
@@ -369,9 +371,9 @@ __device__ __forceinline__ int xcd_block(int lb, int nb) { return (lb & 7) * (nb
 // and in every block: lanes by shuffle tree, then the 4 waves in index order).  The consumer kernels
 // of the fused estimate derive their scalars from the producers' partial tables with it: one memory
 // round trip and one barrier pair for all scalars of a kernel.
-template <int K>
+template <int K, int NW = kBlock / 64>
 __device__ __forceinline__ void block_sum_all(double (&v)[K]) {
-  __shared__ double sh[kBlock / 64][K];
+  __shared__ double sh[NW][K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     double s = wave_sum(v[k]);
@@ -382,7 +384,7 @@ __device__ __forceinline__ void block_sum_all(double (&v)[K]) {
   for (int k = 0; k < K; ++k) {
     double t = sh[0][k];
 #pragma unroll
-    for (int w2 = 1; w2 < kBlock / 64; ++w2) t += sh[w2][k];
+    for (int w2 = 1; w2 < NW; ++w2) t += sh[w2][k];
     v[k] = t;
   }
   __syncthreads();
@@ -1441,9 +1443,9 @@ __global__ void k_assign(const int *slot, const double *r2, double scale, int ns
 }
 
 // K4 (cdcl .txx:196-268)
-__global__ __launch_bounds__(kBlock) void k_errors(PairSrc ps, XfD xf, NormD nm, const double *w, double *partials) {
+__global__ __launch_bounds__(kWide) void k_errors(PairSrc ps, XfD xf, NormD nm, const double *w, double *partials) {
   double acc[3] = {0.0, 0.0, 0.0};
-  for (int s = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+  for (int s = xcd_block(blockIdx.x, gridDim.x) * kWide + threadIdx.x; s < ps.nsrc; s += gridDim.x * kWide) {
     if (ps.slot[s] < 0) continue;
     double r2 = pair_residual2(ps, s, xf, nm);
     double wi = w[s];
@@ -1451,7 +1453,7 @@ __global__ __launch_bounds__(kBlock) void k_errors(PairSrc ps, XfD xf, NormD nm,
     acc[1] += sqrt(r2) * wi;
     acc[2] += wi;
   }
-  block_reduce_store<3>(acc, partials);
+  block_reduce_store<3, kWide / 64>(acc, partials);
 }
 
 // K5 statistics (cdcl .txx:1175-1213)
@@ -1473,16 +1475,16 @@ __global__ void k_mark(const int *slot, const int *m_to, int nsrc, unsigned *fla
   if (s < nsrc && slot[s] >= 0) flag[m_to[s]] = gen;  // benign race: every writer stores the same stamp
 }
 
-__global__ __launch_bounds__(kBlock) void k_to_sum(const double *to_rec, const unsigned *flag, unsigned gen, int nt,
+__global__ __launch_bounds__(kWide) void k_to_sum(const double *to_rec, const unsigned *flag, unsigned gen, int nt,
                                                    double *partials) {
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
+  for (int j = blockIdx.x * kWide + threadIdx.x; j < nt; j += gridDim.x * kWide) {
     if (flag[j] == gen) {
       const double *q = to_rec + (size_t)j * kRecStride;
       acc[0] += q[0]; acc[1] += q[1]; acc[2] += q[2]; acc[3] += 1.0;
     }
   }
-  block_reduce_store<4>(acc, partials);
+  block_reduce_store<4, kWide / 64>(acc, partials);
 }
 
 __global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, const double *to_rec, const unsigned *flag, unsigned gen, int nt,
@@ -2031,14 +2033,14 @@ enum { SC_CM = 0, SC_RM = 3, SC_CF = 4, SC_RF = 7, SC_ND = 8, SC_SIGF = 9, SC_SI
 
 // F1: residuals of both lists (un-normalised coordinates: rrl sym .txx:701-705), sums for the
 // RMS scale, centroid sums and distinct-target marks of the forward list
-__global__ __launch_bounds__(kBlock) void k_f_residual(DirArgs F, DirArgs B, int nbF, int nbB, XfD xfF,
+__global__ __launch_bounds__(kWide) void k_f_residual(DirArgs F, DirArgs B, int nbF, int nbB, XfD xfF,
                                                        XfD xfB, NormD ident, int want_stats, double *P1) {
   const bool isF = (int)blockIdx.x < nbF;
   const DirArgs &D = isF ? F : B;
   const XfD &xf = isF ? xfF : xfB;
   const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
+  for (int s = lb * kWide + threadIdx.x; s < D.ps.nsrc; s += nb * kWide) {
     // every load whose address does not depend on another is issued before the first test: two
     // dependent memory levels per source (streams, then the gather) instead of three
     const int sl = D.ps.slot[s], mt = D.ps.m_to[s];
@@ -2068,20 +2070,20 @@ __global__ __launch_bounds__(kBlock) void k_f_residual(DirArgs F, DirArgs B, int
       D.flag[mt] = D.gen;
     }
   }
-  block_reduce_store<5>(acc, P1);
+  block_reduce_store<5, kWide / 64>(acc, P1);
 }
 
 // F3: mean radii about the centroids (cdcl .txx:1195-1213)
-__global__ __launch_bounds__(kBlock) void k_f_radii(DirArgs F, int nbF, const double *P1, const double *P2,
+__global__ __launch_bounds__(kWide) void k_f_radii(DirArgs F, int nbF, const double *P1, const double *P2,
                                                     int nbT, const double *to_rec, int nt, double *P3,
                                                     double *SC) {
   double cm[3], cf[3];
   double tot[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // from-sums (3), distinct-to sums (3) and their count
-  for (int b = threadIdx.x; b < nbF; b += kBlock)
+  for (int b = threadIdx.x; b < nbF; b += kWide)
     for (int k = 0; k < 3; ++k) tot[k] += P1[(size_t)b * 5 + 2 + k];
-  for (int b = threadIdx.x; b < nbT; b += kBlock)
+  for (int b = threadIdx.x; b < nbT; b += kWide)
     for (int k = 0; k < 4; ++k) tot[3 + k] += P2[(size_t)b * 4 + k];
-  block_sum_all<7>(tot);
+  block_sum_all<7, kWide / 64>(tot);
   const double nd = tot[6];
   for (int k = 0; k < 3; ++k) { cm[k] = tot[k] / (double)F.n; cf[k] = tot[3 + k] / nd; }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2089,21 +2091,21 @@ __global__ __launch_bounds__(kBlock) void k_f_radii(DirArgs F, int nbF, const do
     SC[SC_ND] = nd;
   }
   double acc[2] = {0.0, 0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+  for (int s = blockIdx.x * kWide + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kWide) {
     if (F.ps.slot[s] < 0) continue;
     double p0, p1, p2;
     load_from(F.ps, s, p0, p1, p2);
     p0 -= cm[0]; p1 -= cm[1]; p2 -= cm[2];
     acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
   }
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
+  for (int j = blockIdx.x * kWide + threadIdx.x; j < nt; j += gridDim.x * kWide) {
     if (F.flag[j] == F.gen) {
       const double *q = to_rec + (size_t)j * kRecStride;
       double q0 = q[0] - cf[0], q1 = q[1] - cf[1], q2 = q[2] - cf[2];
       acc[1] += sqrt((q0 * q0 + q1 * q1) + q2 * q2);
     }
   }
-  block_reduce_store<2>(acc, P3);
+  block_reduce_store<2, kWide / 64>(acc, P3);
 }
 
 struct WeightOpts {
@@ -2126,7 +2128,7 @@ __device__ __forceinline__ NormD norm_from_scalars(const double *SC, bool flippe
 
 // F4: Beaton-Tukey weights, strength gain and spatial keys.  The multiplications by 1/MADscale
 // are deferred to F6, in the reference's order: w = BT/s^2 ; w *= g ; w *= 1/gs ; w *= sw ; w *= 1/ss.
-__global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
+__global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
                                                       const double *P1, const double *P3, int nb3,
                                                       double *SC, double *P4) {
   const bool isF = (int)blockIdx.x < nbF;
@@ -2136,10 +2138,10 @@ __global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int 
   const int mode = isF ? o.mode_f : o.mode_b;
   double tot[4] = {0.0, 0.0, 0.0, 0.0};  // S, W of this list's residuals; radius sums of both clouds
   if (mode == LRR_ICP_SCALE_RMS)
-    for (int b = r0 + (int)threadIdx.x; b < r1; b += kBlock) { tot[0] += P1[(size_t)b * 5]; tot[1] += P1[(size_t)b * 5 + 1]; }
+    for (int b = r0 + (int)threadIdx.x; b < r1; b += kWide) { tot[0] += P1[(size_t)b * 5]; tot[1] += P1[(size_t)b * 5 + 1]; }
   if (o.normalize)
-    for (int b = threadIdx.x; b < nb3; b += kBlock) { tot[2] += P3[(size_t)b * 2]; tot[3] += P3[(size_t)b * 2 + 1]; }
-  block_sum_all<4>(tot);
+    for (int b = threadIdx.x; b < nb3; b += kWide) { tot[2] += P3[(size_t)b * 2]; tot[3] += P3[(size_t)b * 2 + 1]; }
+  block_sum_all<4, kWide / 64>(tot);
   const double scale = mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : (isF ? o.inj_f : o.inj_b);
   __shared__ double sc_norm[8];
   if (o.normalize) {
@@ -2162,7 +2164,7 @@ __global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int 
   double *wdst = clone ? D.wc : D.w;
   const double scale2 = scale * scale;
   double acc[1] = {0.0};
-  for (int s = lb * kBlock + threadIdx.x; s < D.ps.nsrc; s += nb * kBlock) {
+  for (int s = lb * kWide + threadIdx.x; s < D.ps.nsrc; s += nb * kWide) {
     if (D.ps.slot[s] < 0) { D.key_g[s] = INFINITY; D.key_s[s] = INFINITY; continue; }
     double u = D.r2[s] / scale2, bt = 0.0;
     if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
@@ -2190,7 +2192,7 @@ __global__ __launch_bounds__(kBlock) void k_f_weights(DirArgs F, DirArgs B, int 
     }
     wdst[s] = wi;
   }
-  block_reduce_store<1>(acc, P4);
+  block_reduce_store<1, kWide / 64>(acc, P4);
 }
 
 __device__ __forceinline__ double mad_factor(const double *sel) {  // 1 / rrel_util_median_abs_dev_scale
@@ -2380,16 +2382,16 @@ __global__ __launch_bounds__(kBlock) void k_transfer_cov(PairSrc ps, CovarArg C,
 // the same for its own bookkeeping once they arrive).
 // ---------------------------------------------------------------------------------------------
 // FW0: sums of the from-locations, stamps of the distinct matched targets (cdcl .txx:1159-1190)
-__global__ __launch_bounds__(kBlock) void k_fw_stats(DirArgs F, double *P1) {
+__global__ __launch_bounds__(kWide) void k_fw_stats(DirArgs F, double *P1) {
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // columns 2..4: the layout k_f_radii reads
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+  for (int s = blockIdx.x * kWide + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kWide) {
     if (F.ps.slot[s] < 0) continue;
     double p0, p1, p2;
     load_from(F.ps, s, p0, p1, p2);
     acc[2] += p0; acc[3] += p1; acc[4] += p2;
     F.flag[F.ps.m_to[s]] = F.gen;
   }
-  block_reduce_store<5>(acc, P1);
+  block_reduce_store<5, kWide / 64>(acc, P1);
 }
 
 struct FwdOpts {
@@ -2418,8 +2420,8 @@ __device__ __forceinline__ NormD fwd_norm(const FwdOpts &o, const DirArgs &F, co
   __shared__ double sc_norm[8];
   double tot[2] = {0.0, 0.0};
   if (o.normalize)
-    for (int b = threadIdx.x; b < nb3; b += kBlock) { tot[0] += P3[(size_t)b * 2]; tot[1] += P3[(size_t)b * 2 + 1]; }
-  block_sum_all<2>(tot);
+    for (int b = threadIdx.x; b < nb3; b += kWide) { tot[0] += P3[(size_t)b * 2]; tot[1] += P3[(size_t)b * 2 + 1]; }
+  block_sum_all<2, kWide / 64>(tot);
   if (threadIdx.x == 0) {
     if (o.normalize) {
       for (int k = 0; k < 3; ++k) { sc_norm[k] = SC[SC_CM + k]; sc_norm[4 + k] = SC[SC_CF + k]; }
@@ -2434,7 +2436,7 @@ __device__ __forceinline__ NormD fwd_norm(const FwdOpts &o, const DirArgs &F, co
 
 // FW1: residuals (cdcl .txx:660-735): also leaves the matched target's location and the pair's
 // strength gain per source, and the sums for the RMS scale under the previous weights
-__global__ __launch_bounds__(kBlock) void k_fw_residual(DirArgs F, FwdOpts o, XfD xf, const double *P3, int nb3,
+__global__ __launch_bounds__(kWide) void k_fw_residual(DirArgs F, FwdOpts o, XfD xf, const double *P3, int nb3,
                                                         double *SC, double *P1) {
   const NormD nm = fwd_norm(o, F, P3, nb3, SC);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2443,7 +2445,7 @@ __global__ __launch_bounds__(kBlock) void k_fw_residual(DirArgs F, FwdOpts o, Xf
   }
   const XfD T = o.normalize ? normalized_xf(xf, nm, o.rigid) : xf;
   double acc[2] = {0.0, 0.0};
-  for (int s = xcd_block(blockIdx.x, gridDim.x) * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+  for (int s = xcd_block(blockIdx.x, gridDim.x) * kWide + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kWide) {
     if (F.ps.slot[s] < 0) { F.key_s[s] = INFINITY; continue; }
     double p0, p1, p2, y0, y1, y2;
     load_from(F.ps, s, p0, p1, p2);
@@ -2464,21 +2466,21 @@ __global__ __launch_bounds__(kBlock) void k_fw_residual(DirArgs F, FwdOpts o, Xf
     F.r2[s] = r2;
     F.key_s[s] = sqrt(r2);  // MUSE sorts these (first estimate)
   }
-  block_reduce_store<2>(acc, P1);
+  block_reduce_store<2, kWide / 64>(acc, P1);
 }
 
 // FW2: scale, Beaton-Tukey weights (cdcl .txx:736-822), strength gain and its key (cdcl .txx:826-862)
-__global__ __launch_bounds__(kBlock) void k_fw_weights(DirArgs F, FwdOpts o, const double *P1, int nb1, double *SC,
+__global__ __launch_bounds__(kWide) void k_fw_weights(DirArgs F, FwdOpts o, const double *P1, int nb1, double *SC,
                                                        double *P4) {
   double tot[2] = {0.0, 0.0};
   if (o.mode == LRR_ICP_SCALE_RMS)
-    for (int b = threadIdx.x; b < nb1; b += kBlock) { tot[0] += P1[(size_t)b * 2]; tot[1] += P1[(size_t)b * 2 + 1]; }
-  block_sum_all<2>(tot);
+    for (int b = threadIdx.x; b < nb1; b += kWide) { tot[0] += P1[(size_t)b * 2]; tot[1] += P1[(size_t)b * 2 + 1]; }
+  block_sum_all<2, kWide / 64>(tot);
   const double scale = o.mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : o.injected;
   if (blockIdx.x == 0 && threadIdx.x == 0) SC[SC_SIGF] = scale;
   const double scale2 = scale * scale;
   double acc[1] = {0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kBlock) {
+  for (int s = blockIdx.x * kWide + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kWide) {
     if (F.ps.slot[s] < 0) { F.key_g[s] = INFINITY; continue; }
     double u = F.r2[s] / scale2, bt = 0.0;
     if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
@@ -2493,7 +2495,7 @@ __global__ __launch_bounds__(kBlock) void k_fw_weights(DirArgs F, FwdOpts o, con
     F.key_g[s] = key;
     F.w[s] = wi;
   }
-  block_reduce_store<1>(acc, P4);
+  block_reduce_store<1, kWide / 64>(acc, P4);
 }
 
 // FW3: final weights and the normal equations (cdcl .txx:1039-1069)
@@ -2560,6 +2562,11 @@ inline int grid_for(int64_t n) {  // a multiple of 8 blocks: see xcd_block
   int64_t b = ((n + kBlock - 1) / kBlock + 7) / 8 * 8;
   if (b < 8) b = 8;
   return (int)std::min<int64_t>(b, kMaxBlocks);
+}
+inline int grid_wide(int64_t n) {  // blocks of kWide threads, a multiple of 8, at most kWideBlocks
+  int64_t b = ((n + kWide - 1) / kWide + 7) / 8 * 8;
+  if (b < 8) b = 8;
+  return (int)std::min<int64_t>(b, kWideBlocks);
 }
 inline int blocks_for(int64_t n) { return (int)std::max<int64_t>(1, (n + kBlock - 1) / kBlock); }
 
@@ -3576,8 +3583,8 @@ int lrr_icp_normalize_stats(lrr_icp_dir *d, lrr_icp_norm *out) {
   if ((rc = next_flag_gen(d, &gen))) return rc;
   hipLaunchKernelGGL(k_mark, dim3(blocks_for(ps.nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->m_to, ps.nsrc, d->flag, gen);
   HIPCHK(ctx, hipGetLastError());
-  int nbt = grid_for(nt);
-  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kBlock), 0, ctx->stream, d->to->rec, d->flag, gen, (int)nt, ctx->d_partials);
+  int nbt = grid_wide(nt);
+  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kWide), 0, ctx->stream, d->to->rec, d->flag, gen, (int)nt, ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   rc = finish_reduce(ctx, nbt, 4, r);
   if (rc) return rc;
@@ -3710,8 +3717,8 @@ int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, doub
   if (d->n > 0) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PairSrc ps = pairs_of(d);
-    int nb = grid_for(ps.nsrc);
-    hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, ctx->d_partials);
+    int nb = grid_wide(ps.nsrc);
+    hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kWide), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, ctx->d_partials);
     HIPCHK(ctx, hipGetLastError());
     int rc = finish_reduce(ctx, nb, 3, r);
     if (rc) return rc;
@@ -3735,12 +3742,12 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   double *SC = OUT, *SEL = OUT + SEL_OFF, *FIN = OUT + FIN_OFF;
   DirArgs aF = dir_args(F), aB = dir_args(B);
   const int nsF = aF.ps.nsrc, nsB = aB.ps.nsrc;
-  int nbF = grid_for(nsF), nbB = grid_for(nsB), nt = (int)F->to->n, nbT = grid_for(nt);
+  int nbF = grid_wide(nsF), nbB = grid_wide(nsB), nt = (int)F->to->n, nbT = grid_wide(nt);
   int nb3 = std::max(nbF, nbT);
   NormD ident = to_dev((const lrr_icp_norm *)nullptr);
   // F1
   if (o->normalize) { int rc = next_flag_gen(F, &aF.gen); if (rc) return rc; }
-  hipLaunchKernelGGL(k_f_residual, dim3(nbF + nbB), dim3(kBlock), 0, st, aF, aB, nbF, nbB, to_dev(xfF), to_dev(xfB), ident, o->normalize, P1);
+  hipLaunchKernelGGL(k_f_residual, dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, to_dev(xfF), to_dev(xfB), ident, o->normalize, P1);
   HIPCHK(ctx, hipGetLastError());
   // scale modes; MUSE needs the sorted residuals: its tables and argmin stay on the host (first
   // estimate after set_transform only)
@@ -3750,12 +3757,12 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   if (wo.mode_f == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &wo.inj_f); if (rc) return rc; wo.mode_f = LRR_ICP_SCALE_INJECTED; }
   if (wo.mode_b == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(B, &wo.inj_b); if (rc) return rc; wo.mode_b = LRR_ICP_SCALE_INJECTED; }
   if (o->normalize) {
-    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kBlock), 0, st, F->to->rec, F->flag, aF.gen, nt, P2);
+    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kWide), 0, st, F->to->rec, F->flag, aF.gen, nt, P2);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kBlock), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
+    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kWide), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
     HIPCHK(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_f_weights, dim3(nbF + nbB), dim3(kBlock), 0, st, aF, aB, nbF, nbB, wo, P1, P3, nb3, SC, P4);
+  hipLaunchKernelGGL(k_f_weights, dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, wo, P1, P3, nb3, SC, P4);
   HIPCHK(ctx, hipGetLastError());
   // order statistics: ranks of the strength jobs come from the device-side counts
   SelJob *hj = ctx->h_jobs;
@@ -3778,7 +3785,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   }
   { int rc = launch_select_kth(ctx, nj); if (rc) return rc; }
   // F6 + final reduction
-  int nbAF = std::min(nbF, kAccBlocks), nbAB = std::min(nbB, kAccBlocks);
+  int nbAF = std::min(grid_for(nsF), kAccBlocks), nbAB = std::min(grid_for(nsB), kAccBlocks);
   const double *c = o->jac_centre;
   const int nt2 = o->dof * (o->dof + 1) / 2, K = nt2 + o->dof;
   if (o->dof == 12 && o->rrl) hipLaunchKernelGGL((k_f_accumulate<12, true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
@@ -3903,25 +3910,25 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   double *P4 = ctx->d_fused + kFusedP4, *P6 = ctx->d_fused + kFusedP6, *OUT = ctx->d_fused + kFusedOut;
   double *SC = OUT, *SEL = OUT + SEL_OFF, *FIN = OUT + FIN_OFF;
   DirArgs aF = dir_args(F);
-  const int nsF = aF.ps.nsrc, nbF = grid_for(nsF), nt = (int)F->to->n, nbT = grid_for(nt), nb3 = std::max(nbF, nbT);
+  const int nsF = aF.ps.nsrc, nbF = grid_wide(nsF), nt = (int)F->to->n, nbT = grid_wide(nt), nb3 = std::max(nbF, nbT);
   if (o->normalize) {
     int rc = next_flag_gen(F, &aF.gen);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fw_stats, dim3(nbF), dim3(kBlock), 0, st, aF, P1);
+    hipLaunchKernelGGL(k_fw_stats, dim3(nbF), dim3(kWide), 0, st, aF, P1);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kBlock), 0, st, F->to->rec, F->flag, aF.gen, nt, P2);
+    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kWide), 0, st, F->to->rec, F->flag, aF.gen, nt, P2);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kBlock), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
+    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kWide), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
     HIPCHK(ctx, hipGetLastError());
   }
   FwdOpts fo;
   fo.normalize = o->normalize; fo.strength = o->strength; fo.rigid = o->rigid_transform;
   fo.mode = o->scale_mode; fo.injected = o->injected;
-  hipLaunchKernelGGL(k_fw_residual, dim3(nbF), dim3(kBlock), 0, st, aF, fo, to_dev(xf), P3, nb3, SC, P1);
+  hipLaunchKernelGGL(k_fw_residual, dim3(nbF), dim3(kWide), 0, st, aF, fo, to_dev(xf), P3, nb3, SC, P1);
   HIPCHK(ctx, hipGetLastError());
   // MUSE needs the sorted residuals: its tables and argmin stay on the host (first estimate only)
   if (fo.mode == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &fo.injected); if (rc) return rc; fo.mode = LRR_ICP_SCALE_INJECTED; }
-  hipLaunchKernelGGL(k_fw_weights, dim3(nbF), dim3(kBlock), 0, st, aF, fo, P1, nbF, SC, P4);
+  hipLaunchKernelGGL(k_fw_weights, dim3(nbF), dim3(kWide), 0, st, aF, fo, P1, nbF, SC, P4);
   HIPCHK(ctx, hipGetLastError());
   if (o->strength) {
     SelJob j = make_job(F->key_g, nsF, nullptr, 0, -1, 0);
@@ -3932,7 +3939,7 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
     int rc = launch_select_kth(ctx, 1);
     if (rc) return rc;
   }
-  const int nbA = std::min(nbF, kAccBlocks);
+  const int nbA = std::min(grid_for(nsF), kAccBlocks);
   const double *c = o->jac_centre;
   const int nt2 = o->dof * (o->dof + 1) / 2, K = nt2 + o->dof;
   if (o->dof == 12) hipLaunchKernelGGL((k_fw_accumulate<12>), dim3(nbA), dim3(kBlock), 0, st, aF, fo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
