@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -87,6 +88,28 @@ class device {
  private:
   struct state { lrr_icp_ctx *ctx = nullptr; int want = -1; };
   static state &slot() { static thread_local state s; return s; }
+};
+
+// how set_voronoi_maps() / set_fixed_voronoi_map() of the rrl classes are honoured (see icp_symmetric)
+struct voronoi_lookup {
+  static void enable(bool on) { flag() = on ? 1 : 0; }
+  static bool enabled() {
+    if (flag() < 0) {
+      const char *e = std::getenv("LRR_ICP_VORONOI");
+      flag() = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return flag() == 1;
+  }
+  static void note_ignored() {
+    static bool said = false;
+    if (!said) {
+      said = true;
+      std::fprintf(stderr, "lrr_amd: set_voronoi_maps(): the maps are not used — matches are the exact nearest neighbours, which the "
+                           "1 mm maps approximate (lrr_amd::voronoi_lookup::enable(true) or LRR_ICP_VORONOI=1 selects the lookup semantics)\n");
+    }
+  }
+ private:
+  static int &flag() { static int f = -1; return f; }
 };
 
 inline void check(int rc, const char *what) {
@@ -706,8 +729,14 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     backward_->set_moving_data(ff);
     reset_schedule();
   }
-  // the exact device search needs no precomputed Voronoi volume (rrl sym .txx:293-299)
-  template <class VoronoiPointer> void set_voronoi_maps(VoronoiPointer const &, VoronoiPointer const &) {}
+  // (rrl sym .txx:293-299) The reference hands its two precomputed 1 mm Voronoi index volumes over here; the
+  // device needs neither.  By default the search is the EXACT nearest neighbour (what the volumes approximate);
+  // with voronoi_lookup::enable(true) — or LRR_ICP_VORONOI=1 in the environment — this call switches both
+  // directions to the quantised lookup semantics of the volumes (LRR_ICP_NN_VORONOI, include/lrr_icp.h).
+  template <class VoronoiPointer> void set_voronoi_maps(VoronoiPointer const &, VoronoiPointer const &) {
+    if (voronoi_lookup::enabled()) set_nn_method(LRR_ICP_NN_VORONOI);
+    else voronoi_lookup::note_ignored();
+  }
   // (rrl sym .txx:303-315)
   void set_transform(trans_sptr_type const &trans) {
     forward_->set_transform(trans);

@@ -38,8 +38,12 @@ typedef struct { double A[9]; double t[3]; double c[3]; } lrr_icp_xform;
 /* from-side points are normalised by (cm, rm), to-side points by (cf, rf); identity = {0,1,0,1} */
 typedef struct { double cm[3]; double rm; double cf[3]; double rf; } lrr_icp_norm;
 
-/* nearest-neighbour methods: both exact, ties -> lowest index */
-enum { LRR_ICP_NN_AUTO = 0, LRR_ICP_NN_BRUTE = 1, LRR_ICP_NN_GRID = 2 };
+/* nearest-neighbour methods.  BRUTE and GRID are exact (ties -> lowest index).  VORONOI reproduces the lookup
+ * of the production rrl matcher (rrl/rrl_estimation_ICP_matching_all.txx:530-543): the mapped point is rounded
+ * to its voxel of a 1 mm volume over the to-cloud's bounding box, clamped to the volume, and matched to the
+ * feature the nearest occupied voxel stands for (rrl/examples/compute_distance_map.cxx:55-151; exact distances
+ * between voxel centres where the reference uses Danielsson's approximation; ties -> lowest feature index) */
+enum { LRR_ICP_NN_AUTO = 0, LRR_ICP_NN_BRUTE = 1, LRR_ICP_NN_GRID = 2, LRR_ICP_NN_VORONOI = 3 };
 
 /* accumulate flags */
 enum {
@@ -79,6 +83,9 @@ int  lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const 
                           const double *strength, int float_strength, lrr_icp_cloud **out);
 void lrr_icp_cloud_destroy(lrr_icp_cloud *cloud);
 int64_t lrr_icp_cloud_size(const lrr_icp_cloud *cloud);
+/* the occupied voxels of the 1 mm index volume compute_distance_map builds for this feature set (what
+ * set_voronoi_maps hands to the rrl classes); called on demand by the first LRR_ICP_NN_VORONOI search */
+int  lrr_icp_cloud_build_voronoi(lrr_icp_cloud *cloud);
 
 /* ---- one estimation direction ------------------------------------------------------------ */
 int  lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to, lrr_icp_dir **out);

@@ -170,6 +170,13 @@ struct lrr_icp_cloud {
   Chunk *chunks = nullptr; int nchunks = 0;
   double lo[3] = {0, 0, 0}, h = 1.0, inv_h = 1.0, tol = 0.0;
   int dim[3] = {1, 1, 1};
+  // Voronoi-lookup semantics of the production rrl matcher (lrr_icp_cloud_build_voronoi): the occupied voxels of
+  // the reference's 1 mm index volume as a cloud of their own, and the feature each stands for
+  lrr_icp_cloud *vor = nullptr;
+  int *vor_site_to_feature = nullptr;  // site canonical index -> canonical index of the feature in THIS cloud
+  std::vector<int> h_vor_site_to_orig;  // ... -> its original index (stand-alone queries)
+  double vor_origin[3] = {0, 0, 0};
+  int vor_size[3] = {1, 1, 1};
 };
 
 struct lrr_icp_dir {
@@ -244,7 +251,17 @@ struct GridView {
   const GridPoint *cpt;   // points in canonical order (exact confirmation)
   double lox, loy, loz, h, inv_h, tol;
   int dx, dy, dz, n, fine;
+  // Voronoi-lookup semantics (LRR_ICP_NN_VORONOI): the mapped query is first rounded to the centre of its voxel of
+  // the 1 mm volume (origin qo*, size qs*), clamped to the volume (rrl .txx:530-543)
+  int quant, qsx, qsy, qsz;
+  double qox, qoy, qoz;
 };
+__device__ __forceinline__ void vor_quantize(const GridView &g, double &x, double &y, double &z) {
+  if (!g.quant) return;
+  x = g.qox + fmin(fmax(floor((x - g.qox) + 0.5), 0.0), (double)(g.qsx - 1));
+  y = g.qoy + fmin(fmax(floor((y - g.qoy) + 0.5), 0.0), (double)(g.qsy - 1));
+  z = g.qoz + fmin(fmax(floor((z - g.qoz) + 0.5), 0.0), (double)(g.qsz - 1));
+}
 
 __device__ __forceinline__ void map_loc(const XfD &T, double x0, double x1, double x2, double &y0,
                                         double &y1, double &y2) {
@@ -480,11 +497,12 @@ __device__ __forceinline__ void query_point(const QSrc &q, int s, double &x, dou
   else { x = q.raw[3 * (size_t)s]; y = q.raw[3 * (size_t)s + 1]; z = q.raw[3 * (size_t)s + 2]; }
 }
 // the query point mapped by the launch's transform, or by its own location's in a batch
-__device__ __forceinline__ void mapped_query(const QSrc &q, const XfD &xf, int s, double &yx, double &yy, double &yz) {
+__device__ __forceinline__ void mapped_query(const GridView &g, const QSrc &q, const XfD &xf, int s, double &yx, double &yy, double &yz) {
   double x, y, z;
   query_point(q, s, x, y, z);
   if (q.bloc) map_loc(q.bloc[q.loc_of[s]].xf[q.dir], x, y, z, yx, yy, yz);
   else map_loc(xf, x, y, z, yx, yy, yz);
+  vor_quantize(g, yx, yy, yz);
 }
 __device__ __forceinline__ int result_index(const QSrc &q, const Best &b) {
   if (b.orig == 0x7fffffff) return 0;  // only reachable with non-finite input
@@ -594,6 +612,7 @@ __global__ __launch_bounds__(kBlock) void k_match_direct(GridView g, QSrc q, con
   double x, y, z, yx, yy, yz;
   query_point(q, s, x, y, z);
   map_loc(xf, x, y, z, yx, yy, yz);
+  vor_quantize(g, yx, yy, yz);
   Best b;
   if (grid_search_easy(g, yx, yy, yz, kEasyBudget, b)) m_to[s] = result_index(q, b);
   else hard[atomicAdd(hard_count, 1)] = s;  // m_to[s] keeps the previous match (cloud queries)
@@ -1155,7 +1174,7 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
   for (int o = wave; o < cnt; o += nwaves) {
     int s = hard[o];
     double yx, yy, yz;
-    mapped_query(q, xf, s, yx, yy, yz);
+    mapped_query(g, q, xf, s, yx, yy, yz);
     int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
     int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
     int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
@@ -1263,7 +1282,7 @@ __device__ __forceinline__ void match_overflow_body(const OverArgs &A) {
   for (int o = blockIdx.x; o < cnt; o += gridDim.x) {
     int s = overflow[o];
     double yx, yy, yz;
-    mapped_query(q, xf, s, yx, yy, yz);
+    mapped_query(g, q, xf, s, yx, yy, yz);
     Best b;
     b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
     for (int j = threadIdx.x; j < g.n; j += kBlock) {
@@ -1336,6 +1355,7 @@ __global__ __launch_bounds__(kBlock) void k_match_brute(GridView g, QSrc q, cons
       double x, y_, z_;
       query_point(q, s, x, y_, z_);
       map_loc(xf, x, y_, z_, yx[u], yy[u], yz[u]);
+      vor_quantize(g, yx[u], yy[u], yz[u]);
     }
   }
   int begin = blockIdx.y * chunk, end = min(begin + chunk, g.n);
@@ -1571,6 +1591,13 @@ __global__ void k_copy_w(const double *src, double *dst, int n) {
 }
 
 // matches_ in the reference's list order: (original from index, original to index, weight)
+// Voronoi-lookup search: the matches of the active sources are canonical indices of the SITE cloud (occupied
+// voxels); each site carries the feature whose index the reference's volume stores in that voxel
+__global__ void k_vor_remap(const int *slot, int *m_to, const int *site_to_feature, int nsrc) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nsrc && slot[s] >= 0) m_to[s] = site_to_feature[m_to[s]];
+}
+
 // lazy: the last search ran at the finest level without materialising list positions (k_match_cert):
 // every source is active and its position is perm^-1(original index) under that search's keys
 __global__ void k_export(const int *slot, const int *m_to, const double *w, const int *from_orig,
@@ -2603,6 +2630,15 @@ GridView view_of(const lrr_icp_cloud *c) {
   g.h = c->h; g.inv_h = c->inv_h; g.tol = c->tol;
   g.dx = c->dim[0]; g.dy = c->dim[1]; g.dz = c->dim[2];
   g.n = (int)c->n;
+  g.quant = 0; g.qsx = g.qsy = g.qsz = 1; g.qox = g.qoy = g.qoz = 0.0;
+  return g;
+}
+// the search structure of a cloud's Voronoi sites, with the voxel rounding of the queries switched on
+GridView view_of_voronoi(const lrr_icp_cloud *c) {
+  GridView g = view_of(c->vor);
+  g.quant = 1;
+  g.qsx = c->vor_size[0]; g.qsy = c->vor_size[1]; g.qsz = c->vor_size[2];
+  g.qox = c->vor_origin[0]; g.qoy = c->vor_origin[1]; g.qoz = c->vor_origin[2];
   return g;
 }
 
@@ -3150,8 +3186,88 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
 void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
   if (!c) return;
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
+  if (c->vor) lrr_icp_cloud_destroy(c->vor);
+  if (c->vor_site_to_feature) (void)hipFree(c->vor_site_to_feature);
   if (c->slab) (void)hipFree(c->slab);
   delete c;
+}
+
+// The occupied voxels of the 1 mm index volume rrl/examples/compute_distance_map.cxx:55-151 builds for a feature
+// set: origin = minimum corner of the bounding box, size = ceil(extent), feature i > 0 writes i into the voxel its
+// location rounds to (a later feature overwrites an earlier one; 0 is the background value, so feature 0 is never
+// stored).  The volume itself (nearest occupied voxel of every voxel) is not materialised: a lookup is the exact
+// nearest occupied voxel of the query's voxel, found with the grid search over the site cloud, ties to the lowest
+// feature index.  Same choices as the oracle (oracle/lrr_oracle.c, vor_build): rounding half up, exact distances
+// where the reference uses Danielsson's approximation — parity with the reference binary unpinned.
+int lrr_icp_cloud_build_voronoi(lrr_icp_cloud *c) {
+  if (!c) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = c->ctx;
+  if (c->vor) return LRR_ICP_OK;
+  if (c->n <= 0) return fail(ctx, LRR_ICP_ERR_ARG, "build_voronoi: empty cloud");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int64_t n = c->n;
+  std::vector<double> loc(3 * (size_t)n);
+  HIPCHK(ctx, hipMemcpy(loc.data(), c->loc_orig, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+  double mx[3];
+  for (int d = 0; d < 3; ++d) { c->vor_origin[d] = loc[d]; mx[d] = loc[d]; }
+  for (int64_t i = 0; i < n; ++i)
+    for (int d = 0; d < 3; ++d) {
+      c->vor_origin[d] = std::min(c->vor_origin[d], loc[3 * i + d]);
+      mx[d] = std::max(mx[d], loc[3 * i + d]);
+    }
+  for (int d = 0; d < 3; ++d) {
+    double sz = std::ceil(mx[d] - c->vor_origin[d]);
+    if (sz < 1.0) sz = 1.0;
+    if (sz > 2.0e9) return fail(ctx, LRR_ICP_ERR_ARG, "build_voronoi: extent too large for a 1 mm volume");
+    c->vor_size[d] = (int)sz;
+  }
+  auto vindex = [&](int d, double x) {
+    double v = std::floor((x - c->vor_origin[d]) + 0.5);
+    if (v < 0.0) v = 0.0;
+    if (v > (double)(c->vor_size[d] - 1)) v = (double)(c->vor_size[d] - 1);
+    return (int64_t)v;
+  };
+  std::vector<std::pair<int64_t, int64_t>> pairs;  // (voxel, feature)
+  pairs.reserve((size_t)n);
+  for (int64_t i = 1; i < n; ++i) {
+    const int64_t ix = vindex(0, loc[3 * i]), iy = vindex(1, loc[3 * i + 1]), iz = vindex(2, loc[3 * i + 2]);
+    pairs.push_back({(iz * c->vor_size[1] + iy) * (int64_t)c->vor_size[0] + ix, i});
+  }
+  if (pairs.empty()) {  // only feature 0: every lookup reads the background value 0
+    pairs.push_back({(vindex(2, loc[2]) * c->vor_size[1] + vindex(1, loc[1])) * (int64_t)c->vor_size[0] + vindex(0, loc[0]), 0});
+  }
+  std::sort(pairs.begin(), pairs.end());
+  std::vector<std::pair<int64_t, int64_t>> sites;  // (feature, voxel): the last writer of every voxel, ascending feature
+  for (size_t k = 0; k < pairs.size(); ++k)
+    if (k + 1 == pairs.size() || pairs[k + 1].first != pairs[k].first) sites.push_back({pairs[k].second, pairs[k].first});
+  std::sort(sites.begin(), sites.end());
+  const int64_t ns = (int64_t)sites.size();
+  std::vector<double> sloc(3 * (size_t)ns), sproj(9 * (size_t)ns, 0.0);
+  for (int64_t k = 0; k < ns; ++k) {
+    const int64_t v = sites[(size_t)k].second;
+    const int64_t ix = v % c->vor_size[0], iy = (v / c->vor_size[0]) % c->vor_size[1], iz = v / ((int64_t)c->vor_size[0] * c->vor_size[1]);
+    sloc[3 * k] = c->vor_origin[0] + (double)ix;
+    sloc[3 * k + 1] = c->vor_origin[1] + (double)iy;
+    sloc[3 * k + 2] = c->vor_origin[2] + (double)iz;
+    sproj[9 * k] = sproj[9 * k + 4] = sproj[9 * k + 8] = 1.0;
+  }
+  lrr_icp_cloud *sc = nullptr;
+  int rc = lrr_icp_cloud_create(ctx, ns, sloc.data(), sproj.data(), nullptr, 0, &sc);
+  if (rc) return rc;
+  // site canonical index -> canonical index (in this cloud) of the feature it stands for; the site cloud's own
+  // "original index" is the site number, ascending in the feature index: its tie rule is the lowest feature index
+  std::vector<int> canon_of((size_t)n), s2f((size_t)ns);
+  for (int64_t s2 = 0; s2 < n; ++s2) canon_of[(size_t)c->h_orig_of[(size_t)s2]] = (int)s2;
+  for (int64_t sc_i = 0; sc_i < ns; ++sc_i) s2f[(size_t)sc_i] = canon_of[(size_t)sites[(size_t)sc->h_orig_of[(size_t)sc_i]].first];
+  if (hipMalloc(&c->vor_site_to_feature, sizeof(int) * (size_t)ns) != hipSuccess ||
+      hipMemcpy(c->vor_site_to_feature, s2f.data(), sizeof(int) * (size_t)ns, hipMemcpyHostToDevice) != hipSuccess) {
+    lrr_icp_cloud_destroy(sc);
+    return fail(ctx, LRR_ICP_ERR_HIP, "build_voronoi: upload failed");
+  }
+  c->h_vor_site_to_orig.resize((size_t)ns);
+  for (int64_t sc_i = 0; sc_i < ns; ++sc_i) c->h_vor_site_to_orig[(size_t)sc_i] = (int)sites[(size_t)sc->h_orig_of[(size_t)sc_i]].first;
+  c->vor = sc;
+  return LRR_ICP_OK;
 }
 
 int64_t lrr_icp_cloud_size(const lrr_icp_cloud *c) { return c ? c->n : 0; }
@@ -3240,6 +3356,7 @@ struct MatchPrep {
   int *counts = nullptr;
   int64_t N = 0;
   bool dense = false, steady = false, use_keys = false, empty = false;
+  bool voronoi = false;   // Voronoi-lookup semantics: searches the to-cloud's site cloud with voxel-rounded queries
   bool cert = false;      // finest level with second-nearest bounds from the previous search: certificate kernel
   bool short_list = false;  // ... whose list was short last time: the listed sources go straight to the wave-per-query kernel
   lrr_icp_xform prev_xf;  // transform of that search
@@ -3294,10 +3411,15 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
     P.d_order = L.d_order;
   }
   P.method = method == LRR_ICP_NN_AUTO ? LRR_ICP_NN_GRID : method;
-  P.g = view_of(d->to);
+  P.voronoi = P.method == LRR_ICP_NN_VORONOI;
+  if (P.voronoi) {
+    if ((rc = lrr_icp_cloud_build_voronoi(d->to))) return rc;  // built once per cloud
+    P.method = LRR_ICP_NN_GRID;
+  }
+  P.g = P.voronoi ? view_of_voronoi(d->to) : view_of(d->to);
   P.q.src = d->from->src; P.q.raw = nullptr; P.q.want_orig = 0; P.q.pidx = nullptr; P.q.bloc = nullptr; P.q.loc_of = nullptr; P.q.dir = 0;
   P.x = to_dev(xf);
-  P.dense = !order && n_points * 4 >= N;  // fine levels: every source feature is looked at
+  P.dense = !order && n_points * 4 >= N && !P.voronoi;  // fine levels: every source feature is looked at
   if ((rc = fresh_counts(ctx, L, st, &P.counts))) return rc;
   // a level's later iterations: every active source carries its previous match -> ball search
   P.steady = P.method == LRR_ICP_NN_GRID && P.dense && d->prev_n == n_points;
@@ -3359,6 +3481,18 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, P.counts);
   }
   HIPCHK(ctx, hipGetLastError());
+  if (P.voronoi) {
+    // previous matches are feature indices, not site indices: the wave-per-query phase starts from scratch
+    HardArgs h = hard_args(L, d->to->vor, P.g, P.q, P.x, d->m_to, P.counts);
+    h.use_prev = 0;
+    hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n_points)), dim3(kBlock), 0, st, h);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, st, over_args(h));
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_vor_remap, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->slot, d->m_to, d->to->vor_site_to_feature, (int)N);
+    HIPCHK(ctx, hipGetLastError());
+    return LRR_ICP_OK;
+  }
   return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady && n_points == N, d->d2lb, P.cert, P.short_list);
 }
 
@@ -3392,7 +3526,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
   int rc, rc2;
   // Later iterations of a level (both directions in the ball-search state): every phase handles both
   // directions in ONE launch on the main stream (blockIdx.y = direction) — no fork/join at all.
-  const bool both_steady = method != LRR_ICP_NN_BRUTE && !order_f && !order_b && n_f > 0 && n_b > 0 &&
+  const bool both_steady = method != LRR_ICP_NN_BRUTE && method != LRR_ICP_NN_VORONOI && !order_f && !order_b && n_f > 0 && n_b > 0 &&
                            n_f * 4 >= f->from->n && n_b * 4 >= b->from->n && f->prev_n == n_f && b->prev_n == n_b;
   if (both_steady) {
     MatchPrep Pf, Pb;
@@ -4013,25 +4147,29 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
   int *counts = nullptr;
   if (!rc) rc = fresh_counts(ctx, L, ctx->stream, &counts);
   if (!rc) {
-    GridView g = view_of(cloud);
+    const bool voronoi = method == LRR_ICP_NN_VORONOI;
+    if (voronoi) rc = lrr_icp_cloud_build_voronoi(cloud);
+    GridView g = (voronoi && !rc) ? view_of_voronoi(cloud) : view_of(cloud);
     QSrc q;
-    q.src = nullptr; q.raw = dq; q.want_orig = 1; q.pidx = nullptr; q.bloc = nullptr; q.loc_of = nullptr; q.dir = 0;
+    q.src = nullptr; q.raw = dq; q.want_orig = voronoi ? 0 : 1; q.pidx = nullptr; q.bloc = nullptr; q.loc_of = nullptr; q.dir = 0;
     Keys kk;
     std::memset(&kk, 0, sizeof kk);
     XfD x = identity_xf();
     if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
     ProfScope prof(ctx, ctx->stream, 1);
-    if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, L, ctx->stream, cloud, g, q, nullptr, x, (int)nq, dto);
+    if (rc) {
+    } else if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, L, ctx->stream, cloud, g, q, nullptr, x, (int)nq, dto);
     else {
       hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(nq)), dim3(kBlock), 0, ctx->stream, g, q, (const int *)nullptr, 0, kk, 1, (int)nq, (const int *)nullptr, x, (int)nq, (int *)nullptr, dto, (double *)nullptr, L.d_hard, counts);
       if (hipGetLastError() != hipSuccess) rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: launch failed");
-      if (!rc) rc = launch_hard_phases(ctx, L, ctx->stream, cloud, g, q, x, (int)nq, dto, counts, false);
+      if (!rc) rc = launch_hard_phases(ctx, L, ctx->stream, voronoi ? cloud->vor : cloud, g, q, x, (int)nq, dto, counts, false);
     }
   }
   std::vector<int> tmp((size_t)nq);
   if (!rc && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(tmp.data(), dto, sizeof(int) * nq, hipMemcpyDeviceToHost) != hipSuccess))
     rc = fail(ctx, LRR_ICP_ERR_HIP, "nearest: download failed");
-  if (!rc) for (int64_t i = 0; i < nq; ++i) idx[i] = tmp[(size_t)i];
+  if (!rc && method == LRR_ICP_NN_VORONOI) for (int64_t i = 0; i < nq; ++i) idx[i] = cloud->h_vor_site_to_orig[(size_t)tmp[(size_t)i]];  // site -> feature
+  else if (!rc) for (int64_t i = 0; i < nq; ++i) idx[i] = tmp[(size_t)i];
   (void)hipFree(dq); (void)hipFree(dto);
   return rc;
 }

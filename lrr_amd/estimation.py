@@ -17,7 +17,7 @@ HIP_SO = os.path.join(_HERE, "liblrr_icp_hip.so")
 EST_SO = os.path.join(_HERE, "liblrr_est.so")
 
 CDCL_FORWARD, RRL_FORWARD, CDCL_SYMMETRIC, RRL_SYMMETRIC = 0, 1, 2, 3
-NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
+NN_AUTO, NN_BRUTE, NN_GRID, NN_VORONOI = 0, 1, 2, 3
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
@@ -26,7 +26,7 @@ _ip = C.POINTER(C.c_int64)
 ICP_SYMBOLS = [
     "lrr_icp_create", "lrr_icp_destroy", "lrr_icp_last_error", "lrr_icp_synchronize",
     "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile", "lrr_icp_cert_stats",
-    "lrr_icp_cloud_create", "lrr_icp_cloud_destroy", "lrr_icp_cloud_size",
+    "lrr_icp_cloud_create", "lrr_icp_cloud_destroy", "lrr_icp_cloud_size", "lrr_icp_cloud_build_voronoi",
     "lrr_icp_dir_create", "lrr_icp_dir_destroy", "lrr_icp_dir_set_from", "lrr_icp_dir_num_matches",
     "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
     "lrr_icp_residual_pass", "lrr_icp_muse_scale", "lrr_icp_assign_weights",

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liblrr_oracle.so")
 
 CDCL_FORWARD, RRL_FORWARD, CDCL_SYMMETRIC, RRL_SYMMETRIC = 0, 1, 2, 3
-NN_BRUTE, NN_KDTREE = 0, 1
+NN_BRUTE, NN_KDTREE, NN_VORONOI = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)

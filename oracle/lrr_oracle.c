@@ -636,12 +636,121 @@ static int64_t nn_kd(const kdtree *t, const double *q) {
   return bi;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Voronoi index volume of the production rrl matcher                         */
+/* ------------------------------------------------------------------------- */
+/* rrl/examples/compute_distance_map.cxx:55-151 builds, per feature set, a 1 mm volume whose voxels hold
+ * the index of the nearest feature: origin = minimum corner of the features' bounding box, size[d] =
+ * ceil(extent[d]) (:104), every feature i writes its index into the voxel its location rounds to (:122-131:
+ * a later feature overwrites an earlier one of the same voxel, and index 0 is the background value of the
+ * distance filter, so feature 0 is never a site), and itk::DanielssonDistanceMapImageFilter's Voronoi map
+ * gives every voxel the value of its nearest occupied voxel (:136-150).  The matcher rounds the mapped point
+ * to a voxel, clamps it to the volume and reads the index (rrl/rrl_estimation_ICP_matching_all.txx:530-543).
+ *
+ * Restated with two choices the reference leaves to ITK (not in this image, version unpinned): physical point
+ * -> index rounds half up (floor(x + 0.5), ITK >= 3.16 with centred pixel coordinates), and the nearest
+ * occupied voxel is EXACT with ties to the lowest feature index, where Danielsson's vector propagation is an
+ * approximation with an order-dependent tie rule.  A feature whose voxel falls outside the volume (the
+ * reference writes out of bounds there) is clamped into it.  PARITY UNPINNED on both counts.
+ * The volume is filled lazily: a voxel is resolved (exact nearest site through a kd-tree over the occupied
+ * voxel centres) the first time it is looked up; afterwards a lookup is O(1), as in the reference. */
+typedef struct {
+  double origin[3];
+  int64_t size[3];
+  int64_t nsites;
+  double *site_loc;    /* voxel centres of the occupied voxels, ascending label order */
+  int64_t *site_label; /* the feature index each carries */
+  kdtree *kd;          /* over site_loc: ties -> lowest site number = lowest label */
+  int32_t *vol;        /* -1 = not resolved yet */
+} voronoi_map;
+
+static inline int64_t vor_index(const voronoi_map *m, int d, double x) {
+  double v = floor((x - m->origin[d]) + 0.5);
+  if (v < 0.0) v = 0.0;
+  if (v > (double)(m->size[d] - 1)) v = (double)(m->size[d] - 1);
+  return (int64_t)v;
+}
+
+static int cmp_i64_pair(const void *a, const void *b) {
+  const int64_t *x = (const int64_t *)a, *y = (const int64_t *)b;
+  if (x[0] != y[0]) return x[0] < y[0] ? -1 : 1;
+  return x[1] < y[1] ? -1 : (x[1] > y[1] ? 1 : 0);
+}
+
+static voronoi_map *vor_build(const double *loc, int64_t n) {
+  voronoi_map *m = (voronoi_map *)calloc(1, sizeof *m);
+  double mx[3] = { 0, 0, 0 };
+  for (int d = 0; d < 3; ++d) { m->origin[d] = n > 0 ? loc[d] : 0.0; mx[d] = m->origin[d]; }
+  for (int64_t i = 0; i < n; ++i)
+    for (int d = 0; d < 3; ++d) {
+      if (loc[3 * i + d] < m->origin[d]) m->origin[d] = loc[3 * i + d];
+      if (loc[3 * i + d] > mx[d]) mx[d] = loc[3 * i + d];
+    }
+  for (int d = 0; d < 3; ++d) {
+    m->size[d] = (int64_t)ceil(mx[d] - m->origin[d]);
+    if (m->size[d] < 1) m->size[d] = 1;
+  }
+  /* (voxel, feature) pairs sorted: the last of a voxel's run is the feature that wrote it last */
+  int64_t *pairs = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)(n > 0 ? n : 1));
+  int64_t np = 0;
+  for (int64_t i = 1; i < n; ++i) { /* feature 0 = background value */
+    int64_t ix = vor_index(m, 0, loc[3 * i]), iy = vor_index(m, 1, loc[3 * i + 1]), iz = vor_index(m, 2, loc[3 * i + 2]);
+    pairs[2 * np] = (iz * m->size[1] + iy) * m->size[0] + ix;
+    pairs[2 * np + 1] = i;
+    ++np;
+  }
+  qsort(pairs, (size_t)np, 2 * sizeof(int64_t), cmp_i64_pair);
+  int64_t *lab = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)(np > 0 ? np : 1));
+  int64_t ns = 0;
+  for (int64_t k = 0; k < np; ++k)
+    if (k + 1 == np || pairs[2 * (k + 1)] != pairs[2 * k]) { lab[2 * ns] = pairs[2 * k + 1]; lab[2 * ns + 1] = pairs[2 * k]; ++ns; }
+  qsort(lab, (size_t)ns, 2 * sizeof(int64_t), cmp_i64_pair); /* ascending label */
+  m->nsites = ns;
+  m->site_loc = (double *)malloc(sizeof(double) * 3 * (size_t)(ns > 0 ? ns : 1));
+  m->site_label = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ns > 0 ? ns : 1));
+  for (int64_t k = 0; k < ns; ++k) {
+    int64_t v = lab[2 * k + 1];
+    int64_t ix = v % m->size[0], iy = (v / m->size[0]) % m->size[1], iz = v / (m->size[0] * m->size[1]);
+    m->site_loc[3 * k] = m->origin[0] + (double)ix;
+    m->site_loc[3 * k + 1] = m->origin[1] + (double)iy;
+    m->site_loc[3 * k + 2] = m->origin[2] + (double)iz;
+    m->site_label[k] = lab[2 * k];
+  }
+  free(pairs); free(lab);
+  m->kd = kd_build(m->site_loc, ns);
+  size_t nv = (size_t)(m->size[0] * m->size[1] * m->size[2]);
+  m->vol = (int32_t *)malloc(sizeof(int32_t) * nv);
+  memset(m->vol, 0xff, sizeof(int32_t) * nv);
+  return m;
+}
+
+static void vor_free(voronoi_map *m) {
+  if (!m) return;
+  free(m->site_loc); free(m->site_label); kd_free(m->kd); free(m->vol); free(m);
+}
+
+/* rrl .txx:530-543 */
+static int64_t vor_lookup(voronoi_map *m, const double *y) {
+  if (m->nsites == 0) return 0; /* an empty map reads the background value */
+  int64_t ix = vor_index(m, 0, y[0]), iy = vor_index(m, 1, y[1]), iz = vor_index(m, 2, y[2]);
+  size_t v = (size_t)((iz * m->size[1] + iy) * m->size[0] + ix);
+  if (m->vol[v] < 0) {
+    double c[3] = { m->origin[0] + (double)ix, m->origin[1] + (double)iy, m->origin[2] + (double)iz };
+    m->vol[v] = (int32_t)m->site_label[nn_kd(m->kd, c)];
+  }
+  return m->vol[v];
+}
+
 void lrr_oracle_nn(const double *fixed_loc, int64_t nf, const double *query, int64_t nq, int backend,
                    int64_t *idx_out) {
   if (backend == LRR_ORACLE_NN_KDTREE) {
     kdtree *t = kd_build(fixed_loc, nf);
     for (int64_t i = 0; i < nq; ++i) idx_out[i] = nn_kd(t, query + 3 * i);
     kd_free(t);
+  } else if (backend == LRR_ORACLE_NN_VORONOI) {
+    voronoi_map *m = vor_build(fixed_loc, nf);
+    for (int64_t i = 0; i < nq; ++i) idx_out[i] = vor_lookup(m, query + 3 * i);
+    vor_free(m);
   } else {
     for (int64_t i = 0; i < nq; ++i) idx_out[i] = nn_brute(fixed_loc, nf, query + 3 * i);
   }
@@ -697,6 +806,7 @@ typedef struct {
   cloud moving;         /* moving_[res_] */
   cloud fixed;          /* fixed_[res_]  */
   kdtree *kd;           /* kd_tree_[res_] (built from the un-normalised locations, once) */
+  voronoi_map *vor;     /* fixed_voronoi_map_ (rrl .txx:496-498), when the backend is the Voronoi lookup */
   int nn_backend;
   int64_t *order;       /* current order of the moving_ vector */
   int64_t number_points;
@@ -723,6 +833,7 @@ static fwd_est *fwd_create(int rrl, int dof, const lrr_oracle_features *moving,
   cloud_copy_in(&f->moving, moving, rrl);
   cloud_copy_in(&f->fixed, fixed, rrl);
   if (nn_backend == LRR_ORACLE_NN_KDTREE) f->kd = kd_build(f->fixed.loc, f->fixed.n);
+  if (nn_backend == LRR_ORACLE_NN_VORONOI) f->vor = vor_build(f->fixed.loc, f->fixed.n);
   f->order = (int64_t *)malloc(sizeof(int64_t) * (size_t)(f->moving.n > 0 ? f->moving.n : 1));
   for (int64_t i = 0; i < f->moving.n; ++i) f->order[i] = i;
   f->tr = *T;
@@ -737,7 +848,7 @@ static fwd_est *fwd_create(int rrl, int dof, const lrr_oracle_features *moving,
 
 static void fwd_free(fwd_est *f) {
   if (!f) return;
-  cloud_free(&f->moving); cloud_free(&f->fixed); kd_free(f->kd);
+  cloud_free(&f->moving); cloud_free(&f->fixed); kd_free(f->kd); vor_free(f->vor);
   free(f->order); free(f->m_from); free(f->m_to); free(f->m_w); free(f->m_from_loc);
   free(f->flag); free(f->explicit_order); free(f);
 }
@@ -819,7 +930,7 @@ static void fwd_find_closest_euclidean(fwd_est *f) {
     int64_t p = f->order[i];
     double y[3];
     trans_map(&f->tr, f->moving.loc + 3 * p, y);
-    int64_t q = f->kd ? nn_kd(f->kd, y) : nn_brute(f->fixed.loc, f->fixed.n, y);
+    int64_t q = f->vor ? vor_lookup(f->vor, y) : (f->kd ? nn_kd(f->kd, y) : nn_brute(f->fixed.loc, f->fixed.n, y));
     if (q < 0) continue; /* indices.size() > 0 guard (cdcl .txx:574) */
     f->m_from[f->nmatch] = p;
     f->m_to[f->nmatch] = q;

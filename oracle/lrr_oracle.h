@@ -37,8 +37,10 @@ enum {
   LRR_ORACLE_RRL_SYMMETRIC  = 3  /* rrl_estimation_symmetric_ICP_matching_all<3,dof>   */
 };
 
-/* nearest-neighbour back-ends (both exact, ties -> lowest index) */
-enum { LRR_ORACLE_NN_BRUTE = 0, LRR_ORACLE_NN_KDTREE = 1 };
+/* nearest-neighbour back-ends: brute force and kd-tree are exact (ties -> lowest index); VORONOI is the
+ * production rrl matcher's 1 mm index-volume lookup (rrl/rrl_estimation_ICP_matching_all.txx:530-543,
+ * rrl/examples/compute_distance_map.cxx:55-151) */
+enum { LRR_ORACLE_NN_BRUTE = 0, LRR_ORACLE_NN_KDTREE = 1, LRR_ORACLE_NN_VORONOI = 2 };
 
 typedef struct lrr_oracle_est lrr_oracle_est;
 

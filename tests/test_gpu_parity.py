@@ -565,3 +565,36 @@ def test_locations_driver_against_oracle(E, ob):
     # the partition over threads / ranks does not change any location's result
     rows2, _ = locations.register_locations_sequential(pair, rois, inits, seed=19, workers=3, device_index=0)
     assert np.array_equal(rows, rows2)
+
+
+# ---- the production rrl matcher's Voronoi-volume lookup (LRR_ICP_NN_VORONOI) -----------------------------------
+def test_voronoi_lookup_equals_oracle(E, ob):
+    """the quantised lookup of rrl/rrl_estimation_ICP_matching_all.txx:530-543 on the device (exact nearest occupied
+    voxel of the query's voxel, found in the site cloud) against the oracle's lazily filled 1 mm index volume: stand-alone
+    queries inside, outside and far from the volume (clamping), then a symmetric estimator run at 50k x 50k with
+    the lookup in both directions, every iteration compared.  PARITY UNPINNED with the reference binary itself:
+    its volume comes from ITK's Danielsson filter (approximate, tie order unknown)."""
+    rng = np.random.default_rng(17)
+    pair = synth.make_pair(20000, 100, 606, kind="affine", extent=120.0)
+    fx = pair.fixed
+    q = np.concatenate([rng.uniform(-20, 140, size=(20000, 3)), fx.loc[:3000] + rng.normal(scale=0.4, size=(3000, 3)),
+                        rng.uniform(500, 600, size=(50, 3)), fx.loc[:500]])
+    want = ob.nn(fx.loc, q, ob.NN_VORONOI)
+    cloud = E.DeviceCloud(fx)
+    got = cloud.nearest(q, E.NN_VORONOI)
+    assert np.array_equal(got, want)
+    assert 0 not in got  # feature 0 is the volume's background value: never a match (compute_distance_map.cxx:131)
+    exact = cloud.nearest(q, E.NN_GRID)
+    inside = np.all((q > 0) & (q < 120), axis=1)
+    assert 0.2 < (got[inside] == exact[inside]).mean() < 1.0  # a 1 mm approximation of the exact answer, not the same thing
+    cloud.close()
+    pair = synth.make_pair(50000, 50000, 20244, kind="affine")
+    T0 = synth.perturbed(pair.planted, 4)
+    args = dict(moving_inside=pair.moving, fixed_inside=pair.fixed, seed=31)
+    g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, nn_method=E.NN_VORONOI, **args)
+    c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, nn_backend=ob.NN_VORONOI, **args)
+    for it in range(40):
+        if _compare_iteration(g, c, it, (0, 1)):
+            break
+    assert g.finest_level() and g.number_points(0) == 50000
+    g.close()

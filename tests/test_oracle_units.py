@@ -84,3 +84,33 @@ def test_sym_pinv_and_svd3(oracle_lib):
         assert np.allclose(U.T @ U, np.eye(3), atol=1e-13)
         assert np.allclose(V.T @ V, np.eye(3), atol=1e-13)
         assert np.allclose(np.sort(s), np.sort(np.linalg.svd(M, compute_uv=False)), atol=1e-13)
+
+
+def test_voronoi_volume_lookup_against_numpy(oracle_lib):
+    """the oracle's lazily filled 1 mm index volume (compute_distance_map.cxx:55-151 + rrl .txx:530-543) against a
+    dense numpy construction of the same volume: every voxel's nearest occupied voxel (exact, ties -> lowest
+    feature index), feature 0 never stored, later features overwrite earlier ones, queries clamped to the volume"""
+    import numpy as np
+    from oracle import binding as ob
+    rng = np.random.default_rng(3)
+    loc = rng.uniform(10.0, 22.0, size=(300, 3))
+    loc[50:80] = loc[20:50] + 0.2  # several features per voxel: the later one stays
+    origin = loc.min(0)
+    size = np.maximum(np.ceil(loc.max(0) - origin).astype(int), 1)
+    vox = np.clip(np.floor((loc - origin) + 0.5).astype(int), 0, size - 1)
+    label = -np.ones(size[::-1], dtype=int)  # [z, y, x]
+    for i in range(1, loc.shape[0]):
+        label[vox[i, 2], vox[i, 1], vox[i, 0]] = i
+    sites = np.argwhere(label >= 0)  # (z, y, x)
+    site_label = label[sites[:, 0], sites[:, 1], sites[:, 2]]
+    order = np.argsort(site_label)
+    sites, site_label = sites[order], site_label[order]
+    site_xyz = origin + sites[:, ::-1].astype(float)
+    q = np.concatenate([rng.uniform(5.0, 27.0, size=(4000, 3)), loc, origin + vox + 0.5])
+    qv = np.clip(np.floor((q - origin) + 0.5), 0, size - 1)
+    centre = origin + qv
+    d2 = ((centre[:, None, :] - site_xyz[None, :, :]) ** 2).sum(-1)
+    want = site_label[d2.argmin(1)]  # argmin returns the first minimum: lowest label among equidistant sites
+    got = ob.nn(loc, q, ob.NN_VORONOI)
+    assert np.array_equal(got, want)
+    assert 0 not in got
