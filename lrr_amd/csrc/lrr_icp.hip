@@ -2583,12 +2583,165 @@ __global__ __launch_bounds__(kBlock) void k_fw_accumulate(DirArgs F, FwdOpts o, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// search-grid build on the device (lrr_icp_cloud_create): counting sort of the features by x-slice of
+// their cell (raster order, the search structure) and by (tile, cell) (canonical order), both with
+// the original index as the tie rule, so the arrays do not depend on the order the atomics land in
+// ---------------------------------------------------------------------------------------------
+struct GridGeom { double lox, loy, loz, inv_h; int dx, dy, dz, fine, tdx, tdy; };
+__device__ __forceinline__ void cell_of(const GridGeom &G, double x, double y, double z, int &id, int &slice) {
+  int cx = clampi((int)floor((x - G.lox) * G.inv_h), 0, G.dx - 1);
+  int cy = clampi((int)floor((y - G.loy) * G.inv_h), 0, G.dy - 1);
+  int cz = clampi((int)floor((z - G.loz) * G.inv_h), 0, G.dz - 1);
+  id = (cz * G.dy + cy) * G.dx + cx;
+  // floor(fine * a) / fine == floor(a) for a power of two: the slice lies inside the point's cell; the clamp covers the grid boundary
+  int xf = (int)floor((x - G.lox) * (G.inv_h * G.fine));
+  xf = min(max(xf, cx * G.fine), cx * G.fine + G.fine - 1);
+  slice = id * G.fine + (xf - cx * G.fine);
+}
+// position of cell `id` in the canonical cell order: tiles of kTile^3 cells, raster order inside a tile
+__device__ __forceinline__ int canon_cell(const GridGeom &G, int id) {
+  const int cx = id % G.dx, cy = (id / G.dx) % G.dy, cz = id / (G.dx * G.dy);
+  const int tile = ((cz / kTile) * G.tdy + cy / kTile) * G.tdx + cx / kTile;
+  return tile * (kTile * kTile * kTile) + ((cz % kTile) * kTile + cy % kTile) * kTile + cx % kTile;
+}
+__global__ void k_g_count(const double *loc, int n, GridGeom G, int *slice_of, int *fine_count, int *ccount) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int id, sl;
+  cell_of(G, loc[3 * (size_t)i], loc[3 * (size_t)i + 1], loc[3 * (size_t)i + 2], id, sl);
+  slice_of[i] = sl;
+  atomicAdd(&fine_count[sl], 1);           // integer counts: order-independent
+  atomicAdd(&ccount[canon_cell(G, id)], 1);
+}
+// exclusive scan of n ints in place, three launches: per-block scan of kScanItems items, scan of the block totals, add
+constexpr int kScanThreads = 1024, kScanPer = 8, kScanItems = kScanThreads * kScanPer;
+__global__ __launch_bounds__(kScanThreads) void k_scan_blocks(int *data, long long n, int *sums) {
+  __shared__ int wave_tot[kScanThreads / 64];
+  const long long base = (long long)blockIdx.x * kScanItems + (long long)threadIdx.x * kScanPer;
+  int v[kScanPer], t = 0;
+#pragma unroll
+  for (int u = 0; u < kScanPer; ++u) { v[u] = base + u < n ? data[base + u] : 0; t += v[u]; }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = t;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { int x = __shfl_up(incl, off, 64); if (lane >= off) incl += x; }
+  if (lane == 63) wave_tot[wv] = incl;
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int w2 = 0; w2 < kScanThreads / 64; ++w2) { if (w2 < wv) before += wave_tot[w2]; total += wave_tot[w2]; }
+  int run = before + incl - t;
+#pragma unroll
+  for (int u = 0; u < kScanPer; ++u) { if (base + u < n) data[base + u] = run; run += v[u]; }
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_sums(int *sums, int nb) {
+  __shared__ int wave_tot[kScanThreads / 64];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += kScanThreads) {
+    const int b = b0 + threadIdx.x;
+    const int v = b < nb ? sums[b] : 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int x = __shfl_up(incl, off, 64); if (lane >= off) incl += x; }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w2 = 0; w2 < kScanThreads / 64; ++w2) { if (w2 < wv) before += wave_tot[w2]; total += wave_tot[w2]; }
+    if (b < nb) sums[b] = carry + before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kScanThreads) void k_scan_add(int *data, long long n, const int *sums) {
+  const int add = sums[blockIdx.x];
+  const long long base = (long long)blockIdx.x * kScanItems + (long long)threadIdx.x * kScanPer;
+#pragma unroll
+  for (int u = 0; u < kScanPer; ++u) if (base + u < n) data[base + u] += add;
+}
+__global__ void k_g_cell_start(const int *fine_start, int fine, long long ncell, int *cell_start) {
+  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c <= ncell) cell_start[c] = fine_start[c * fine];
+}
+__global__ void k_g_scatter(const int *slice_of, int n, const int *fine_start, int *cursor, int *raster_orig) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int sl = slice_of[i];
+  raster_orig[fine_start[sl] + atomicAdd(&cursor[sl], 1)] = i;  // any order inside the slice: k_g_place ranks it
+}
+// every feature finds its rank among the features of its slice / of its cell by original index: its final
+// raster position and its canonical index
+__global__ void k_g_place(const int *slice_of, const int *raster_orig, int n, GridGeom G, const int *fine_start,
+                          const int *cstart, const double *loc, int *canon_of, int *orig_of, GridPoint *gp, float4 *gpf) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int i = raster_orig[p], sl = slice_of[i], id = sl / G.fine;
+  const int s0 = fine_start[sl], s1 = fine_start[sl + 1], c0 = fine_start[id * G.fine], c1 = fine_start[(id + 1) * G.fine];
+  int rs = 0, rc = 0;
+  for (int j = c0; j < c1; ++j) {
+    const int o = raster_orig[j];
+    rc += o < i;
+    rs += (j >= s0 && j < s1 && o < i);
+  }
+  const int canon = cstart[canon_cell(G, id)] + rc;
+  canon_of[i] = canon;
+  orig_of[canon] = i;
+  const double x = loc[3 * (size_t)i], y = loc[3 * (size_t)i + 1], z = loc[3 * (size_t)i + 2];
+  GridPoint pt;
+  pt.x = x; pt.y = y; pt.z = z; pt.canon = canon; pt.orig = i;
+  gp[s0 + rs] = pt;
+  float4 f;
+  f.x = (float)((x - G.lox) * G.inv_h); f.y = (float)((y - G.loy) * G.inv_h); f.z = (float)((z - G.loz) * G.inv_h);
+  f.w = __int_as_float(canon);
+  gpf[s0 + rs] = f;
+}
+// the per-feature arrays in canonical order
+__global__ void k_g_fill(const int *orig_of, int n, const double *loc, const double *proj, const double *strength,
+                         int float_strength, double *rec, SrcPoint *src, double *str, GridPoint *cpt) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int i = orig_of[s];
+  const double x = loc[3 * (size_t)i], y = loc[3 * (size_t)i + 1], z = loc[3 * (size_t)i + 2];
+  const double *P = proj + 9 * (size_t)i;
+  double *r = rec + (size_t)s * kRecStride;
+  r[0] = x; r[1] = y; r[2] = z;
+  r[3] = P[0]; r[4] = P[1]; r[5] = P[2]; r[6] = P[4]; r[7] = P[5]; r[8] = P[8];
+  double st = strength ? strength[i] : 0.0;
+  if (float_strength) st = (double)(float)st;
+  r[9] = st;
+  str[s] = st;
+  SrcPoint sp;
+  sp.x = x; sp.y = y; sp.z = z; sp.orig = i;
+  src[s] = sp;
+  GridPoint pt;
+  pt.x = x; pt.y = y; pt.z = z; pt.canon = s; pt.orig = i;
+  cpt[s] = pt;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host helpers
 // ---------------------------------------------------------------------------------------------
 inline int grid_for(int64_t n) {  // a multiple of 8 blocks: see xcd_block
   int64_t b = ((n + kBlock - 1) / kBlock + 7) / 8 * 8;
   if (b < 8) b = 8;
   return (int)std::min<int64_t>(b, kMaxBlocks);
+}
+// exclusive scan of n ints in place on stream st; sums: scratch of >= n / kScanItems + 1 ints
+int device_scan(lrr_icp_ctx *ctx, hipStream_t st, int *data, long long n, int *sums) {
+  const int nb = (int)((n + kScanItems - 1) / kScanItems);
+  if (nb <= 0) return LRR_ICP_OK;
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(kScanThreads), 0, st, data, n, sums);
+  HIPCHK(ctx, hipGetLastError());
+  if (nb > 1) {
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanThreads), 0, st, sums, nb);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanThreads), 0, st, data, n, sums);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return LRR_ICP_OK;
 }
 inline int grid_wide(int64_t n) {  // blocks of kWide threads, a multiple of 8, at most kWideBlocks
   int64_t b = ((n + kWide - 1) / kWide + 7) / 8 * 8;
@@ -3086,99 +3239,85 @@ int lrr_icp_cloud_create(lrr_icp_ctx *ctx, int64_t n, const double *loc, const d
   if (const char *e = std::getenv("LRR_ICP_GRID_FINE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) { fine = 1; while (fine * 2 <= v) fine *= 2; } }
   while (fine > 1 && ncell * fine > (int64_t)1 << 25) fine >>= 1;
   c->fine = fine;
-  std::vector<int> cell(m), slice(m), start((size_t)ncell + 1, 0), fstart((size_t)ncell * fine + 1, 0);
-  std::vector<unsigned long long> key(m);  // (tile, cell): the canonical order
-  const int tdx = (dim[0] + kTile - 1) / kTile, tdy = (dim[1] + kTile - 1) / kTile;
-  for (int64_t i = 0; i < n; ++i) {
-    int cc[3];
-    for (int d = 0; d < 3; ++d) {
-      int v = (int)std::floor((loc[3 * i + d] - lo[d]) * c->inv_h);
-      cc[d] = v < 0 ? 0 : (v > dim[d] - 1 ? dim[d] - 1 : v);
-    }
-    int id = (cc[2] * dim[1] + cc[1]) * dim[0] + cc[0];
-    cell[(size_t)i] = id;
-    start[(size_t)id + 1]++;
-    // floor(fine * a) / fine == floor(a) for a power of two: the slice lies inside the point's cell; the clamp covers the grid boundary
-    int xf = (int)std::floor((loc[3 * i] - lo[0]) * (c->inv_h * fine));  // same expression as the kernels (fine is a power of two: exact)
-    xf = std::min(std::max(xf, cc[0] * fine), cc[0] * fine + fine - 1);
-    slice[(size_t)i] = id * fine + (xf - cc[0] * fine);
-    fstart[(size_t)slice[(size_t)i] + 1]++;
-    unsigned long long tile = (unsigned long long)(((cc[2] / kTile) * tdy + cc[1] / kTile) * tdx + cc[0] / kTile);
-    key[(size_t)i] = (tile << 32) | (unsigned)id;
-  }
-  for (int64_t k = 0; k < ncell; ++k) start[(size_t)k + 1] += start[(size_t)k];
-  for (int64_t k = 0; k < ncell * fine; ++k) fstart[(size_t)k + 1] += fstart[(size_t)k];
-  std::vector<int> orig_of(m, 0), canon_of(m, 0);
-  for (int64_t i = 0; i < n; ++i) orig_of[(size_t)i] = (int)i;
-  std::sort(orig_of.begin(), orig_of.begin() + n, [&](int a, int b) { return key[(size_t)a] != key[(size_t)b] ? key[(size_t)a] < key[(size_t)b] : a < b; });
-  for (int64_t s = 0; s < n; ++s) canon_of[(size_t)orig_of[(size_t)s]] = (int)s;
-  std::vector<double> rec(m * kRecStride, 0.0);
-  std::vector<SrcPoint> src(m);
-  std::vector<Chunk> chunks;
-  for (int64_t s = 0; s < n; ++s) {
-    int i = orig_of[(size_t)s];
-    const double *P = proj + 9 * (int64_t)i;
-    double *r = &rec[(size_t)s * kRecStride];
-    r[0] = loc[3 * (int64_t)i]; r[1] = loc[3 * (int64_t)i + 1]; r[2] = loc[3 * (int64_t)i + 2];
-    r[3] = P[0]; r[4] = P[1]; r[5] = P[2]; r[6] = P[4]; r[7] = P[5]; r[8] = P[8];
-    double st = strength ? strength[i] : 0.0;
-    r[9] = float_strength ? (double)(float)st : st;
-    src[(size_t)s] = SrcPoint{r[0], r[1], r[2], (long long)i};
-    unsigned long long tile = key[(size_t)i] >> 32;
-    if (chunks.empty() || chunks.back().count == kBlock || (key[(size_t)orig_of[(size_t)chunks.back().start]] >> 32) != tile)
-      chunks.push_back(Chunk{(int)s, 0});
-    chunks.back().count++;
-  }
-  std::vector<int> cursor(fstart.begin(), fstart.end() - 1);
-  std::vector<GridPoint> gp(m);
-  for (int64_t i = 0; i < n; ++i) {  // ascending i: original order kept inside a slice
-    int pos = cursor[(size_t)slice[(size_t)i]]++;
-    gp[(size_t)pos] = GridPoint{loc[3 * i], loc[3 * i + 1], loc[3 * i + 2], canon_of[(size_t)i], (int)i};
-  }
-  std::vector<float4> gpf(m);
-  for (size_t k = 0; k < (size_t)n; ++k) {
-    const GridPoint &pt = gp[k];
-    float4 f;
-    f.x = (float)((pt.x - lo[0]) * c->inv_h); f.y = (float)((pt.y - lo[1]) * c->inv_h); f.z = (float)((pt.z - lo[2]) * c->inv_h);
-    f.w = __int_as_float_host(pt.canon);
-    gpf[k] = f;
-  }
-  std::vector<GridPoint> cpt(m);
-  std::vector<double> strv(m, 0.0);
-  for (int64_t sidx = 0; sidx < n; ++sidx) strv[(size_t)sidx] = rec[(size_t)sidx * kRecStride + 9];
-  for (int64_t sidx = 0; sidx < n; ++sidx) {
-    const int i = orig_of[(size_t)sidx];
-    cpt[(size_t)sidx] = GridPoint{loc[3 * (int64_t)i], loc[3 * (int64_t)i + 1], loc[3 * (int64_t)i + 2], (int)sidx, i};
-  }
-  c->nchunks = (int)chunks.size();
-  if (chunks.empty()) chunks.push_back(Chunk{0, 0});
+  // The grid is built on the device: the raw arrays go up once, a counting sort by x-slice gives the raster
+  // order (the search structure), a second count by (tile, cell) the canonical order; ranks inside a slice /
+  // cell are by original index, so the result does not depend on the order the atomics land in.
+  const int tdx = (dim[0] + kTile - 1) / kTile, tdy = (dim[1] + kTile - 1) / kTile, tdz = (dim[2] + kTile - 1) / kTile;
+  const long long ntile = (long long)tdx * tdy * tdz, nccell = ntile * (kTile * kTile * kTile);
+  const long long nfine = (long long)ncell * fine;
   auto cleanup = [&](int code, const std::string &msg) { lrr_icp_cloud_destroy(c); return fail(ctx, code, msg); };
-  // one device slab for all arrays and one upload of its host image: a query location re-creates
-  // its two ROI clouds (config 5), and every hipMalloc / hipMemcpy costs tens of microseconds
-  struct Part { void **dst; const void *src; size_t bytes, off; };
+  struct Part { void **dst; size_t bytes, off; };
+  Chunk *d_chunks_dummy = nullptr;
+  (void)d_chunks_dummy;
+  const size_t max_chunks = (size_t)(n / kBlock + ntile + 1);
   Part parts[] = {
-      {(void **)&c->rec, rec.data(), sizeof(double) * m * kRecStride, 0},
-      {(void **)&c->src, src.data(), sizeof(SrcPoint) * m, 0},
-      {(void **)&c->gp, gp.data(), sizeof(GridPoint) * m, 0},
-      {(void **)&c->cpt, cpt.data(), sizeof(GridPoint) * m, 0},
-      {(void **)&c->gpf, gpf.data(), sizeof(float4) * m, 0},
-      {(void **)&c->str, strv.data(), sizeof(double) * m, 0},
-      {(void **)&c->loc_orig, loc, sizeof(double) * 3 * (size_t)n, 0},
-      {(void **)&c->shp, nullptr, sizeof(ShapeRec) * m, 0},
-      {(void **)&c->orig_of, orig_of.data(), sizeof(int) * m, 0},
-      {(void **)&c->canon_of, canon_of.data(), sizeof(int) * m, 0},
-      {(void **)&c->cell_start, start.data(), sizeof(int) * ((size_t)ncell + 1), 0},
-      {(void **)&c->fine_start, fstart.data(), sizeof(int) * fstart.size(), 0},
-      {(void **)&c->chunks, chunks.data(), sizeof(Chunk) * chunks.size(), 0},
+      {(void **)&c->rec, sizeof(double) * m * kRecStride, 0},
+      {(void **)&c->src, sizeof(SrcPoint) * m, 0},
+      {(void **)&c->gp, sizeof(GridPoint) * m, 0},
+      {(void **)&c->cpt, sizeof(GridPoint) * m, 0},
+      {(void **)&c->gpf, sizeof(float4) * m, 0},
+      {(void **)&c->str, sizeof(double) * m, 0},
+      {(void **)&c->loc_orig, sizeof(double) * 3 * m, 0},
+      {(void **)&c->shp, sizeof(ShapeRec) * m, 0},
+      {(void **)&c->orig_of, sizeof(int) * m, 0},
+      {(void **)&c->canon_of, sizeof(int) * m, 0},
+      {(void **)&c->cell_start, sizeof(int) * ((size_t)ncell + 1), 0},
+      {(void **)&c->fine_start, sizeof(int) * ((size_t)nfine + 1), 0},
+      {(void **)&c->chunks, sizeof(Chunk) * max_chunks, 0},
   };
   size_t total = 0;
   for (Part &pt : parts) { pt.off = total; total += (pt.bytes + 255) & ~(size_t)255; }
-  std::vector<unsigned char> image(total, 0);
-  for (const Part &pt : parts) if (pt.src) std::memcpy(image.data() + pt.off, pt.src, pt.bytes);
   if (hipMalloc(&c->slab, total) != hipSuccess) return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
-  if (hipMemcpy(c->slab, image.data(), total, hipMemcpyHostToDevice) != hipSuccess) return cleanup(LRR_ICP_ERR_HIP, "cloud_create: upload failed");
   for (const Part &pt : parts) *pt.dst = (unsigned char *)c->slab + pt.off;
-  c->h_orig_of.assign(orig_of.begin(), orig_of.end());
+  hipStream_t st = ctx->stream;
+  // build scratch: projectors, strengths, slice of every feature, raster permutation, cursors, canonical cell counts, scan sums
+  const size_t nsums = (size_t)(std::max(nfine, nccell) / kScanItems + 2);
+  const size_t scratch_bytes = sizeof(double) * (9 * m + m) + sizeof(int) * (2 * m + (size_t)nfine + 1 + (size_t)nccell + 1 + nsums);
+  unsigned char *scratch = nullptr;
+  if (hipMalloc(&scratch, scratch_bytes) != hipSuccess) return cleanup(LRR_ICP_ERR_HIP, "cloud_create: hipMalloc failed");
+  double *d_proj = (double *)scratch, *d_str = d_proj + 9 * m;
+  int *d_slice = (int *)(d_str + m), *d_raster = d_slice + m, *d_cursor = d_raster + m, *d_cstart = d_cursor + (size_t)nfine + 1, *d_sums = d_cstart + (size_t)nccell + 1;
+  auto bail = [&](const char *what) { (void)hipStreamSynchronize(st); (void)hipFree(scratch); return cleanup(LRR_ICP_ERR_HIP, std::string("cloud_create: ") + what); };
+  bool ok = true;
+  if (n > 0) {
+    ok = ok && hipMemcpyAsync(c->loc_orig, loc, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d_proj, proj, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice, st) == hipSuccess;
+    if (strength) ok = ok && hipMemcpyAsync(d_str, strength, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st) == hipSuccess;
+  }
+  ok = ok && hipMemsetAsync(c->fine_start, 0, sizeof(int) * ((size_t)nfine + 1), st) == hipSuccess;
+  ok = ok && hipMemsetAsync(d_cursor, 0, sizeof(int) * ((size_t)nfine + 1), st) == hipSuccess;
+  ok = ok && hipMemsetAsync(d_cstart, 0, sizeof(int) * ((size_t)nccell + 1), st) == hipSuccess;
+  if (!ok) return bail("upload failed");
+  GridGeom G;
+  G.lox = lo[0]; G.loy = lo[1]; G.loz = lo[2]; G.inv_h = c->inv_h;
+  G.dx = dim[0]; G.dy = dim[1]; G.dz = dim[2]; G.fine = fine; G.tdx = tdx; G.tdy = tdy;
+  std::vector<int> tile_start((size_t)ntile + 1, 0);
+  if (n > 0) {
+    const int nbn = blocks_for(n);
+    hipLaunchKernelGGL(k_g_count, dim3(nbn), dim3(kBlock), 0, st, c->loc_orig, (int)n, G, d_slice, c->fine_start, d_cstart);
+    if (device_scan(ctx, st, c->fine_start, nfine + 1, d_sums) || device_scan(ctx, st, d_cstart, nccell + 1, d_sums)) return bail("scan failed");
+    hipLaunchKernelGGL(k_g_cell_start, dim3((unsigned)((ncell + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, c->fine_start, fine, (long long)ncell, c->cell_start);
+    hipLaunchKernelGGL(k_g_scatter, dim3(nbn), dim3(kBlock), 0, st, d_slice, (int)n, c->fine_start, d_cursor, d_raster);
+    hipLaunchKernelGGL(k_g_place, dim3(nbn), dim3(kBlock), 0, st, d_slice, d_raster, (int)n, G, c->fine_start, d_cstart, c->loc_orig, c->canon_of, c->orig_of, c->gp, c->gpf);
+    hipLaunchKernelGGL(k_g_fill, dim3(nbn), dim3(kBlock), 0, st, c->orig_of, (int)n, c->loc_orig, d_proj, strength ? d_str : (const double *)nullptr, float_strength, c->rec, c->src, c->str, c->cpt);
+    if (hipGetLastError() != hipSuccess) return bail("grid build launch failed");
+    // the chunk table of the tile kernel (runs of <= kBlock canonical features of one tile) from the tile starts
+    if (hipMemcpy2DAsync(tile_start.data(), sizeof(int), d_cstart, sizeof(int) * (kTile * kTile * kTile), sizeof(int), (size_t)ntile + 1, hipMemcpyDeviceToHost, st) != hipSuccess)
+      return bail("download failed");
+  } else {
+    if (hipMemsetAsync(c->cell_start, 0, sizeof(int) * ((size_t)ncell + 1), st) != hipSuccess) return bail("memset failed");
+  }
+  c->h_orig_of.assign(m, 0);
+  if (n > 0 && hipMemcpyAsync(c->h_orig_of.data(), c->orig_of, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, st) != hipSuccess) return bail("download failed");
+  if (hipStreamSynchronize(st) != hipSuccess) return bail("grid build failed");
+  std::vector<Chunk> chunks;
+  for (long long t = 0; t < ntile; ++t)
+    for (int s0 = tile_start[(size_t)t]; s0 < tile_start[(size_t)t + 1]; s0 += kBlock)
+      chunks.push_back(Chunk{s0, std::min(kBlock, tile_start[(size_t)t + 1] - s0)});
+  c->nchunks = (int)chunks.size();
+  if (chunks.size() > max_chunks) return bail("chunk table overflow");
+  if (!chunks.empty() && hipMemcpy(c->chunks, chunks.data(), sizeof(Chunk) * chunks.size(), hipMemcpyHostToDevice) != hipSuccess) return bail("upload failed");
+  (void)hipFree(scratch);
   *out = c;
   return LRR_ICP_OK;
 }
