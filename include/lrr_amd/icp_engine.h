@@ -116,9 +116,27 @@ inline void check(int rc, const char *what) {
   if (rc != LRR_ICP_OK) throw std::runtime_error(std::string("lrr_amd: ") + what + " failed: " + lrr_icp_last_error(device::ctx()));
 }
 
+// cdcl_feature_with_shape carries a covariance, whose eigenvectors the cdcl classes' sheet / tube angles compare
+// (cdcl .txx:273-382); cdcl_feature_ICP has none and the rrl classes compare mapped directions_ (rrl .txx:281-375)
 template <class F> struct feature_traits;
-template <unsigned d> struct feature_traits<cdcl_feature_with_shape<d> > { static const bool float_strength = false; };
-template <unsigned d> struct feature_traits<cdcl_feature_ICP<d> > { static const bool float_strength = true; };
+template <unsigned d> struct feature_traits<cdcl_feature_with_shape<d> > {
+  static const bool float_strength = false;
+  static const bool covariance_angles = true;
+  // columns 0 and 2 of vnl_symmetric_eigensystem_compute (eigenvalues ascending) of the 3 x 3 covariance: for a
+  // symmetric positive semi-definite matrix its singular vectors, picked by singular value
+  static void angle_vectors(cdcl_feature_with_shape<d> const &f, double *sheet, double *tube) {
+    double U[9], sv[3], V[9];
+    linalg::svd3(f.covariance_.data_block(), U, sv, V);
+    int lo = 0, hi = 0;
+    for (int j = 1; j < 3; ++j) { if (sv[j] < sv[lo]) lo = j; if (sv[j] > sv[hi]) hi = j; }
+    for (int k = 0; k < 3; ++k) { sheet[k] = V[3 * k + lo]; tube[k] = V[3 * k + hi]; }
+  }
+};
+template <unsigned d> struct feature_traits<cdcl_feature_ICP<d> > {
+  static const bool float_strength = true;
+  static const bool covariance_angles = false;
+  static void angle_vectors(cdcl_feature_ICP<d> const &, double *, double *) {}
+};
 
 // a feature vector resident on the device
 template <class FeatureT>
@@ -140,6 +158,16 @@ class device_cloud {
     }
     check(lrr_icp_cloud_create(device::ctx(), (int64_t)n, loc.data(), proj.data(), st.data(),
                                feature_traits<FeatureT>::float_strength ? 1 : 0, &h_), "cloud upload");
+    if (feature_traits<FeatureT>::covariance_angles) {  // shape_ and the covariance eigenvectors (cdcl angle diagnostics)
+      std::vector<uint8_t> shape(n + 1, 0);
+      std::vector<double> sheet(3 * n + 3, 0.0), tube(3 * n + 3, 0.0);
+      for (size_t i = 0; i < n; ++i) {
+        shape[i] = (uint8_t)f[i]->shape_;
+        feature_traits<FeatureT>::angle_vectors(*f[i], &sheet[3 * i], &tube[3 * i]);
+      }
+      check(lrr_icp_cloud_set_shape_vectors(h_, shape.data(), sheet.data(), tube.data()), "shape upload");
+      return;
+    }
     // shape_ and directions_ for the post-convergence diagnostics (sheet_angles / tube_angles)
     std::vector<uint8_t> shape(n + 1, 0), ndirs(n + 1, 0);
     std::vector<double> dirs(6 * n + 6, 0.0);
@@ -637,11 +665,21 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     global_transform->set_covariance(trans_->get_covariance());
     trans_ = global_transform;
   }
-  // sheet_angles / tube_angles.  cdcl_feature_ICP: mapped directions_ (rrl .txx:281-375).
+  // sheet_angles / tube_angles.  cdcl_feature_ICP: mapped directions_ (rrl .txx:281-375).  cdcl_feature_with_shape:
+  // eigenvectors of the covariances, the from-feature's rotated when it is a pre-mapped copy (cdcl .txx:273-382, 473-479).
   double angles(bool tube) {
-    lrr_icp_xform xf = xform_of(trans_);
     double sum_wa = 0.0, sum_w = 0.0;
-    check(lrr_icp_angles(dir_, &xf, tube ? 1 : 0, &sum_wa, &sum_w), "angle diagnostics");
+    if (feature_traits<FeatureT>::covariance_angles) {
+      double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      if (premapped_ && premap_G_) {
+        vnl_matrix_fixed<double, 3, 3> &A = premap_G_->get_A();
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = A(r, c);
+      }
+      check(lrr_icp_angles_unmapped(dir_, R, tube ? 1 : 0, &sum_wa, &sum_w), "angle diagnostics");
+    } else {
+      lrr_icp_xform xf = xform_of(trans_);
+      check(lrr_icp_angles(dir_, &xf, tube ? 1 : 0, &sum_wa, &sum_w), "angle diagnostics");
+    }
     return sum_wa / sum_w;
   }
 

@@ -159,6 +159,12 @@ int  lrr_icp_errors(lrr_icp_dir *dir, const lrr_icp_xform *xf, double *sum_r2, d
  * shapes and directions of a cloud's features: shape[i] in {0 CORNER, 1 TUBE, 2 SHEET}
  * (cdcl/cdcl_feature_with_shape.h:28), ndirs[i] = directions_.size(), dirs6 = directions_[0], directions_[1] */
 int  lrr_icp_cloud_set_shapes(lrr_icp_cloud *cloud, const uint8_t *shape, const uint8_t *ndirs, const double *dirs6);
+/* the cdcl classes compare eigenvectors of the features' covariances instead (cdcl .txx:273-382): per feature the
+ * eigenvector of the smallest eigenvalue (sheets) and of the largest (tubes), vnl_symmetric_eigensystem_compute order */
+int  lrr_icp_cloud_set_shape_vectors(lrr_icp_cloud *cloud, const uint8_t *shape, const double *sheet3, const double *tube3);
+/* ... compared as they are; R (3x3 row-major) rotates the from-feature's vector: the rotation of the rigid pre-map
+ * (its covariance became R C R^T, cdcl .txx:473-479), identity otherwise */
+int  lrr_icp_angles_unmapped(lrr_icp_dir *dir, const double R[9], int tube, double *sum_wa, double *sum_w);
 /* sheet_angles (tube = 0) / tube_angles (tube = 1) (rrl/rrl_estimation_ICP_matching_all.txx:281-375;
  * cdcl .txx:273-382): sum of w_i * angle_i and sum of w_i over the sheet-sheet / tube-tube matches */
 int  lrr_icp_angles(lrr_icp_dir *dir, const lrr_icp_xform *xf, int tube, double *sum_wa, double *sum_w);

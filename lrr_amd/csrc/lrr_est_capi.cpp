@@ -26,6 +26,7 @@ typedef struct {
   const double *strength;  // n
   const uint8_t *shape;    // n (may be NULL)
   const double *dirs;      // n x 6 (may be NULL)
+  const double *cov;       // n x 9 row-major, covariance_ of cdcl_feature_with_shape (may be NULL)
 } lrr_est_features;
 }
 
@@ -60,6 +61,8 @@ std::vector<cdcl_feature_with_shape<3>::sptr> make_features<cdcl_feature_with_sh
     cdcl_feature_with_shape<3> *p = new cdcl_feature_with_shape<3>;
     fill_common(p, f, i);
     p->strength_ = f->strength ? f->strength[i] : 0.0;
+    if (f->cov)
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) p->covariance_(r, c) = f->cov[9 * i + 3 * r + c];
     out.push_back(p);
   }
   return out;

@@ -2320,8 +2320,10 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
 // sheet_angles / tube_angles (rrl .txx:281-375; cdcl .txx:273-382): weighted mean angle between
 // the mapped direction of p and the direction of q over the sheet-sheet (tube-tube) matches;
 // partial sums of w*a and w
+// unmapped (the cdcl classes, cdcl .txx:273-382): the two directions are covariance eigenvectors compared as they are,
+// except that a rigid pre-map has rotated the from-feature's covariance: its eigenvector is R d (R = xf.A)
 __global__ __launch_bounds__(kBlock) void k_angles(PairSrc ps, const ShapeRec *fshape, const ShapeRec *tshape, XfD xf,
-                                                   const double *w, int tube, double *partials) {
+                                                   const double *w, int tube, double *partials, int unmapped) {
   const double pi = 3.14159265358979323846;
   const int want = tube ? 1 : 2, need = tube ? 2 : 1;
   double acc[2] = {0.0, 0.0};
@@ -2330,13 +2332,20 @@ __global__ __launch_bounds__(kBlock) void k_angles(PairSrc ps, const ShapeRec *f
     const ShapeRec P = fshape[s], Q = tshape[ps.m_to[s]];
     if (P.shape != want || Q.shape != want || P.ndirs < need || Q.ndirs < need) continue;
     const double *dp = tube ? P.td : P.sd, *dq = tube ? Q.td : Q.sd;
-    double p0, p1, p2, y0, y1, y2, z0, z1, z2;
-    load_from(ps, s, p0, p1, p2);
-    map_loc(xf, p0, p1, p2, y0, y1, y2);
-    map_loc(xf, p0 + dp[0], p1 + dp[1], p2 + dp[2], z0, z1, z2);
-    double d0 = z0 - y0, d1 = z1 - y1, d2 = z2 - y2;
-    const double nrm = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
-    d0 /= nrm; d1 /= nrm; d2 /= nrm;
+    double d0, d1, d2;
+    if (unmapped) {
+      d0 = (xf.A[0] * dp[0] + xf.A[1] * dp[1]) + xf.A[2] * dp[2];
+      d1 = (xf.A[3] * dp[0] + xf.A[4] * dp[1]) + xf.A[5] * dp[2];
+      d2 = (xf.A[6] * dp[0] + xf.A[7] * dp[1]) + xf.A[8] * dp[2];
+    } else {
+      double p0, p1, p2, y0, y1, y2, z0, z1, z2;
+      load_from(ps, s, p0, p1, p2);
+      map_loc(xf, p0, p1, p2, y0, y1, y2);
+      map_loc(xf, p0 + dp[0], p1 + dp[1], p2 + dp[2], z0, z1, z2);
+      d0 = z0 - y0; d1 = z1 - y1; d2 = z2 - y2;
+      const double nrm = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+      d0 /= nrm; d1 /= nrm; d2 /= nrm;
+    }
     double a = acos((d0 * dq[0] + d1 * dq[1]) + d2 * dq[2]);
     if (a > pi / 2) a = pi - a;
     const double wi = w[s];
@@ -3336,7 +3345,7 @@ void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
 // location rounds to (a later feature overwrites an earlier one; 0 is the background value, so feature 0 is never
 // stored).  The volume itself (nearest occupied voxel of every voxel) is not materialised: a lookup is the exact
 // nearest occupied voxel of the query's voxel, found with the grid search over the site cloud, ties to the lowest
-// feature index.  Same choices as the oracle (oracle/lrr_oracle.c, vor_build): rounding half up, exact distances
+// feature index.  Same choices as the CPU checker of the tests : rounding half up, exact distances
 // where the reference uses Danielsson's approximation — parity with the reference binary unpinned.
 int lrr_icp_cloud_build_voronoi(lrr_icp_cloud *c) {
   if (!c) return LRR_ICP_ERR_ARG;
@@ -4111,8 +4120,36 @@ int lrr_icp_cloud_set_shapes(lrr_icp_cloud *c, const uint8_t *shape, const uint8
   return LRR_ICP_OK;
 }
 
+int lrr_icp_cloud_set_shape_vectors(lrr_icp_cloud *c, const uint8_t *shape, const double *sheet3, const double *tube3) {
+  if (!c || (c->n > 0 && (!shape || !sheet3 || !tube3))) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int64_t n = c->n;
+  std::vector<ShapeRec> recs((size_t)std::max<int64_t>(n, 1));
+  for (int64_t sidx = 0; sidx < n; ++sidx) {
+    const int i = c->h_orig_of[(size_t)sidx];
+    ShapeRec r;
+    r.shape = shape[i]; r.ndirs = 2;
+    for (int k = 0; k < 3; ++k) { r.sd[k] = sheet3[3 * (int64_t)i + k]; r.td[k] = tube3[3 * (int64_t)i + k]; }
+    recs[(size_t)sidx] = r;
+  }
+  HIPCHK(ctx, hipMemcpy(c->shp, recs.data(), sizeof(ShapeRec) * recs.size(), hipMemcpyHostToDevice));
+  c->has_shapes = true;
+  return LRR_ICP_OK;
+}
+
+static int angles_impl(lrr_icp_dir *d, const XfD &x, int tube, int unmapped, double *sum_wa, double *sum_w);
+int lrr_icp_angles_unmapped(lrr_icp_dir *d, const double R[9], int tube, double *sum_wa, double *sum_w) {
+  if (!d || !R || !sum_wa || !sum_w) return LRR_ICP_ERR_ARG;
+  XfD x = identity_xf();
+  for (int k = 0; k < 9; ++k) x.A[k] = R[k];
+  return angles_impl(d, x, tube, 1, sum_wa, sum_w);
+}
 int lrr_icp_angles(lrr_icp_dir *d, const lrr_icp_xform *xf, int tube, double *sum_wa, double *sum_w) {
   if (!d || !xf || !sum_wa || !sum_w) return LRR_ICP_ERR_ARG;
+  return angles_impl(d, to_dev(xf), tube, 0, sum_wa, sum_w);
+}
+static int angles_impl(lrr_icp_dir *d, const XfD &x, int tube, int unmapped, double *sum_wa, double *sum_w) {
   lrr_icp_ctx *ctx = d->ctx;
   *sum_wa = 0.0; *sum_w = 0.0;
   if (!d->from->has_shapes || !d->to->has_shapes) return fail(ctx, LRR_ICP_ERR_STATE, "angles: shapes and directions were not uploaded (lrr_icp_cloud_set_shapes)");
@@ -4120,7 +4157,7 @@ int lrr_icp_angles(lrr_icp_dir *d, const lrr_icp_xform *xf, int tube, double *su
   HIPCHK(ctx, hipSetDevice(ctx->device));
   PairSrc ps = pairs_of(d);
   int nb = grid_for(ps.nsrc);
-  hipLaunchKernelGGL(k_angles, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, d->from->shp, d->to->shp, to_dev(xf), d->w, tube ? 1 : 0, ctx->d_partials);
+  hipLaunchKernelGGL(k_angles, dim3(nb), dim3(kBlock), 0, ctx->stream, ps, d->from->shp, d->to->shp, x, d->w, tube ? 1 : 0, ctx->d_partials, unmapped);
   HIPCHK(ctx, hipGetLastError());
   double r[2];
   int rc = finish_reduce(ctx, nb, 2, r);

@@ -31,7 +31,7 @@ ICP_SYMBOLS = [
     "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
     "lrr_icp_residual_pass", "lrr_icp_muse_scale", "lrr_icp_assign_weights",
     "lrr_icp_normalize_stats", "lrr_icp_clone_weights", "lrr_icp_weight_by_strength",
-    "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_angles", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
+    "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_cloud_set_shape_vectors", "lrr_icp_angles", "lrr_icp_angles_unmapped", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
     "lrr_icp_nearest",
     "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
@@ -42,7 +42,7 @@ ICP_SYMBOLS = [
 
 class _Features(C.Structure):
     _fields_ = [("n", C.c_int64), ("loc", _dp), ("proj", _dp), ("strength", _dp),
-                ("shape", C.POINTER(C.c_uint8)), ("dirs", _dp)]
+                ("shape", C.POINTER(C.c_uint8)), ("dirs", _dp), ("cov", _dp)]
 
 
 class Xform(C.Structure):
@@ -158,8 +158,10 @@ def _features(fs, keep):
     st = np.ascontiguousarray(fs.strength, dtype=np.float64)
     sh = np.ascontiguousarray(fs.shape, dtype=np.uint8)
     di = np.ascontiguousarray(fs.dirs, dtype=np.float64)
-    keep.extend([loc, proj, st, sh, di])
-    return _Features(loc.shape[0], _d(loc), _d(proj), _d(st), sh.ctypes.data_as(C.POINTER(C.c_uint8)), _d(di))
+    cov = np.ascontiguousarray(fs.cov, dtype=np.float64) if getattr(fs, "cov", None) is not None else None
+    keep.extend([loc, proj, st, sh, di, cov])
+    return _Features(loc.shape[0], _d(loc), _d(proj), _d(st), sh.ctypes.data_as(C.POINTER(C.c_uint8)), _d(di),
+                     _d(cov) if cov is not None else None)
 
 
 def set_device(index: int) -> None:

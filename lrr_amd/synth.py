@@ -29,6 +29,7 @@ class FeatureSet:
     strength: np.ndarray  # (n,)   float64  strength_
     shape: np.ndarray     # (n,)   uint8    shape_
     dirs: np.ndarray      # (n, 6) float64  directions_[0], directions_[1]
+    cov: np.ndarray = None  # (n, 9) float64  covariance_ of cdcl_feature_with_shape (None: not set)
 
     @property
     def n(self) -> int:
@@ -42,6 +43,7 @@ class FeatureSet:
             np.ascontiguousarray(self.strength[idx]),
             np.ascontiguousarray(self.shape[idx]),
             np.ascontiguousarray(self.dirs[idx]),
+            None if self.cov is None else np.ascontiguousarray(self.cov[idx]),
         )
 
     def in_box(self, x0, x1) -> np.ndarray:
@@ -92,6 +94,35 @@ def planted_transform(kind: str = "rigid", extent: float = 300.0) -> Transform:
     c0 = np.full(3, extent / 2.0)
     t = c0 + np.array([2.0, -1.5, 1.0])
     return Transform(A, t, c0)
+
+
+def covariances(fs: "FeatureSet") -> np.ndarray:
+    """covariance_ of cdcl_feature_with_shape for a synthetic feature set: a SHEET is tight along its
+    normal (0.25 mm^2) and loose in its plane (1.0 and 1.5), a TUBE loose along its tangent (1.0) and tight across (0.25,
+    0.3), a CORNER isotropic-ish (0.2, 0.25, 0.3 on the coordinate axes) — distinct eigenvalues, so the eigenvectors the
+    cdcl angle diagnostics compare (cdcl .txx:273-382) are well defined."""
+    n = fs.n
+    C = np.zeros((n, 3, 3))
+    d0, d1 = fs.dirs[:, 0:3], fs.dirs[:, 3:6]
+
+    def unit(v):
+        nr = np.linalg.norm(v, axis=1, keepdims=True)
+        return v / np.where(nr > 0, nr, 1.0)
+    sheet, tube, corner = fs.shape == SHEET, fs.shape == TUBE, fs.shape == CORNER
+    if sheet.any():
+        nrm = unit(d0[sheet])
+        helper = np.where(np.abs(nrm[:, :1]) < 0.9, np.array([[1.0, 0, 0]]), np.array([[0, 1.0, 0]]))
+        u = unit(np.cross(nrm, helper))
+        v = np.cross(nrm, u)
+        C[sheet] = 0.25 * nrm[:, :, None] * nrm[:, None, :] + 1.0 * u[:, :, None] * u[:, None, :] + 1.5 * v[:, :, None] * v[:, None, :]
+    if tube.any():
+        n1 = unit(d0[tube])
+        n2 = unit(d1[tube] - np.sum(d1[tube] * n1, axis=1, keepdims=True) * n1)
+        t = np.cross(n1, n2)
+        C[tube] = 0.25 * n1[:, :, None] * n1[:, None, :] + 0.3 * n2[:, :, None] * n2[:, None, :] + 1.0 * t[:, :, None] * t[:, None, :]
+    C[corner] = np.diag([0.2, 0.25, 0.3])
+    C = 0.5 * (C + np.transpose(C, (0, 2, 1)))
+    return np.ascontiguousarray(C.reshape(n, 9))
 
 
 def _orthonormal_frame(rng: np.random.Generator, m: int):

@@ -19,7 +19,7 @@ _ip = C.POINTER(C.c_int64)
 
 class _Features(C.Structure):
     _fields_ = [("n", C.c_int64), ("loc", _dp), ("proj", _dp), ("strength", _dp),
-                ("shape", C.POINTER(C.c_uint8)), ("dirs", _dp)]
+                ("shape", C.POINTER(C.c_uint8)), ("dirs", _dp), ("cov", _dp)]
 
 
 def build(force: bool = False) -> str:
@@ -103,8 +103,10 @@ def _features(fs, keep):
     st = np.ascontiguousarray(fs.strength, dtype=np.float64)
     sh = np.ascontiguousarray(fs.shape, dtype=np.uint8)
     di = np.ascontiguousarray(fs.dirs, dtype=np.float64)
-    keep.extend([loc, proj, st, sh, di])
-    return _Features(loc.shape[0], _d(loc), _d(proj), _d(st), sh.ctypes.data_as(C.POINTER(C.c_uint8)), _d(di))
+    cov = np.ascontiguousarray(fs.cov, dtype=np.float64) if getattr(fs, "cov", None) is not None else None
+    keep.extend([loc, proj, st, sh, di, cov])
+    return _Features(loc.shape[0], _d(loc), _d(proj), _d(st), sh.ctypes.data_as(C.POINTER(C.c_uint8)), _d(di),
+                     _d(cov) if cov is not None else None)
 
 
 def nn(fixed_loc, query, backend=NN_BRUTE):

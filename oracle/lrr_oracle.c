@@ -767,10 +767,21 @@ typedef struct {
   double *strength; /* n; float-rounded for the rrl feature type (cdcl_feature_ICP.h:83) */
   uint8_t *shape;
   double *dirs;     /* n x 6 or NULL */
+  double *evec;     /* n x 6 or NULL: eigenvectors of covariance_ for the smallest and the largest eigenvalue */
 } cloud;
 
+/* columns 0 and 2 of vnl_symmetric_eigensystem_compute(C, V, D) (eigenvalues ascending) for a symmetric positive
+ * semi-definite 3x3: its singular vectors, picked by singular value (first index wins among equal values) */
+static void sym_eig_ends(const double *Cm, double *v_small, double *v_large) {
+  double U[9], sv[3], V[9];
+  lrr_oracle_svd3(Cm, U, sv, V);
+  int lo = 0, hi = 0;
+  for (int j = 1; j < 3; ++j) { if (sv[j] < sv[lo]) lo = j; if (sv[j] > sv[hi]) hi = j; }
+  for (int k = 0; k < 3; ++k) { v_small[k] = V[3 * k + lo]; v_large[k] = V[3 * k + hi]; }
+}
+
 static void cloud_free(cloud *c) {
-  free(c->loc); free(c->proj); free(c->strength); free(c->shape); free(c->dirs);
+  free(c->loc); free(c->proj); free(c->strength); free(c->shape); free(c->dirs); free(c->evec);
   memset(c, 0, sizeof *c);
 }
 
@@ -793,6 +804,10 @@ static void cloud_copy_in(cloud *c, const lrr_oracle_features *f, int float_stre
   if (f->dirs) {
     c->dirs = (double *)malloc(sizeof(double) * 6 * m);
     memcpy(c->dirs, f->dirs, sizeof(double) * 6 * (size_t)n);
+  }
+  if (f->cov) {
+    c->evec = (double *)malloc(sizeof(double) * 6 * m);
+    for (int64_t i = 0; i < n; ++i) sym_eig_ends(f->cov + 9 * i, c->evec + 6 * i, c->evec + 6 * i + 3);
   }
 }
 
@@ -817,6 +832,7 @@ typedef struct {
   int64_t *m_from, *m_to;
   double *m_w;
   int from_is_copy;     /* rigid pre-map replaced from_ by new feature objects */
+  double premap_R[9];   /* ... whose covariance is R C R^T: rotation of that pre-map */
   double *m_from_loc;   /* their locations (3 per match) */
   uint8_t *flag;        /* scratch: distinct-to marker, size fixed.n */
   double last_scale, injected_scale;
@@ -1240,6 +1256,7 @@ static void fwd_rigid_premap(fwd_est *f, trans *global_out) {
     memcpy(f->m_from_loc + 3 * i, y, 24);
   }
   f->from_is_copy = 1;
+  memcpy(f->premap_R, global_out->A, sizeof f->premap_R);
   double zero6[6] = { 0, 0, 0, 0, 0, 0 };
   trans_set_param(&inc, zero6);
   f->tr = inc;
@@ -1338,6 +1355,38 @@ static double fwd_angles_rrl(const fwd_est *f, int tube) {
     sum_weight += w;
   }
   return avg / sum_weight;
+}
+
+/* sheet_angles / tube_angles of the cdcl class (cdcl .txx:273-382): angle between the covariance eigenvectors of the
+ * smallest eigenvalue (sheets, column 0) / the largest (tubes, column 2), no mapping by the transform; a pre-mapped
+ * from_ carries R C R^T (cdcl .txx:473-479), whose eigenvector is R v */
+static double fwd_angles_cdcl(const fwd_est *f, int tube) {
+  double avg = 0.0, sum_weight = 0.0;
+  if (!f->moving.evec || !f->fixed.evec) return NAN;
+  for (int64_t i = 0; i < f->nmatch; ++i) {
+    int64_t p = f->m_from[i], q = f->m_to[i];
+    uint8_t want = tube ? 1 : 2;
+    if (f->moving.shape[p] != want) continue;
+    if (f->fixed.shape[q] != want) continue;
+    const double *vp = f->moving.evec + 6 * p + (tube ? 3 : 0), *vq = f->fixed.evec + 6 * q + (tube ? 3 : 0);
+    double d[3] = { vp[0], vp[1], vp[2] };
+    if (f->from_is_copy) {
+      const double *R = f->premap_R;
+      d[0] = (R[0] * vp[0] + R[1] * vp[1]) + R[2] * vp[2];
+      d[1] = (R[3] * vp[0] + R[4] * vp[1]) + R[5] * vp[2];
+      d[2] = (R[6] * vp[0] + R[7] * vp[1]) + R[8] * vp[2];
+    }
+    double a = acos((d[0] * vq[0] + d[1] * vq[1]) + d[2] * vq[2]);
+    if (a > M_PI / 2) a = M_PI - a;
+    double w = f->m_w[i];
+    avg += w * a;
+    sum_weight += w;
+  }
+  return avg / sum_weight;
+}
+static double fwd_angles(const fwd_est *f, int tube) {
+  /* the cdcl classes on cdcl_feature_with_shape compare covariance eigenvectors, the rrl classes mapped directions_ */
+  return (!f->rrl && f->moving.evec && f->fixed.evec) ? fwd_angles_cdcl(f, tube) : fwd_angles_rrl(f, tube);
 }
 
 /* compute_transfer_error_covariance (cdcl .txx:388-404; rrl .txx:381-397) */
@@ -1651,11 +1700,11 @@ double lrr_oracle_weighted_error(lrr_oracle_est *e, int dir) {
 }
 double lrr_oracle_sheet_angles(lrr_oracle_est *e, int dir) {
   fwd_est *f = dir ? e->bwd : e->fwd;
-  return f ? fwd_angles_rrl(f, 0) : NAN;
+  return f ? fwd_angles(f, 0) : NAN;
 }
 double lrr_oracle_tube_angles(lrr_oracle_est *e, int dir) {
   fwd_est *f = dir ? e->bwd : e->fwd;
-  return f ? fwd_angles_rrl(f, 1) : NAN;
+  return f ? fwd_angles(f, 1) : NAN;
 }
 void lrr_oracle_compute_transfer_error_covariance(lrr_oracle_est *e, double *cf, double *cb) {
   fwd_transfer_error_covariance(e->fwd);

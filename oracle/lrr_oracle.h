@@ -27,6 +27,7 @@ typedef struct {
   const double  *strength;  /* n, strength_ (rounded to float for the rrl kinds) */
   const uint8_t *shape;     /* n, 0 CORNER 1 TUBE 2 SHEET (may be NULL)          */
   const double  *dirs;      /* n x 6, directions_[0], directions_[1] (may be NULL) */
+  const double  *cov;       /* n x 9 row-major, covariance_ of cdcl_feature_with_shape (may be NULL)  */
 } lrr_oracle_features;
 
 /* estimator kinds */

@@ -54,7 +54,7 @@ def test_product_never_touches_the_oracle():
     for base in ("lrr_amd", "include"):
         for d, _, files in os.walk(os.path.join(ROOT, base)):
             for f in files:
-                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".inc")):
                     txt = open(os.path.join(d, f)).read()
                     if re.search(r"^\s*(from|import)\s+oracle|lrr_oracle|liblrr_oracle", txt, flags=re.M):
                         bad.append(os.path.join(d, f))

@@ -598,3 +598,37 @@ def test_voronoi_lookup_equals_oracle(E, ob):
             break
     assert g.finest_level() and g.number_points(0) == 50000
     g.close()
+
+
+@pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("CDCL_SYMMETRIC", 6), ("CDCL_SYMMETRIC", 12)])
+def test_cdcl_covariance_angles(E, ob, kind_name, dof):
+    """sheet_angles / tube_angles of the cdcl classes compare eigenvectors of the features' covariances (cdcl .txx:273-382):
+    column 0 for sheets, column 2 for tubes, un-mapped — except that the rigid classes' pre-mapped from_ copies carry
+    R C R^T (cdcl .txx:473-479).  Device against the oracle, forward and symmetric, rigid and affine."""
+    import dataclasses
+    pair = synth.make_pair(9000, 9000, 515, kind="rigid" if dof == 6 else "affine")
+    pair = dataclasses.replace(pair, moving=dataclasses.replace(pair.moving, cov=synth.covariances(pair.moving)),
+                               fixed=dataclasses.replace(pair.fixed, cov=synth.covariances(pair.fixed)))
+    T0 = synth.perturbed(pair.planted, 6)
+    sym = kind_name == "CDCL_SYMMETRIC"
+    g, c = _both(E, ob, getattr(E, kind_name), dof, pair, T0, 41, sym, n_points=None if sym else 9000)
+    for it in range(4):
+        _compare_iteration(g, c, it, (0, 1) if sym else (0,))
+        for d in ((0, 1) if sym else (0,)):
+            sa, ta = c.sheet_angles(d), c.tube_angles(d)
+            assert np.isfinite(sa) and np.isfinite(ta) and 0.0 < sa < np.pi / 2 and 0.0 < ta < np.pi / 2
+            assert abs(g.sheet_angles(d) - sa) < 1e-9 and abs(g.tube_angles(d) - ta) < 1e-9, (it, d)
+    # the eigenvector form is not the mapped-directions form of the rrl classes: without covariances the oracle falls
+    # back to the latter, and the numbers differ
+    pair2 = dataclasses.replace(pair, moving=dataclasses.replace(pair.moving, cov=None), fixed=dataclasses.replace(pair.fixed, cov=None))
+    _, c2 = _both(E, ob, getattr(E, kind_name), dof, pair2, T0, 41, sym, n_points=None if sym else 9000)
+    c2.one_iteration(0)
+    c3 = ob.OracleEstimator(getattr(ob, kind_name), dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                            moving_inside=pair.moving if sym else None, fixed_inside=pair.fixed if sym else None, seed=41)
+    if not sym:
+        c3.weight_by_strength(False)
+        c3.set_transform(T0.A, T0.t, T0.c)
+        c3.set_number_points(9000)
+    c3.one_iteration(0)
+    assert abs(c2.sheet_angles(0) - c3.sheet_angles(0)) > 1e-6
+    g.close()
