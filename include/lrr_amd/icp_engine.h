@@ -654,8 +654,16 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     trans_->set_covariance(global_transform->get_covariance());
     lrr_icp_xform G = xform_of(global_transform);
     check(lrr_icp_premap(dir_, &G), "rigid pre-map");
+    if (premapped_ && premap_G_) {
+      // copies that are pre-mapped again (estimate_LS_backward after an iteration): their covariance carries both
+      // rotations; only the rotation part of premap_G_ is used later (the angle diagnostics)
+      trans_sptr_type both = global_transform->clone();
+      both->get_A() = global_transform->get_A() * premap_G_->get_A();
+      premap_G_ = both;
+    } else {
+      premap_G_ = global_transform->clone();
+    }
     premapped_ = true;
-    premap_G_ = global_transform->clone();
     touch();
     trans_->set_parameterization(vnl_vector<double>(6, 0.0));
     return global_transform;
@@ -837,16 +845,60 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     if (rigid) F.end_rigid_increment(forward_global);
     if (estimate_parameters) B.trans_ = F.trans_->inverse();
   }
-  // swap forward_/backward_, estimate_LS, swap back (rrl sym .txx:921-934).  The cdcl class's own
-  // variant (cdcl sym .txx:704-863) is not provided.
+  // rrl: swap forward_/backward_, estimate_LS, swap back (rrl sym .txx:921-934).
+  // cdcl: the class's own hand-written variant (cdcl sym .txx:704-863), step by step through the granular C-ABI calls
+  // (a diagnostic outside the iteration loop): only the backward list is pre-mapped (rigid); both lists get their scale
+  // and Beaton-Tukey weights; the forward matches join the backward list as role-reversed clones BEFORE the
+  // normalisation statistics are taken (every clone counts among the distinct to_); strength weighting of the merged
+  // list, no spatial weighting; normal equations under the backward transform's Jacobian; covariance (and, when asked,
+  // parameters) of the backward transform; forward = inverse(backward) — of the INCREMENT in the rigid case, before the
+  // increment is recomposed, as the reference orders it (:843-858).
   void estimate_LS_backward(bool estimate_parameters) {
-    if (!RRL) throw std::runtime_error("lrr_amd: estimate_LS_backward is implemented for the rrl class only");
-    vbl_smart_ptr<estimation_type> f = forward_, b = backward_;
-    forward_ = b;
-    backward_ = f;
-    this->estimate_LS(estimate_parameters);
-    forward_ = f;
-    backward_ = b;
+    if (RRL) {
+      vbl_smart_ptr<estimation_type> f = forward_, b = backward_;
+      forward_ = b;
+      backward_ = f;
+      this->estimate_LS(estimate_parameters);
+      forward_ = f;
+      backward_ = b;
+      return;
+    }
+    estimation_type &F = *forward_, &B = *backward_;
+    trans_sptr_type backward_global;
+    const bool rigid = B.is_rigid();
+    if (rigid) backward_global = B.begin_rigid_increment();
+    F.estimate_scale_and_assign_weight();
+    B.estimate_scale_and_assign_weight();
+    check(lrr_icp_clone_weights(F.dir_), "add_constraints");
+    lrr_icp_norm nm = estimation_type::identity_norm();
+    location_type cm(0.0), cf(0.0);
+    if (normalize_matches_) {
+      check(lrr_icp_normalize_stats_merged(B.dir_, F.dir_, &nm), "merged normalize statistics");
+      for (int d = 0; d < 3; ++d) { cm[d] = nm.cm[d]; cf[d] = nm.cf[d]; }
+      B.trans_->normalize(nm.rm, nm.rf, cm, cf);
+    }
+    if (B.weight_by_strength_) {
+      double gs = 0;
+      check(lrr_icp_weight_by_strength(B.dir_, F.dir_, &gs), "weight_by_strength");
+    }
+    // the clones: from_ = the forward match's to_ (normalised like the merged from-side), to_ = its from_
+    lrr_icp_norm flipped;
+    for (int d = 0; d < 3; ++d) { flipped.cm[d] = nm.cf[d]; flipped.cf[d] = nm.cm[d]; }
+    flipped.rm = nm.rf;
+    flipped.rf = nm.rm;
+    double c[3] = {B.trans_->center_moving_[0], B.trans_->center_moving_[1], B.trans_->center_moving_[2]};
+    double AtA[dof * dof], Atb[dof], AtA2[dof * dof], Atb2[dof];
+    const int inc = rigid ? LRR_ICP_ACC_RIGID_INCREMENT : 0;
+    check(lrr_icp_accumulate(B.dir_, (int)dof, c, &nm, inc, AtA, Atb), "normal equations");
+    check(lrr_icp_accumulate(F.dir_, (int)dof, c, &flipped, inc | LRR_ICP_ACC_REVERSED | LRR_ICP_ACC_CLONE_W, AtA2, Atb2), "normal equations");
+    for (unsigned i = 0; i < dof * dof; ++i) AtA[i] += AtA2[i];
+    for (unsigned i = 0; i < dof; ++i) Atb[i] += Atb2[i];
+    B.solve_and_set(B.trans_, AtA, Atb, estimate_parameters);
+    if (normalize_matches_) B.trans_->unnormalize(nm.rm, nm.rf, cm, cf);
+    F.touch();
+    B.touch();
+    if (estimate_parameters) F.trans_ = B.trans_->inverse();
+    if (rigid) B.end_rigid_increment(backward_global);
   }
 
   // stubs in the reference too ("to be implemented": cdcl sym .h:90-93, rrl sym .h:104-107)

@@ -131,6 +131,11 @@ int  lrr_icp_assign_weights(lrr_icp_dir *dir, double sigma);
  * mean radius of from_ over matches and of the DISTINCT matched to_ */
 int  lrr_icp_normalize_stats(lrr_icp_dir *dir, lrr_icp_norm *out);
 
+/* the same statistics over a merged list: own's matches plus the role-reversed clones of rev's matches (clones are new
+ * objects: each counts among the distinct to_).  cdcl sym estimate_LS_backward adds the constraints BEFORE it normalises
+ * (cdcl/cdcl_estimation_symmetric_ICP_matching_all.txx:742-755) */
+int  lrr_icp_normalize_stats_merged(lrr_icp_dir *own, lrr_icp_dir *rev, lrr_icp_norm *out);
+
 /* add_constraints (cdcl sym .txx:367-393): the role-reversed clones of this direction's matches
  * start with a copy of its weights; the merged weighting calls below then work on the copy. */
 int  lrr_icp_clone_weights(lrr_icp_dir *dir);

@@ -1528,6 +1528,25 @@ __global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, const double *to_r
   block_reduce_store<2>(acc, partials);
 }
 
+// per-match sums of a list whose to_ objects are all distinct (the role-reversed clones of add_constraints, cdcl sym
+// .txx:367-393): sum of from-locations, sum of to-locations, sum |from - c_from|, sum |to - c_to|
+__global__ __launch_bounds__(kBlock) void k_pair_stats(PairSrc ps, const double *to_rec, double cf0, double cf1, double cf2,
+                                                       double ct0, double ct1, double ct2, double *partials) {
+  double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
+    if (ps.slot[s] < 0) continue;
+    double p0, p1, p2;
+    load_from(ps, s, p0, p1, p2);
+    const double *q = to_rec + (size_t)ps.m_to[s] * kRecStride;
+    acc[0] += p0; acc[1] += p1; acc[2] += p2;
+    acc[3] += q[0]; acc[4] += q[1]; acc[5] += q[2];
+    const double a0 = p0 - cf0, a1 = p1 - cf1, a2 = p2 - cf2, b0 = q[0] - ct0, b1 = q[1] - ct1, b2 = q[2] - ct2;
+    acc[6] += sqrt((a0 * a0 + a1 * a1) + a2 * a2);
+    acc[7] += sqrt((b0 * b0 + b1 * b1) + b2 * b2);
+  }
+  block_reduce_store<8>(acc, partials);
+}
+
 __device__ __forceinline__ double strength_gain(const PairSrc &ps, int s, int float_product) {
   double sp = ps.from_str[s];
   double sq = ps.to_rec[(size_t)ps.m_to[s] * kRecStride + 9];
@@ -3880,6 +3899,55 @@ int lrr_icp_normalize_stats(lrr_icp_dir *d, lrr_icp_norm *out) {
   if (rc) return rc;
   out->rm = r[0] / (double)n;
   out->rf = r[1] / nd;
+  return LRR_ICP_OK;
+}
+
+// cdcl_normalize_matches over a MERGED list (cdcl sym .txx:742-755, estimate_LS_backward: the constraints are added
+// before the statistics are taken): `own`'s matches plus the role-reversed clones of `rev`'s matches, whose from_ is
+// rev's to_ and whose to_ is rev's from_; clones are new objects, so every one of them counts among the distinct to_
+int lrr_icp_normalize_stats_merged(lrr_icp_dir *own, lrr_icp_dir *rev, lrr_icp_norm *out) {
+  if (!own || !rev || !out) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = own->ctx;
+  if (rev->ctx != ctx) return fail(ctx, LRR_ICP_ERR_ARG, "normalize_stats_merged: directions of different contexts");
+  if (own->n <= 0 || rev->n <= 0) return fail(ctx, LRR_ICP_ERR_STATE, "normalize_stats_merged: both lists need matches");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const double n_own = (double)own->n, n_rev = (double)rev->n;
+  PairSrc po = pairs_of(own), pr = pairs_of(rev);
+  double r[8], sum_from[3], sum_to[3];
+  int rc;
+  const int nbo = grid_for(po.nsrc), nbr = grid_for(pr.nsrc), nt = (int)own->to->n, nbt = grid_wide(nt);
+  hipLaunchKernelGGL(k_from_sum, dim3(nbo), dim3(kBlock), 0, ctx->stream, po, ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  if ((rc = finish_reduce(ctx, nbo, 3, r))) return rc;
+  for (int k = 0; k < 3; ++k) sum_from[k] = r[k];
+  unsigned gen = 0;
+  if ((rc = next_flag_gen(own, &gen))) return rc;
+  hipLaunchKernelGGL(k_mark, dim3(blocks_for(po.nsrc)), dim3(kBlock), 0, ctx->stream, own->slot, own->m_to, po.nsrc, own->flag, gen);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kWide), 0, ctx->stream, own->to->rec, own->flag, gen, nt, ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  if ((rc = finish_reduce(ctx, nbt, 4, r))) return rc;
+  const double nd = r[3];
+  for (int k = 0; k < 3; ++k) sum_to[k] = r[k];
+  hipLaunchKernelGGL(k_pair_stats, dim3(nbr), dim3(kBlock), 0, ctx->stream, pr, rev->to->rec, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  if ((rc = finish_reduce(ctx, nbr, 8, r))) return rc;
+  for (int k = 0; k < 3; ++k) {
+    out->cm[k] = (sum_from[k] + r[3 + k]) / (n_own + n_rev);  // clones' from_ = rev's to_
+    out->cf[k] = (sum_to[k] + r[k]) / (nd + n_rev);           // clones' to_ = rev's from_
+  }
+  const int nb2 = std::max(nbo, nbt);
+  hipLaunchKernelGGL(k_radii, dim3(nb2), dim3(kBlock), 0, ctx->stream, po, own->to->rec, own->flag, gen, nt,
+                     out->cm[0], out->cm[1], out->cm[2], out->cf[0], out->cf[1], out->cf[2], ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  double ro[2];
+  if ((rc = finish_reduce(ctx, nb2, 2, ro))) return rc;
+  hipLaunchKernelGGL(k_pair_stats, dim3(nbr), dim3(kBlock), 0, ctx->stream, pr, rev->to->rec, out->cf[0], out->cf[1], out->cf[2],
+                     out->cm[0], out->cm[1], out->cm[2], ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  if ((rc = finish_reduce(ctx, nbr, 8, r))) return rc;
+  out->rm = (ro[0] + r[7]) / (n_own + n_rev);
+  out->rf = (ro[1] + r[6]) / (nd + n_rev);
   return LRR_ICP_OK;
 }
 

@@ -1255,8 +1255,16 @@ static void fwd_rigid_premap(fwd_est *f, trans *global_out) {
     trans_map(global_out, fwd_from_loc(f, i), y);
     memcpy(f->m_from_loc + 3 * i, y, 24);
   }
+  if (f->from_is_copy) { /* copies pre-mapped again: their covariance carries both rotations */
+    double both[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        both[3 * r + c] = (global_out->A[3 * r] * f->premap_R[c] + global_out->A[3 * r + 1] * f->premap_R[3 + c]) + global_out->A[3 * r + 2] * f->premap_R[6 + c];
+    memcpy(f->premap_R, both, sizeof both);
+  } else {
+    memcpy(f->premap_R, global_out->A, sizeof f->premap_R);
+  }
   f->from_is_copy = 1;
-  memcpy(f->premap_R, global_out->A, sizeof f->premap_R);
   double zero6[6] = { 0, 0, 0, 0, 0, 0 };
   trans_set_param(&inc, zero6);
   f->tr = inc;
@@ -1617,13 +1625,74 @@ void lrr_oracle_estimate_LS(lrr_oracle_est *e, int estimate_parameters) {
   else sym_estimate_LS_cdcl(e, e->fwd, e->bwd, estimate_parameters);
 }
 
-/* estimate_LS_backward: swap forward_/backward_, estimate_LS, swap back
- * (rrl sym .txx:921-934).  The cdcl class has a different hand-written variant
- * (cdcl sym .txx:704-863: constraints added before normalisation, no spatial weighting);
- * it is not called by location_registration and is NOT restated: no-op for that kind. */
+/* cdcl_estimation_symmetric_ICP_matching_all::estimate_LS_backward (cdcl sym .txx:704-863): NOT estimate_LS with the
+ * roles swapped.  Only the backward list is pre-mapped (rigid, :707-734); scale and Beaton-Tukey weights of both lists
+ * (:737-741); the forward matches are appended to the backward list as role-reversed clones (:743-745) BEFORE
+ * cdcl_normalize_matches runs on it (:753-757), so the statistics are those of the merged list and every clone counts as a
+ * distinct to_; weight_by_strength of the merged list (:765), no spatial weighting; generic accumulation under the backward
+ * transform (:778-812); covariance / parameters of the backward transform (:823-838); the clones are erased (:841);
+ * un-normalise (:843-851); forward = inverse(backward) (:853-855) and only then, rigid, the increment is recomposed
+ * (:860-866). */
+static void sym_estimate_LS_backward_cdcl(lrr_oracle_est *e, fwd_est *F, fwd_est *B, int estimate_parameters) {
+  trans Gb;
+  int rigid = (e->dof == 6);
+  if (rigid) fwd_rigid_premap(B, &Gb);
+  fwd_estimate_scale_and_assign_weight(F);
+  fwd_estimate_scale_and_assign_weight(B);
+  flat_list L;
+  flat_alloc(&L, F->nmatch + B->nmatch);
+  flat_append(&L, B, 0);
+  flat_append(&L, F, 1);
+  double cm[3] = { 0, 0, 0 }, cf[3] = { 0, 0, 0 }, rm = 0.0, rf = 0.0;
+  if (e->normalize_matches) {
+    /* from_: every match; to_: the distinct objects among the backward list's own to_, every clone */
+    int64_t nB = B->nmatch, n = L.n, nd = 0;
+    memset(B->flag, 0, (size_t)B->fixed.n);
+    for (int64_t i = 0; i < n; ++i) {
+      const double *p = L.from_loc + 3 * i, *q = L.to_loc + 3 * i;
+      cm[0] += p[0]; cm[1] += p[1]; cm[2] += p[2];
+      int first = 1;
+      if (i < nB) { first = !B->flag[B->m_to[i]]; B->flag[B->m_to[i]] = 1; }
+      if (first) { ++nd; cf[0] += q[0]; cf[1] += q[1]; cf[2] += q[2]; }
+    }
+    for (int d = 0; d < 3; ++d) { cm[d] /= (double)n; cf[d] /= (double)nd; }
+    memset(B->flag, 0, (size_t)B->fixed.n);
+    for (int64_t i = 0; i < n; ++i) {
+      double *p = L.from_loc + 3 * i, *q = L.to_loc + 3 * i;
+      for (int d = 0; d < 3; ++d) { p[d] -= cm[d]; q[d] -= cf[d]; }
+      rm += sqrt((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+      int first = 1;
+      if (i < nB) { first = !B->flag[B->m_to[i]]; B->flag[B->m_to[i]] = 1; }
+      if (first) rf += sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+    }
+    rm /= (double)n;
+    rf /= (double)nd;
+    for (int64_t i = 0; i < n; ++i) {
+      double *p = L.from_loc + 3 * i, *q = L.to_loc + 3 * i;
+      for (int d = 0; d < 3; ++d) { p[d] /= rm; q[d] /= rf; }
+    }
+    trans_normalize(&B->tr, rm, rf, cm, cf);
+  }
+  if (B->weight_by_strength) flat_weight_by_strength(&L, B->rrl);
+  memset(&e->ne, 0, sizeof e->ne);
+  flat_accumulate_generic(&L, &B->tr, rigid, e->ne.AtA, e->ne.Atb);
+  memcpy(B->m_w, L.w, sizeof(double) * (size_t)B->nmatch); /* the clones are erased (:841) */
+  flat_free(&L);
+  solve_and_set(&B->tr, e->ne.AtA, e->ne.Atb, estimate_parameters);
+  if (e->normalize_matches) trans_unnormalize(&B->tr, rm, rf, cm, cf);
+  if (estimate_parameters) trans_inverse(&B->tr, &F->tr);
+  if (rigid) {
+    trans_recompose_increment(&Gb, &B->tr);
+    memcpy(Gb.covar, B->tr.covar, sizeof Gb.covar);
+    B->tr = Gb;
+  }
+}
+
+/* estimate_LS_backward: the rrl class swaps forward_/backward_, calls estimate_LS and swaps back (rrl sym .txx:921-934);
+ * the cdcl class has its own variant (above) */
 void lrr_oracle_estimate_LS_backward(lrr_oracle_est *e, int estimate_parameters) {
-  if (e->kind != LRR_ORACLE_RRL_SYMMETRIC) return;
-  sym_estimate_LS_rrl(e, e->bwd, e->fwd, estimate_parameters);
+  if (e->kind == LRR_ORACLE_RRL_SYMMETRIC) sym_estimate_LS_rrl(e, e->bwd, e->fwd, estimate_parameters);
+  else if (e->kind == LRR_ORACLE_CDCL_SYMMETRIC) sym_estimate_LS_backward_cdcl(e, e->fwd, e->bwd, estimate_parameters);
 }
 
 /* symmetric one_iteration (rrl sym .txx:341-438; cdcl sym .txx:268-363) */

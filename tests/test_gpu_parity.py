@@ -632,3 +632,35 @@ def test_cdcl_covariance_angles(E, ob, kind_name, dof):
     c3.one_iteration(0)
     assert abs(c2.sheet_angles(0) - c3.sheet_angles(0)) > 1e-6
     g.close()
+
+
+@pytest.mark.parametrize("dof", [6, 12])
+def test_cdcl_estimate_LS_backward(E, ob, dof):
+    """the cdcl symmetric class's own estimate_LS_backward (cdcl sym .txx:704-863: constraints added before the
+    normalisation statistics, strength weighting only, forward = inverse(backward) before the rigid increment is
+    recomposed): device path (granular C-ABI calls) against the oracle, covariance only and with new parameters"""
+    import dataclasses
+    pair = synth.make_pair(10000, 9000, 616, kind="rigid" if dof == 6 else "affine")
+    pair = dataclasses.replace(pair, moving=dataclasses.replace(pair.moving, cov=synth.covariances(pair.moving)),
+                               fixed=dataclasses.replace(pair.fixed, cov=synth.covariances(pair.fixed)))
+    T0 = synth.perturbed(pair.planted, 7, rot_deg=0.2, trans_mm=0.3)
+    g, c = _both(E, ob, E.CDCL_SYMMETRIC, dof, pair, T0, 43, True)
+    for it in range(5):
+        _compare_iteration(g, c, it, (0, 1))
+    for params in (False, True):
+        g.estimate_LS_backward(params)
+        c.estimate_LS_backward(params)
+        for d in (0, 1):
+            fg, tg, wg = g.matches(d)
+            fc, tc, wc = c.matches(d)
+            assert np.array_equal(fg, fc) and np.array_equal(tg, tc)
+            assert np.allclose(wg, wc, rtol=1e-8, atol=1e-12 * np.abs(wc).max()), (params, d)
+            Ag, t_g, c_g, cov_g = g.get_transform(d)
+            Ac, t_c, c_c, cov_c = c.get_transform(d)
+            assert rel(Ag, Ac) < 1e-7 and rel(t_g, t_c) < 1e-7, (params, d)
+            if d == 1:
+                assert rel(cov_g, cov_c) < 1e-5, params
+            assert abs(g.weighted_error(d) - c.weighted_error(d)) <= 1e-8 * max(1.0, c.weighted_error(d))
+            assert abs(g.sheet_angles(d) - c.sheet_angles(d)) < 1e-9 and abs(g.tube_angles(d) - c.tube_angles(d)) < 1e-9
+    AtA_g, Atb_g = g.normal_equations()
+    g.close()
