@@ -280,6 +280,21 @@ int64_t lrr_icp_batch_num_matches(const lrr_icp_batch *batch, int64_t b, int dir
 /* matches_ of location b: from = index in the ROI list, to = index in the full volume */
 int  lrr_icp_batch_get_matches(lrr_icp_batch *batch, int64_t b, int dir, int64_t *from_idx, int64_t *to_idx, double *w);
 
+/* ---- covariance-driven EM, E-step (first step) ---------------------------------------
+ * covariance_ of every feature of a cloud (n x 9 row-major, original order): cdcl/cdcl_feature.h:21-64 */
+int  lrr_icp_cloud_set_covariances(lrr_icp_cloud *cloud, const double *cov9);
+/* cdcl_estimation::compute_weights at one resolution (cdcl/cdcl_estimation.txx:342-545): for every moving feature the
+ * fixed features within 5 sqrt(lambda_max(J C_theta J^T + J_p C_p J_p^T)) of its mapped location, at most max_matches
+ * of them (the reference keeps the first 100 of a shuffled list: here the candidates with the smallest rank under the
+ * keyed permutation `keys` of the fixed set), Mahalanobis weights f (1 - r/16)^2 and the two-sided normalisation
+ * w_ij^2 / (sum_j w_ij sum_i w_ij).  Rows of max_matches slots per moving feature (original order): row_count[i]
+ * matches, to_idx = original fixed indices (-1 in unused slots), in no particular order inside a row.
+ * overflow_rows: moving features with more candidates inside the radius than one wavefront holds (1536): their
+ * selection is taken among the first 1536 found. */
+int  lrr_icp_cdc_compute_weights(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, const lrr_icp_xform *xf, int dof,
+                                 const double *param_covar, const uint32_t keys[4], int max_matches,
+                                 int64_t *row_count, int64_t *to_idx, double *w, int64_t *overflow_rows);
+
 /* stand-alone exact nearest neighbour of host query points (tests, diagnostics) */
 int  lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int method, int64_t *idx);
 

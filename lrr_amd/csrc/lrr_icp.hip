@@ -163,6 +163,7 @@ struct lrr_icp_cloud {
   float4 *gpf = nullptr;        // n, raster order like gp: (x, y, z) in cell units relative to the grid origin as floats + canonical index bits:
                                 // the single-precision pre-filter of the ball search
   GridPoint *cpt = nullptr;     // n, canonical order: location + indices of target `canon` in one 32-B read (previous-match bound)
+  double *cov = nullptr;        // n x 9, canonical order: covariance_ (own allocation; lrr_icp_cloud_set_covariances, the CDC-EM E-step)
   double *loc_orig = nullptr;   // n x 3, ORIGINAL order: the box test of the device-side ROI selection streams it (FeaturesInROIs walks the features in this order)
   int *cell_start = nullptr;    // ncell + 1
   int *fine_start = nullptr;    // ncell * fine + 1: every cell cut into `fine` slices along x (ball search)
@@ -3355,6 +3356,7 @@ void lrr_icp_cloud_destroy(lrr_icp_cloud *c) {
   if (c->ctx) (void)hipSetDevice(c->ctx->device);
   if (c->vor) lrr_icp_cloud_destroy(c->vor);
   if (c->vor_site_to_feature) (void)hipFree(c->vor_site_to_feature);
+  if (c->cov) (void)hipFree(c->cov);
   if (c->slab) (void)hipFree(c->slab);
   delete c;
 }
@@ -4421,3 +4423,4 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
 }  // extern "C"
 
 #include "lrr_icp_batch.inc"
+#include "lrr_icp_cdc.inc"

@@ -33,7 +33,7 @@ ICP_SYMBOLS = [
     "lrr_icp_normalize_stats", "lrr_icp_normalize_stats_merged", "lrr_icp_clone_weights", "lrr_icp_weight_by_strength",
     "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_cloud_set_shape_vectors", "lrr_icp_angles", "lrr_icp_angles_unmapped", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
-    "lrr_icp_nearest",
+    "lrr_icp_nearest", "lrr_icp_cloud_set_covariances", "lrr_icp_cdc_compute_weights",
     "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
     "lrr_icp_batch_match", "lrr_icp_batch_estimate", "lrr_icp_batch_errors", "lrr_icp_batch_angles",
     "lrr_icp_batch_num_matches", "lrr_icp_batch_get_matches",
@@ -223,6 +223,11 @@ class DeviceCloud:
             raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
         self.h = h
 
+    def set_covariances(self, cov9):
+        c = np.ascontiguousarray(cov9, dtype=np.float64)
+        if self.L.lrr_icp_cloud_set_covariances(self.h, _d(c)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+
     def nearest(self, query, method=NN_GRID):
         q = np.ascontiguousarray(query, dtype=np.float64)
         out = np.empty(q.shape[0], dtype=np.int64)
@@ -236,6 +241,31 @@ class DeviceCloud:
             self.h = None
 
     __del__ = close
+
+
+def cdc_compute_weights(moving: "DeviceCloud", fixed: "DeviceCloud", dof, A, t, c, param_covar, seed, max_matches=100):
+    """cdcl_estimation::compute_weights at one resolution on the device (lrr_icp_cdc_compute_weights); the clouds need
+    set_covariances().  Returns (row_count, to_idx (nm, max_matches), w, overflow_rows)."""
+    L = hip_lib()
+    x = Xform()
+    x.A[:] = np.asarray(A, dtype=np.float64).ravel()
+    x.t[:] = np.asarray(t, dtype=np.float64)
+    x.c[:] = np.asarray(c, dtype=np.float64)
+    cov = np.ascontiguousarray(param_covar, dtype=np.float64)
+    st = C.c_uint64(seed)
+    keys = (C.c_uint32 * 4)()
+    L.lrr_icp_perm_keys(C.byref(st), keys)
+    nm = L.lrr_icp_cloud_size(moving.h)
+    rc = np.zeros(nm, dtype=np.int64)
+    ti = np.zeros((nm, max_matches), dtype=np.int64)
+    w = np.zeros((nm, max_matches))
+    over = C.c_int64(0)
+    L.lrr_icp_cdc_compute_weights.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Xform), C.c_int, _dp, C.POINTER(C.c_uint32), C.c_int,
+                                              _ip, _ip, _dp, _ip]
+    if L.lrr_icp_cdc_compute_weights(moving.h, fixed.h, C.byref(x), dof, _d(cov), keys, max_matches, rc.ctypes.data_as(_ip),
+                                     ti.ctypes.data_as(_ip), _d(w), C.byref(over)) != 0:
+        raise RuntimeError(L.lrr_icp_last_error(moving.ctx).decode())
+    return rc, ti, w, over.value
 
 
 def subset_perm(n: int, seed: int):

@@ -117,6 +117,28 @@ def nn(fixed_loc, query, backend=NN_BRUTE):
     return out
 
 
+def cdc_compute_weights(moving, fixed, dof, A, t, c, param_covar, seed, max_matches=100):
+    """cdcl_estimation::compute_weights at one resolution; returns (row_count, to_idx, w) with rows of max_matches slots"""
+    L = lib()
+    keep = []
+    fm, ff = _features(moving, keep), _features(fixed, keep)
+    A, t, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, t, c))
+    cov = np.ascontiguousarray(param_covar, dtype=np.float64)
+    st = C.c_uint64(seed)
+    keys = (C.c_uint32 * 4)()
+    L.lrr_oracle_perm_keys(C.byref(st), keys)
+    nm = moving.n
+    rc = np.zeros(nm, dtype=np.int64)
+    ti = np.full((nm, max_matches), -1, dtype=np.int64)
+    w = np.zeros((nm, max_matches))
+    L.lrr_oracle_cdc_compute_weights.restype = C.c_int64
+    L.lrr_oracle_cdc_compute_weights.argtypes = [C.POINTER(_Features), C.POINTER(_Features), C.c_int, _dp, _dp, _dp, _dp,
+                                                 C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _dp]
+    L.lrr_oracle_cdc_compute_weights(C.byref(fm), C.byref(ff), dof, _d(A), _d(t), _d(c), _d(cov), keys, max_matches,
+                                     rc.ctypes.data_as(C.POINTER(C.c_int64)), ti.ctypes.data_as(C.POINTER(C.c_int64)), _d(w))
+    return rc, ti, w
+
+
 def muse_scale(res):
     r = np.ascontiguousarray(res, dtype=np.float64)
     return lib().lrr_oracle_muse_scale(_d(r), r.shape[0])

@@ -812,6 +812,141 @@ static void cloud_copy_in(cloud *c, const lrr_oracle_features *f, int float_stre
 }
 
 /* ------------------------------------------------------------------------- */
+/* SURVEY section 8(f)4, first step: cdcl_estimation::compute_weights          */
+/* ------------------------------------------------------------------------- */
+/* vnl_symmetric_eigensystem_compute_eigenvals (VXL core/vnl/algo, not in this image; restated from the published
+ * closed form — the trigonometric solution of the characteristic cubic — as VXL writes it: PARITY UNPINNED):
+ * eigenvalues of a symmetric 3x3 in ascending order. */
+static void sym3_eigenvalues(double M11, double M12, double M13, double M22, double M23, double M33,
+                             double *l1, double *l2, double *l3) {
+  const double b = -M11 - M22 - M33;
+  const double c = M11 * M22 + M11 * M33 + M22 * M33 - M12 * M12 - M13 * M13 - M23 * M23;
+  const double d = M11 * M23 * M23 + M12 * M12 * M33 + M13 * M13 * M22 - 2.0 * M12 * M13 * M23 - M11 * M22 * M33;
+  const double b_3 = b / 3.0;
+  const double f = b_3 * b_3 - c / 3.0;
+  const double g = b * c / 6.0 - b_3 * b_3 * b_3 - 0.5 * d;
+  if (f == 0.0 && g == 0.0) { *l1 = *l2 = *l3 = -b_3; return; }
+  const double f3 = f * f * f, g2 = g * g;
+  const double sqrt_f = -sqrt(f);
+  if (g2 >= f3) { /* repeated root (complex pairs are treated as inaccurate repeated roots) */
+    if (g < 0.0) { *l1 = 2.0 * sqrt_f - b_3; *l2 = *l3 = -sqrt_f - b_3; }
+    else { *l1 = *l2 = sqrt_f - b_3; *l3 = -2.0 * sqrt_f - b_3; }
+    return;
+  }
+  const double sqrt_f3 = sqrt_f * sqrt_f * sqrt_f;
+  const double k = acos(g / sqrt_f3) / 3.0;
+  const double j = 2.0 * sqrt_f;
+  double a1 = j * cos(k) - b_3, a2 = j * cos(k + M_PI * 2.0 / 3.0) - b_3, a3 = j * cos(k - M_PI * 2.0 / 3.0) - b_3, t;
+  if (a2 < a1) { t = a2; a2 = a1; a1 = t; }
+  if (a3 < a2) { t = a2; a2 = a3; a3 = t; if (a2 < a1) { t = a2; a2 = a1; a1 = t; } }
+  *l1 = a1; *l2 = a2; *l3 = a3;
+}
+
+/* vnl_inverse of a 3x3 (adjugate over determinant) */
+static void inverse3_cofactor(const double *m, double *o) {
+  double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+  double id = 1.0 / det;
+  o[0] = (m[4] * m[8] - m[5] * m[7]) * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  o[3] = (m[5] * m[6] - m[3] * m[8]) * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  o[6] = (m[3] * m[7] - m[4] * m[6]) * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+/* weight() of cdcl/cdcl_utils.h:212-232: f (1 - r / b^2)^2 up to r = b^2 = 16, f = 2.9872 */
+static double cdc_weight(double residual) {
+  const double b_2 = 16.0, f = 2.9872;
+  if (residual <= b_2) return f * (1 - residual / b_2) * (1 - residual / b_2);
+  return 0;
+}
+
+/* cdcl_estimation::compute_weights at one resolution (cdcl/cdcl_estimation.txx:342-545): for every moving feature p,
+ * y = T(p); C_p' = J_th C_theta J_th^T + J_p C_p J_p^T (:375-383); all fixed features within 5 sqrt(lambda_max(C_p'))
+ * of y (:385-393); at most `max_matches` of them (:400-404: the reference shuffles the list with rand() and keeps the
+ * first 100 — here the candidates with the smallest rank under a keyed permutation of the fixed set, the stand-in used
+ * for every shuffle of this project); Mahalanobis residual e^T (C_p' + C_q)^-1 e and weight() (:411-423); matches with a
+ * positive weight are kept; finally w_ij <- w_ij^2 / (sum_j w_ij  sum_i w_ij) (:524-537).
+ * Output per moving feature: row_count[i] matches, to_idx / w at [i * max_matches ...], ascending fixed index.
+ * Brute-force radius search: checker code for small cases.  Returns the total number of matches. */
+int64_t lrr_oracle_cdc_compute_weights(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int dof,
+                                       const double *A, const double *t, const double *c, const double *param_covar,
+                                       const uint32_t keys[4], int max_matches, int64_t *row_count, int64_t *to_idx, double *w) {
+  trans T;
+  trans_identity(&T, dof);
+  memcpy(T.A, A, sizeof T.A); memcpy(T.t, t, sizeof T.t); memcpy(T.c, c, sizeof T.c);
+  memcpy(T.covar, param_covar, sizeof(double) * (size_t)dof * (size_t)dof);
+  const double eval_multiplier = 5.0;
+  int64_t nm = moving->n, nf = fixed->n, total = 0;
+  double *to_weights = (double *)calloc((size_t)(nf > 0 ? nf : 1), sizeof(double));
+  double *from_weights = (double *)calloc((size_t)(nm > 0 ? nm : 1), sizeof(double));
+  int64_t *cand = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)(nf > 0 ? nf : 1));
+  for (int64_t i = 0; i < nm; ++i) {
+    const double *p = moving->loc + 3 * i;
+    double y[3], J[3 * MAXDOF], JC[3 * MAXDOF], Cp[9];
+    trans_map(&T, p, y);
+    trans_jac(&T, p, J);
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < dof; ++cc) {
+        double s2 = 0.0;
+        for (int k = 0; k < dof; ++k) s2 += J[r * dof + k] * T.covar[k * dof + cc];
+        JC[r * dof + cc] = s2;
+      }
+    for (int r = 0; r < 3; ++r)
+      for (int e = 0; e < 3; ++e) {
+        double s2 = 0.0;
+        for (int k = 0; k < dof; ++k) s2 += JC[r * dof + k] * J[e * dof + k];
+        Cp[3 * r + e] = s2;
+      }
+    { /* + J_p C_p J_p^T, J_p = A (jacobian_wrt_loc) */
+      const double *Cm = moving->cov + 9 * i;
+      double AC[9];
+      for (int r = 0; r < 3; ++r)
+        for (int e = 0; e < 3; ++e) AC[3 * r + e] = (T.A[3 * r] * Cm[e] + T.A[3 * r + 1] * Cm[3 + e]) + T.A[3 * r + 2] * Cm[6 + e];
+      for (int r = 0; r < 3; ++r)
+        for (int e = 0; e < 3; ++e) Cp[3 * r + e] += (AC[3 * r] * T.A[3 * e] + AC[3 * r + 1] * T.A[3 * e + 1]) + AC[3 * r + 2] * T.A[3 * e + 2];
+    }
+    double l1, l2, l3;
+    sym3_eigenvalues(Cp[0], Cp[1], Cp[2], Cp[4], Cp[5], Cp[8], &l1, &l2, &l3);
+    const double radius = eval_multiplier * sqrt(l3), r2 = radius * radius;
+    int64_t nc = 0;
+    for (int64_t j = 0; j < nf; ++j)
+      if (dist2(y, fixed->loc + 3 * j) <= r2) { cand[2 * nc] = lrr_oracle_subset_perm(j, nf, keys); cand[2 * nc + 1] = j; ++nc; }
+    if (nc > max_matches) { qsort(cand, (size_t)nc, 2 * sizeof(int64_t), cmp_i64_pair); nc = max_matches; }
+    for (int64_t k = 0; k < nc; ++k) { cand[2 * k] = cand[2 * k + 1]; }  /* order the kept ones by fixed index */
+    qsort(cand, (size_t)nc, 2 * sizeof(int64_t), cmp_i64_pair);
+    int64_t kept = 0;
+    double sum_w = 0.0;
+    for (int64_t k = 0; k < nc; ++k) {
+      int64_t j = cand[2 * k];
+      const double *q = fixed->loc + 3 * j, *Cq = fixed->cov + 9 * j;
+      double e[3] = { y[0] - q[0], y[1] - q[1], y[2] - q[2] }, Cij[9], Ci[9];
+      for (int a = 0; a < 9; ++a) Cij[a] = Cp[a] + Cq[a];
+      inverse3_cofactor(Cij, Ci);
+      double v0 = (e[0] * Ci[0] + e[1] * Ci[3]) + e[2] * Ci[6];
+      double v1 = (e[0] * Ci[1] + e[1] * Ci[4]) + e[2] * Ci[7];
+      double v2 = (e[0] * Ci[2] + e[1] * Ci[5]) + e[2] * Ci[8];
+      double residual = (v0 * e[0] + v1 * e[1]) + v2 * e[2];
+      double w0 = cdc_weight(residual);
+      if (w0 > 0.0) {
+        to_idx[i * max_matches + kept] = j;
+        w[i * max_matches + kept] = w0;
+        to_weights[j] += w0;
+        sum_w += w0;
+        ++kept;
+      }
+    }
+    row_count[i] = kept;
+    from_weights[i] = sum_w;
+    total += kept;
+  }
+  for (int64_t i = 0; i < nm; ++i)
+    for (int64_t k = 0; k < row_count[i]; ++k) {
+      double w0 = w[i * max_matches + k];
+      w[i * max_matches + k] = w0 * w0 / (from_weights[i] * to_weights[to_idx[i * max_matches + k]]);
+    }
+  free(to_weights); free(from_weights); free(cand);
+  return total;
+}
+
+/* ------------------------------------------------------------------------- */
 /* forward estimator: cdcl_estimation_ICP_matching_all / rrl_estimation_ICP_matching_all */
 /* ------------------------------------------------------------------------- */
 

@@ -94,6 +94,13 @@ double  lrr_oracle_last_scale(lrr_oracle_est *e, int dir);
 void    lrr_oracle_last_normal_equations(lrr_oracle_est *e, double *AtA /*dof*dof*/, double *Atb /*dof*/);
 int     lrr_oracle_finest_level(lrr_oracle_est *e);
 
+/* SURVEY 8(f)4, first step: cdcl_estimation::compute_weights at one resolution (cdcl/cdcl_estimation.txx:342-545):
+ * radius search under the transfer-error covariance, <= max_matches candidates per moving feature, Mahalanobis
+ * weights, two-sided normalisation.  Both feature sets need `cov`.  Rows of max_matches entries, ascending fixed index. */
+int64_t lrr_oracle_cdc_compute_weights(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int dof,
+                                       const double *A, const double *t, const double *c, const double *param_covar,
+                                       const uint32_t keys[4], int max_matches, int64_t *row_count, int64_t *to_idx, double *w);
+
 /* stand-alone pieces (each is also used inside the estimators) */
 void   lrr_oracle_nn(const double *fixed_loc, int64_t nf, const double *query, int64_t nq,
                      int backend, int64_t *idx_out);
