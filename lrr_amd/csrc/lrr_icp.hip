@@ -74,7 +74,8 @@ constexpr int kSelHistBlocks = 128;  // blocks per job of the chip-wide select k
 constexpr int kAccBlocks = 128;      // accumulate grid per direction (90 fp64 accumulators per thread: 2 waves/SIMD)
 constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * kMaxBlocks * 5, kFusedP3 = kFusedP2 + kMaxBlocks * 4,
               kFusedP4 = kFusedP3 + kMaxBlocks * 2, kFusedP6 = kFusedP4 + 2 * kMaxBlocks,
-              kFusedOut = kFusedP6 + 2 * kAccBlocks * 96, kFusedDoubles = kFusedOut + 256;
+              kFusedOut = kFusedP6 + 2 * kAccBlocks * 96, kFusedP5 = kFusedOut + 256,  // P5: per-block counts of keys below the two selection windows
+              kFusedDoubles = kFusedP5 + 2 * kMaxBlocks * 2;
 
 // one candidate of the search grid: 32 B = two 16-B loads
 struct GridPoint { double x, y, z; int canon, orig; };
@@ -95,7 +96,11 @@ struct SelJob {
   int cnt_a0, cnt_a1, cnt_b0, cnt_b1;  // two row ranges whose sum is m
   long long m_fixed;               // m when cnt == nullptr
   int state;                       // slot of the previous result that centres the window (< 0: none)
+  // folded selection (k_f_weights<true> + k_selw_fold_final): the rows of P5 that belong to this job's list(s) and
+  // its column (0: strength keys, 1: spatial keys)
+  int row_a0, row_a1, row_b0, row_b1, col;
 };
+constexpr int kFoldStage = 192;     // in-window keys a block of the weight pass can stage per selection
 constexpr int kSelPack = 4;
 struct SelPack { SelJob j[kSelPack]; };  // the jobs of one windowed selection, passed as a kernel argument
 
@@ -125,6 +130,12 @@ struct lrr_icp_ctx {
   SelState *d_selstate = nullptr;
   int *d_selhist = nullptr;      // kMaxSelJobs x 2048, zero between selections
   double *d_selprev = nullptr;   // kSelStates previous results
+  double *d_selwin = nullptr;    // kSelStates relative half-widths of the folded selection's windows (self-tuning)
+  // folded selection (host side): the last two results of the 4 selections, and what they belonged to
+  double sel_last[4] = {0, 0, 0, 0}, sel_prev[4] = {0, 0, 0, 0};
+  const void *sel_dirs[2] = {nullptr, nullptr};
+  int64_t sel_n[2] = {-1, -1};
+  int sel_runs = 0;
   unsigned long long *d_selcoll = nullptr;  // kMaxSelJobs x kSelCap gathered keys
   int *d_selcursor = nullptr;    // kMaxSelJobs, zero between selections
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
@@ -2175,9 +2186,18 @@ __device__ __forceinline__ NormD norm_from_scalars(const double *SC, bool flippe
 
 // F4: Beaton-Tukey weights, strength gain and spatial keys.  The multiplications by 1/MADscale
 // are deferred to F6, in the reference's order: w = BT/s^2 ; w *= g ; w *= 1/gs ; w *= sw ; w *= 1/ss.
+// FOLD: the first half of the order statistics rides along.  Each of the two selections of this list (strength keys,
+// spatial keys) has a narrow window around its previous result (prev * (1 -+ win)): the pass counts the keys below the
+// window (P5) and gathers the keys inside it (staged in LDS, one global reservation per block); k_selw_fold_final then
+// picks the exact rank among the gathered keys.  Used when the scales moved little over the last iterations (the host
+// decides); a window that misses the rank or overflows falls back to the full select inside the final kernel.
+struct FoldArgs { const double *prev, *win; unsigned long long *coll; int *cursor; double *P5; };
+template <bool FOLD>
 __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
                                                       const double *P1, const double *P3, int nb3,
-                                                      double *SC, double *P4) {
+                                                      double *SC, double *P4, FoldArgs fo) {
+  __shared__ unsigned long long stage[FOLD ? 2 : 1][FOLD ? kFoldStage : 1];
+  __shared__ int nstage[2], gpos[2];
   const bool isF = (int)blockIdx.x < nbF;
   const DirArgs &D = isF ? F : B;
   const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
@@ -2211,6 +2231,17 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
   double *wdst = clone ? D.wc : D.w;
   const double scale2 = scale * scale;
   double acc[1] = {0.0};
+  // folded selection: jobs and windows of this list (slots as in lrr_icp_estimate_symmetric: rrl {F.g, B.g, F.s, B.s}; cdcl {g, s})
+  const int jg = o.rrl ? (isF ? 0 : 1) : 0, js = o.rrl ? (isF ? 2 : 3) : 1;
+  double lo_g = INFINITY, hi_g = INFINITY, lo_s = INFINITY, hi_s = INFINITY, below[2] = {0.0, 0.0};
+  if (FOLD) {
+    const int base = o.rrl ? 0 : 4;
+    const double vg = fo.prev[base + jg], vs = fo.prev[base + js], dg = fo.win[base + jg], ds = fo.win[base + js];
+    if (vg > 0.0 && vg < INFINITY) { lo_g = vg * (1.0 - dg); hi_g = vg * (1.0 + dg); }
+    if (vs > 0.0 && vs < INFINITY) { lo_s = vs * (1.0 - ds); hi_s = vs * (1.0 + ds); }
+    if (threadIdx.x < 2) nstage[threadIdx.x] = 0;
+    __syncthreads();
+  }
   for (int s = lb * kWide + threadIdx.x; s < D.ps.nsrc; s += nb * kWide) {
     if (D.ps.slot[s] < 0) { D.key_g[s] = INFINITY; D.key_s[s] = INFINITY; continue; }
     double u = D.r2[s] / scale2, bt = 0.0;
@@ -2225,6 +2256,10 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
       acc[0] += 1.0;
     }
     D.key_g[s] = key;
+    if (FOLD) {
+      if (key < lo_g) below[0] += 1.0;
+      else if (key <= hi_g) { const int p = atomicAdd(&nstage[0], 1); if (p < kFoldStage) stage[0][p] = (unsigned long long)__double_as_longlong(key); }
+    }
     {  // weight_spatially's 1 / (1 + 5 |q~|^2) on the normalised to-location (clones: their from-location)
       double q0, q1, q2;
       if (clone) {
@@ -2235,11 +2270,102 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
         q0 = (q[0] - nm.cf[0]) / nm.rf; q1 = (q[1] - nm.cf[1]) / nm.rf; q2 = (q[2] - nm.cf[2]) / nm.rf;
       }
       double dq = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
-      D.key_s[s] = 1.0 / (1.0 + 5.0 * dq * dq);
+      const double ks = 1.0 / (1.0 + 5.0 * dq * dq);
+      D.key_s[s] = ks;
+      if (FOLD) {
+        if (ks < lo_s) below[1] += 1.0;
+        else if (ks <= hi_s) { const int p = atomicAdd(&nstage[1], 1); if (p < kFoldStage) stage[1][p] = (unsigned long long)__double_as_longlong(ks); }
+      }
     }
     wdst[s] = wi;
   }
   block_reduce_store<1, kWide / 64>(acc, P4);
+  if (FOLD) {
+    block_reduce_store<2, kWide / 64>(below, fo.P5);  // (its barriers also publish the staged keys)
+    if (threadIdx.x < 2) {
+      const int j = threadIdx.x == 0 ? jg : js, n = nstage[threadIdx.x];
+      // a block that staged more than it holds makes the gathered set useless: push the cursor beyond the capacity
+      gpos[threadIdx.x] = atomicAdd(&fo.cursor[j], n > kFoldStage ? kSelCap + 1 : n);
+    }
+    __syncthreads();
+    for (int t = 0; t < 2; ++t) {
+      const int j = t == 0 ? jg : js, n = min(nstage[t], kFoldStage), p0 = gpos[t];
+      if (nstage[t] <= kFoldStage && p0 + n <= kSelCap)
+        for (int k = threadIdx.x; k < n; k += kWide) fo.coll[(size_t)j * kSelCap + p0 + k] = stage[t][k];
+    }
+  }
+}
+
+// second half of the folded selection: one block per job.  m (the number of keys that take part) and the rank as in
+// k_selw_collect; `below` = keys under the window (P5); when the rank lies among the gathered keys it is selected there,
+// else (window missed, overflowed, no previous result) by the full radix select over all keys of the job.  The window
+// width tunes itself: halved when it gathers more than a quarter of the capacity, doubled when it gathers next to
+// nothing, widened after a miss.
+__global__ __launch_bounds__(kSelThreads) void k_selw_fold_final(SelPack jobs, double *prev, double *win, const double *P5,
+                                                                const unsigned long long *coll, int *cursor) {
+  __shared__ unsigned long long keys[kSelCap];
+  __shared__ int lh[2048];
+  __shared__ int wave_tot[kSelThreads / 64];
+  __shared__ int sel[3];
+  __shared__ unsigned long long picked;
+  __shared__ double red[kSelThreads / 64][2];
+  SelJob job = jobs.j[blockIdx.x];
+  double part[2] = {0.0, 0.0};  // m (counted jobs), keys below the window: whole numbers, exact in any order
+  if (job.cnt) {
+    for (int b = job.cnt_a0 + (int)threadIdx.x; b < job.cnt_a1; b += kSelThreads) part[0] += job.cnt[b];
+    for (int b = job.cnt_b0 + (int)threadIdx.x; b < job.cnt_b1; b += kSelThreads) part[0] += job.cnt[b];
+  }
+  for (int b = job.row_a0 + (int)threadIdx.x; b < job.row_a1; b += kSelThreads) part[1] += P5[(size_t)b * 2 + job.col];
+  for (int b = job.row_b0 + (int)threadIdx.x; b < job.row_b1; b += kSelThreads) part[1] += P5[(size_t)b * 2 + job.col];
+  for (int k = 0; k < 2; ++k) {
+    double v = wave_sum(part[k]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  double tot[2] = {0.0, 0.0};
+  for (int w2 = 0; w2 < kSelThreads / 64; ++w2) { tot[0] += red[w2][0]; tot[1] += red[w2][1]; }
+  const long long m = job.cnt ? (long long)tot[0] : job.m_fixed, below = (long long)tot[1];
+  const int n = job.n0 + job.n1, c = cursor[blockIdx.x];
+  long long k = job.k;
+  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
+  if (k >= n) k = -1;
+  const double pv = prev[job.state], pw = win[job.state];
+  __syncthreads();
+  if (threadIdx.x == 0) cursor[blockIdx.x] = 0;  // ready for the next selection
+  if (k < 0) {
+    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m; }
+    return;
+  }
+  const bool hit = pv > 0.0 && pv < INFINITY && c <= kSelCap && below <= k && k < below + c;
+  unsigned long long value;
+  if (hit) {
+    const long long kk = k - below;
+    for (int i = threadIdx.x; i < c; i += kSelThreads) keys[i] = coll[(size_t)blockIdx.x * kSelCap + i];
+    __syncthreads();
+    if (c <= 256) {
+      const bool have = (int)threadIdx.x < c;
+      const unsigned long long mine = have ? keys[threadIdx.x] : ~0ull;
+      int less = 0, leq = 0;
+      for (int j = 0; j < c; ++j) { unsigned long long kj = keys[j]; less += kj < mine; leq += kj <= mine; }
+      if (have && kk >= less && kk < leq) picked = mine;
+      __syncthreads();
+      value = picked;
+    } else {
+      value = radix_select_block([&](int i) { return keys[i]; }, c, kk, lh, wave_tot, sel);
+    }
+  } else {
+    value = radix_select_block([&](int i) { return job_key(job, i); }, n, k, lh, wave_tot, sel);
+  }
+  if (threadIdx.x == 0) {
+    const double v = __longlong_as_double((long long)value);
+    job.out[0] = v; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m;
+    prev[job.state] = v;
+    double w2 = pw;
+    if (!hit) w2 = fmin(pw * 4.0, 0.125);
+    else if (c > kSelCap / 4) w2 = pw * 0.5;
+    else if (c < 64) w2 = fmin(pw * 2.0, 0.125);
+    win[job.state] = w2;
+  }
 }
 
 __device__ __forceinline__ double mad_factor(const double *sel) {  // 1 / rrel_util_median_abs_dev_scale
@@ -2902,6 +3028,7 @@ SelJob make_job(const double *k0, int n0, const double *k1, int n1, long long k,
   SelJob j{};
   j.k0 = k0; j.n0 = n0; j.k1 = k1; j.n1 = n1; j.k = k; j.out = nullptr;
   j.cnt = nullptr; j.cnt_a0 = j.cnt_a1 = j.cnt_b0 = j.cnt_b1 = 0; j.m_fixed = m; j.state = -1;
+  j.row_a0 = j.row_a1 = j.row_b0 = j.row_b1 = 0; j.col = 0;
   return j;
 }
 
@@ -3129,6 +3256,12 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipMemset(ctx->d_selhist, 0, sizeof(int) * kMaxSelJobs * 2048)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selprev, sizeof(double) * kSelStates)) != hipSuccess) return bail(e);
   if ((e = hipMemset(ctx->d_selprev, 0, sizeof(double) * kSelStates)) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_selwin, sizeof(double) * kSelStates)) != hipSuccess) return bail(e);
+  {
+    double w0[kSelStates];
+    for (int k = 0; k < kSelStates; ++k) w0[k] = 1.0 / 256.0;
+    if ((e = hipMemcpy(ctx->d_selwin, w0, sizeof w0, hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+  }
   if ((e = hipMalloc(&ctx->d_selcoll, sizeof(unsigned long long) * kMaxSelJobs * kSelCap)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selcursor, sizeof(int) * kMaxSelJobs)) != hipSuccess) return bail(e);
   if ((e = hipMemset(ctx->d_selcursor, 0, sizeof(int) * kMaxSelJobs)) != hipSuccess) return bail(e);
@@ -3152,7 +3285,7 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   void *dev[] = {ctx->d_partials, ctx->d_final, ctx->d_jobs, ctx->d_fused, ctx->d_selstate, ctx->d_selhist,
-                 ctx->d_selprev, ctx->d_selcoll, ctx->d_selcursor};
+                 ctx->d_selprev, ctx->d_selcoll, ctx->d_selcursor, ctx->d_selwin};
   for (void *p : dev) if (p) (void)hipFree(p);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
@@ -4114,28 +4247,50 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
     hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kWide), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
     HIPCHK(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(k_f_weights, dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, wo, P1, P3, nb3, SC, P4);
+  // The order statistics ride along with the weight pass (FOLD) when the scales have settled: same lists and sizes as
+  // the last two estimates and all four results within 1e-3 of their predecessors.  Otherwise the three-kernel windowed
+  // select (wide window: survives any jump).
+  const bool same = ctx->sel_dirs[0] == (const void *)F && ctx->sel_dirs[1] == (const void *)B && ctx->sel_n[0] == F->n && ctx->sel_n[1] == B->n;
+  if (!same) ctx->sel_runs = 0;
+  bool fold = same && ctx->sel_runs >= 2 && o->dof == 12 && std::getenv("LRR_ICP_NO_FOLD") == nullptr;
+  for (int k = 0; k < 4 && fold; ++k)
+    if (!(std::fabs(ctx->sel_last[k] - ctx->sel_prev[k]) <= 1e-3 * std::fabs(ctx->sel_last[k]))) fold = false;
+  FoldArgs fa;
+  fa.prev = ctx->d_selprev; fa.win = ctx->d_selwin; fa.coll = ctx->d_selcoll; fa.cursor = ctx->d_selcursor; fa.P5 = ctx->d_fused + kFusedP5;
+  if (fold) hipLaunchKernelGGL((k_f_weights<true>), dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, wo, P1, P3, nb3, SC, P4, fa);
+  else hipLaunchKernelGGL((k_f_weights<false>), dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, wo, P1, P3, nb3, SC, P4, fa);
   HIPCHK(ctx, hipGetLastError());
   // order statistics: ranks of the strength jobs come from the device-side counts
   SelJob *hj = ctx->h_jobs;
   int nj = 0;
-  auto job = [&](const double *k0, int n0, const double *k1, int n1, long long m, bool counted, int a0, int a1, int b0, int b1) {
+  auto job = [&](const double *k0, int n0, const double *k1, int n1, long long m, bool counted, int a0, int a1, int b0, int b1, int col,
+                 int ra0, int ra1, int rb0, int rb1) {
     SelJob j = make_job(k0, n0, k1, n1, -1, m);
     j.out = SEL + 4 * nj;
     j.cnt = counted ? P4 : nullptr; j.cnt_a0 = a0; j.cnt_a1 = a1; j.cnt_b0 = b0; j.cnt_b1 = b1;
+    j.row_a0 = ra0; j.row_a1 = ra1; j.row_b0 = rb0; j.row_b1 = rb1; j.col = col;
     j.state = (o->rrl ? 0 : 4) + nj;
     hj[nj++] = j;
   };
   if (o->rrl) {
-    job(F->key_g, nsF, nullptr, 0, 0, true, 0, nbF, 0, 0);
-    job(B->key_g, nsB, nullptr, 0, 0, true, nbF, nbF + nbB, 0, 0);
-    job(F->key_s, nsF, nullptr, 0, F->n, false, 0, 0, 0, 0);
-    job(B->key_s, nsB, nullptr, 0, B->n, false, 0, 0, 0, 0);
+    job(F->key_g, nsF, nullptr, 0, 0, true, 0, nbF, 0, 0, 0, 0, nbF, 0, 0);
+    job(B->key_g, nsB, nullptr, 0, 0, true, nbF, nbF + nbB, 0, 0, 0, nbF, nbF + nbB, 0, 0);
+    job(F->key_s, nsF, nullptr, 0, F->n, false, 0, 0, 0, 0, 1, 0, nbF, 0, 0);
+    job(B->key_s, nsB, nullptr, 0, B->n, false, 0, 0, 0, 0, 1, nbF, nbF + nbB, 0, 0);
   } else {
-    job(F->key_g, nsF, B->key_g, nsB, 0, true, 0, nbF, nbF, nbF + nbB);
-    job(F->key_s, nsF, B->key_s, nsB, F->n + B->n, false, 0, 0, 0, 0);
+    job(F->key_g, nsF, B->key_g, nsB, 0, true, 0, nbF, nbF, nbF + nbB, 0, 0, nbF, nbF, nbF + nbB);
+    job(F->key_s, nsF, B->key_s, nsB, F->n + B->n, false, 0, 0, 0, 0, 1, 0, nbF, nbF, nbF + nbB);
   }
-  { int rc = launch_select_kth(ctx, nj); if (rc) return rc; }
+  if (fold) {
+    SelPack pk;
+    for (int j = 0; j < kSelPack; ++j) pk.j[j] = hj[std::min(j, nj - 1)];
+    hipLaunchKernelGGL(k_selw_fold_final, dim3(nj), dim3(kSelThreads), 0, st, pk, ctx->d_selprev, ctx->d_selwin, (const double *)(ctx->d_fused + kFusedP5),
+                       (const unsigned long long *)ctx->d_selcoll, ctx->d_selcursor);
+    HIPCHK(ctx, hipGetLastError());
+  } else {
+    int rc = launch_select_kth(ctx, nj);
+    if (rc) return rc;
+  }
   // F6 + final reduction
   int nbAF = std::min(grid_for(nsF), kAccBlocks), nbAB = std::min(grid_for(nsB), kAccBlocks);
   const double *c = o->jac_centre;
@@ -4160,6 +4315,12 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   auto mad = [&](int slot) { const double *sl = h + SEL_OFF + 4 * slot; return sl[3] > 1.0 ? 1.4826 * (1 + 5.0 / (sl[3] - 1.0)) * sl[0] : 0.0; };
   if (o->rrl) { out->grad_scale[0] = mad(0); out->grad_scale[1] = mad(1); out->spatial_scale[0] = mad(2); out->spatial_scale[1] = mad(3); }
   else { out->grad_scale[0] = out->grad_scale[1] = mad(0); out->spatial_scale[0] = out->spatial_scale[1] = mad(1); }
+  for (int k = 0; k < 4; ++k) {  // the selected values themselves: what the folded selection's windows follow
+    ctx->sel_prev[k] = ctx->sel_last[k];
+    ctx->sel_last[k] = h[SEL_OFF + 4 * std::min(k, nj - 1)];
+  }
+  ctx->sel_dirs[0] = F; ctx->sel_dirs[1] = B; ctx->sel_n[0] = F->n; ctx->sel_n[1] = B->n;
+  if (ctx->sel_runs < 1000) ++ctx->sel_runs;
   int t = 0;
   for (int a = 0; a < o->dof; ++a)
     for (int b = a; b < o->dof; ++b) { out->AtA[a * o->dof + b] = h[FIN_OFF + t]; out->AtA[b * o->dof + a] = h[FIN_OFF + t]; ++t; }
