@@ -30,7 +30,10 @@ json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 benc
                       "--pmc WRITE_SIZE (separate passes); summarised by tools/prof_summary.py pmc",
            "code_sha": sha, "unit": "KB as reported (FETCH_SIZE uncorrected)", "kernels": merged},
           open(f"profiles/{out}_pmc_fetch_write_per_kernel.json", "w"), indent=1)
-k1 = [k for k in ("k_match_cert2", "k_match_list2", "k_match_hard2") if k in f]
+# the kernels of a steady finest-level search: k_match_list2 runs only while the certificate list is long (the first searches
+# of the level), so it is counted only when it was dispatched about as often as the certificate kernel
+k1 = [k for k in ("k_match_cert2", "k_match_list2", "k_match_hard2")
+      if k in f and f[k].get("FETCH_SIZE_dispatches", 0) * 2 >= f["k_match_cert2"].get("FETCH_SIZE_dispatches", 1)]
 fe = sum(f[k]["FETCH_SIZE_avg_last20"] for k in k1) / 2
 wr = sum(w[k]["WRITE_SIZE_avg_last20"] for k in k1) / 2
 traffic = (2 * fe + wr) * 1024
