@@ -2300,7 +2300,8 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
 // k_selw_collect; `below` = keys under the window (P5); when the rank lies among the gathered keys it is selected there,
 // else (window missed, overflowed, no previous result) by the full radix select over all keys of the job.  The window
 // width tunes itself: halved when it gathers more than a quarter of the capacity, doubled when it gathers next to
-// nothing, widened after a miss.
+// nothing, widened after a miss, cut to an eighth after an overflow (a couple of slow selections when a level with
+// millions of keys starts).
 __global__ __launch_bounds__(kSelThreads) void k_selw_fold_final(SelPack jobs, double *prev, double *win, const double *P5,
                                                                 const unsigned long long *coll, int *cursor) {
   __shared__ unsigned long long keys[kSelCap];
@@ -2361,7 +2362,8 @@ __global__ __launch_bounds__(kSelThreads) void k_selw_fold_final(SelPack jobs, d
     job.out[0] = v; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m;
     prev[job.state] = v;
     double w2 = pw;
-    if (!hit) w2 = fmin(pw * 4.0, 0.125);
+    if (c > kSelCap) w2 = pw * 0.125;               // gathered far too much (long key lists): much narrower
+    else if (!hit) w2 = fmin(pw * 4.0, 0.125);      // the rank fell outside: wider
     else if (c > kSelCap / 4) w2 = pw * 0.5;
     else if (c < 64) w2 = fmin(pw * 2.0, 0.125);
     win[job.state] = w2;
