@@ -1342,6 +1342,22 @@ __global__ void k_slots_sparse(const int *order, int use_keys, Keys keys, int ha
   active[i] = s;
 }
 
+// Coarse levels of a symmetric estimator (a few thousand of the sources active): every active source goes straight
+// to the wave-per-query kernel — a thousand queries are a thousand wavefronts, each scanning its candidates with 64
+// lanes, where the thread-per-slot ring search walks them one dependent round at a time.  This kernel assigns the
+// list positions of both directions and writes the two work lists (and their lengths).
+struct CoarseArgs { Keys keys; int half, nsrc, n; const int *canon_of; int *slot; double *w; int *list, *list_count; };
+__global__ void k_slots_coarse2(CoarseArgs A, CoarseArgs B) {
+  const CoarseArgs &C = blockIdx.y == 0 ? A : B;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *C.list_count = C.n;
+  if (i >= C.n) return;
+  int s = C.canon_of[subset_perm(i, C.nsrc, C.half, C.keys)];
+  C.slot[s] = i;
+  C.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+  C.list[i] = s;
+}
+
 // All-vs-all matcher: each block owns kBlock*Q queries (Q per thread, in registers) and streams
 // one chunk of the target cloud through LDS in tiles; every lane reads the same LDS address
 // (broadcast, conflict-free).  blockIdx.y splits the target cloud so that small query counts
@@ -3878,6 +3894,34 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     rc = match_launch(f, Pf, ctx->lane[0], st);
     rc2 = match_launch(b, Pb, ctx->lane[1], st);
     return rc ? rc : rc2;
+  }
+  // Coarse levels (both subsets sparse and small, keyed permutations): one stream, three launches for both directions
+  // — list positions + work lists, wave-per-query search (around the previous match where there is one), brute force
+  // for what is left.
+  constexpr int64_t kCoarseMax = 16384;
+  if ((method == LRR_ICP_NN_GRID || method == LRR_ICP_NN_AUTO) && !order_f && !order_b && keys_f && keys_b && n_f > 0 && n_b > 0 &&
+      n_f * 4 < f->from->n && n_b * 4 < b->from->n && n_f <= kCoarseMax && n_b <= kCoarseMax && std::getenv("LRR_ICP_NO_COARSE_PAIR") == nullptr) {
+    MatchPrep Pf, Pb;
+    hipStream_t st = ctx->stream;
+    if ((rc = match_prepare(f, xf_f, keys_f, order_f, n_f, method, ctx->lane[0], st, Pf))) return rc;
+    if ((rc = match_prepare(b, xf_b, keys_b, order_b, n_b, method, ctx->lane[1], st, Pb))) return rc;
+    ProfScope prof(ctx, st, 2);
+    HIPCHK(ctx, hipMemsetAsync(f->slot, 0xff, sizeof(int) * f->cap, st));
+    HIPCHK(ctx, hipMemsetAsync(b->slot, 0xff, sizeof(int) * b->cap, st));
+    CoarseArgs cf, cb;
+    cf.keys = Pf.kk; cf.half = Pf.half; cf.nsrc = (int)Pf.N; cf.n = (int)n_f; cf.canon_of = f->from->canon_of; cf.slot = f->slot; cf.w = f->w;
+    cf.list = ctx->lane[0].d_hard; cf.list_count = Pf.counts;
+    cb.keys = Pb.kk; cb.half = Pb.half; cb.nsrc = (int)Pb.N; cb.n = (int)n_b; cb.canon_of = b->from->canon_of; cb.slot = b->slot; cb.w = b->w;
+    cb.list = ctx->lane[1].d_hard; cb.list_count = Pb.counts;
+    hipLaunchKernelGGL(k_slots_coarse2, dim3(blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, cf, cb);
+    HIPCHK(ctx, hipGetLastError());
+    HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);
+    HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
+    hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
+    HIPCHK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_match_overflow2, dim3(128, 2), dim3(kBlock), 0, st, over_args(hf), over_args(hb));
+    HIPCHK(ctx, hipGetLastError());
+    return LRR_ICP_OK;
   }
   {
     ProfScope prof(ctx, ctx->stream, 2);  // fork .. join on the main stream: both searches
