@@ -52,6 +52,7 @@ constexpr int kBlock = 256;          // 4 wavefronts of 64
 constexpr int kMaxBlocks = 2048;     // reduction grids: 8 blocks / CU on 256 CUs (one dependent gather chain per thread)
 constexpr int kWide = 1024;          // block size of the fused estimate's streaming passes: at most kWideBlocks of them, so a
 constexpr int kWideBlocks = 256;     // consumer's prologue sums <= 256 rows of producer partials (one block per CU, 16 waves each)
+constexpr int kStreamBatch = 2;      // sources a thread of those passes has in flight at once
 constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 for dof 12)
 constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
 constexpr int kTile = 8;             // canonical order: tiles of kTile^3 grid cells
@@ -409,12 +410,26 @@ __device__ __forceinline__ void block_sum_all(double (&v)[K]) {
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = s;
   }
   __syncthreads();
+  if constexpr (NW > 4) {
+    // wide blocks: K threads add the NW wave sums (every thread doing so would hold K x NW values in registers at once)
+    __shared__ double tot[K];
+    if ((int)threadIdx.x < K) {
+      double t = sh[0][threadIdx.x];
 #pragma unroll
-  for (int k = 0; k < K; ++k) {
-    double t = sh[0][k];
+      for (int w2 = 1; w2 < NW; ++w2) t += sh[w2][threadIdx.x];
+      tot[threadIdx.x] = t;
+    }
+    __syncthreads();
 #pragma unroll
-    for (int w2 = 1; w2 < NW; ++w2) t += sh[w2][k];
-    v[k] = t;
+    for (int k = 0; k < K; ++k) v[k] = tot[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      double t = sh[0][k];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; ++w2) t += sh[w2][k];
+      v[k] = t;
+    }
   }
   __syncthreads();
 }
@@ -2114,34 +2129,57 @@ __global__ __launch_bounds__(kWide) void k_f_residual(DirArgs F, DirArgs B, int 
   const XfD &xf = isF ? xfF : xfB;
   const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
   double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int s = lb * kWide + threadIdx.x; s < D.ps.nsrc; s += nb * kWide) {
-    // every load whose address does not depend on another is issued before the first test: two
-    // dependent memory levels per source (streams, then the gather) instead of three
-    const int sl = D.ps.slot[s], mt = D.ps.m_to[s];
-    double p0, p1, p2, y0, y1, y2;
-    load_from(D.ps, s, p0, p1, p2);
-    const double sp = D.ps.from_str[s], wp = D.w[s];
-    if (sl < 0) { D.key_s[s] = INFINITY; continue; }
+  // The grid is one resident round of blocks (grid_wide_pair), so a thread takes its sources kStreamBatch at a time and
+  // issues the loads of the whole batch level by level — the streams, then the gathers — before any arithmetic: two
+  // dependent memory round trips per batch.
+  constexpr int U = kStreamBatch;
+  const int stride = nb * kWide;
+  for (int s0 = lb * kWide + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
+    int sl[U], mt[U];
+    double p[U][3], sp[U], wp[U], q[U][10];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * stride;
+      sl[u] = -2; mt[u] = 0; sp[u] = 0.0; wp[u] = 0.0; p[u][0] = p[u][1] = p[u][2] = 0.0;
+      if (s < D.ps.nsrc) {
+        sl[u] = D.ps.slot[s]; mt[u] = D.ps.m_to[s];
+        load_from(D.ps, s, p[u][0], p[u][1], p[u][2]);
+        sp[u] = D.ps.from_str[s]; wp[u] = D.w[s];
+      }
+    }
     // the one gather of the matched target's record in this estimate: location and strength gain
     // are kept per source for the weight and normal-equation passes
-    const double *q = D.ps.to_rec + (size_t)mt * kRecStride;
-    const double q0 = q[0], q1 = q[1], q2 = q[2];
-    map_loc(xf, (p0 - ident.cm[0]) / ident.rm, (p1 - ident.cm[1]) / ident.rm, (p2 - ident.cm[2]) / ident.rm, y0, y1, y2);
-    double r2 = proj_residual2(y0, y1, y2, (q0 - ident.cf[0]) / ident.rf, (q1 - ident.cf[1]) / ident.rf, (q2 - ident.cf[2]) / ident.rf,
-                               q[3], q[4], q[5], q[6], q[7], q[8]);
-    D.q_loc[3 * (size_t)s] = q0; D.q_loc[3 * (size_t)s + 1] = q1; D.q_loc[3 * (size_t)s + 2] = q2;
-    {
-      const double sq = q[9];
-      const double g = D.float_product ? (double)((float)sp * (float)sq) : sp * sq;
-      D.key_g[s] = g > 90000.0 ? 90000.0 : g;  // strength_gain(); F4 turns it into the selection key
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (sl[u] < 0) continue;
+      const double *r = D.ps.to_rec + (size_t)mt[u] * kRecStride;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) q[u][k] = r[k];
     }
-    acc[0] += wp * r2;
-    acc[1] += wp;
-    D.r2[s] = r2;
-    D.key_s[s] = sqrt(r2);
-    if (isF && want_stats) {
-      acc[2] += p0; acc[3] += p1; acc[4] += p2;
-      D.flag[mt] = D.gen;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * stride;
+      if (sl[u] == -2) continue;
+      if (sl[u] < 0) { D.key_s[s] = INFINITY; continue; }
+      const double q0 = q[u][0], q1 = q[u][1], q2 = q[u][2];
+      double y0, y1, y2;
+      map_loc(xf, (p[u][0] - ident.cm[0]) / ident.rm, (p[u][1] - ident.cm[1]) / ident.rm, (p[u][2] - ident.cm[2]) / ident.rm, y0, y1, y2);
+      double r2 = proj_residual2(y0, y1, y2, (q0 - ident.cf[0]) / ident.rf, (q1 - ident.cf[1]) / ident.rf, (q2 - ident.cf[2]) / ident.rf,
+                                 q[u][3], q[u][4], q[u][5], q[u][6], q[u][7], q[u][8]);
+      D.q_loc[3 * (size_t)s] = q0; D.q_loc[3 * (size_t)s + 1] = q1; D.q_loc[3 * (size_t)s + 2] = q2;
+      {
+        const double sq = q[u][9];
+        const double g = D.float_product ? (double)((float)sp[u] * (float)sq) : sp[u] * sq;
+        D.key_g[s] = g > 90000.0 ? 90000.0 : g;  // strength_gain(); F4 turns it into the selection key
+      }
+      acc[0] += wp[u] * r2;
+      acc[1] += wp[u];
+      D.r2[s] = r2;
+      D.key_s[s] = sqrt(r2);
+      if (isF && want_stats) {
+        acc[2] += p[u][0]; acc[3] += p[u][1]; acc[4] += p[u][2];
+        D.flag[mt[u]] = D.gen;
+      }
     }
   }
   block_reduce_store<5, kWide / 64>(acc, P1);
@@ -2153,10 +2191,10 @@ __global__ __launch_bounds__(kWide) void k_f_radii(DirArgs F, int nbF, const dou
                                                     double *SC) {
   double cm[3], cf[3];
   double tot[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // from-sums (3), distinct-to sums (3) and their count
-  for (int b = threadIdx.x; b < nbF; b += kWide)
-    for (int k = 0; k < 3; ++k) tot[k] += P1[(size_t)b * 5 + 2 + k];
-  for (int b = threadIdx.x; b < nbT; b += kWide)
-    for (int k = 0; k < 4; ++k) tot[3 + k] += P2[(size_t)b * 4 + k];
+  if ((int)threadIdx.x < nbF)  // at most kWideBlocks rows each: one per thread
+    for (int k = 0; k < 3; ++k) tot[k] = P1[(size_t)threadIdx.x * 5 + 2 + k];
+  if ((int)threadIdx.x < nbT)
+    for (int k = 0; k < 4; ++k) tot[3 + k] = P2[(size_t)threadIdx.x * 4 + k];
   block_sum_all<7, kWide / 64>(tot);
   const double nd = tot[6];
   for (int k = 0; k < 3; ++k) { cm[k] = tot[k] / (double)F.n; cf[k] = tot[3 + k] / nd; }
@@ -2220,10 +2258,9 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
   const int r0 = isF ? 0 : nbF, r1 = isF ? nbF : nbF + nbB;
   const int mode = isF ? o.mode_f : o.mode_b;
   double tot[4] = {0.0, 0.0, 0.0, 0.0};  // S, W of this list's residuals; radius sums of both clouds
-  if (mode == LRR_ICP_SCALE_RMS)
-    for (int b = r0 + (int)threadIdx.x; b < r1; b += kWide) { tot[0] += P1[(size_t)b * 5]; tot[1] += P1[(size_t)b * 5 + 1]; }
-  if (o.normalize)
-    for (int b = threadIdx.x; b < nb3; b += kWide) { tot[2] += P3[(size_t)b * 2]; tot[3] += P3[(size_t)b * 2 + 1]; }
+  // (at most kWideBlocks rows: one per thread, no loop to unroll)
+  if (mode == LRR_ICP_SCALE_RMS && r0 + (int)threadIdx.x < r1) { const int b = r0 + threadIdx.x; tot[0] = P1[(size_t)b * 5]; tot[1] = P1[(size_t)b * 5 + 1]; }
+  if (o.normalize && (int)threadIdx.x < nb3) { const int b = threadIdx.x; tot[2] = P3[(size_t)b * 2]; tot[3] = P3[(size_t)b * 2 + 1]; }
   block_sum_all<4, kWide / 64>(tot);
   const double scale = mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : (isF ? o.inj_f : o.inj_b);
   __shared__ double sc_norm[8];
@@ -2258,42 +2295,56 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
     if (threadIdx.x < 2) nstage[threadIdx.x] = 0;
     __syncthreads();
   }
-  for (int s = lb * kWide + threadIdx.x; s < D.ps.nsrc; s += nb * kWide) {
-    if (D.ps.slot[s] < 0) { D.key_g[s] = INFINITY; D.key_s[s] = INFINITY; continue; }
-    double u = D.r2[s] / scale2, bt = 0.0;
-    if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
-    double wi = bt / scale2;
-    if (clone) D.w[s] = wi;  // the backward list itself keeps its Beaton-Tukey weights (cdcl sym .txx:665)
-    double key = INFINITY;
-    if (strength && wi != 0) {
-      double g = D.key_g[s];  // strength_gain() of the pair, left here by F1
-      wi = wi * g;
-      key = g;
-      acc[0] += 1.0;
-    }
-    D.key_g[s] = key;
-    if (FOLD) {
-      if (key < lo_g) below[0] += 1.0;
-      else if (key <= hi_g) { const int p = atomicAdd(&nstage[0], 1); if (p < kFoldStage) stage[0][p] = (unsigned long long)__double_as_longlong(key); }
-    }
-    {  // weight_spatially's 1 / (1 + 5 |q~|^2) on the normalised to-location (clones: their from-location)
-      double q0, q1, q2;
-      if (clone) {
-        load_from(D.ps, s, q0, q1, q2);
-        q0 = (q0 - nm.cm[0]) / nm.rm; q1 = (q1 - nm.cm[1]) / nm.rm; q2 = (q2 - nm.cm[2]) / nm.rm;
-      } else {
-        const double *q = D.q_loc + 3 * (size_t)s;
-        q0 = (q[0] - nm.cf[0]) / nm.rf; q1 = (q[1] - nm.cf[1]) / nm.rf; q2 = (q[2] - nm.cf[2]) / nm.rf;
+  constexpr int U = kStreamBatch;
+  const int stride = nb * kWide;
+  for (int s0 = lb * kWide + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
+    int sl[U];
+    double r2v[U], gv[U], ql[U][3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // all loads of the batch first: one memory round trip
+      const int s = s0 + u * stride;
+      sl[u] = -2; r2v[u] = 0.0; gv[u] = 0.0; ql[u][0] = ql[u][1] = ql[u][2] = 0.0;
+      if (s < D.ps.nsrc) {
+        sl[u] = D.ps.slot[s]; r2v[u] = D.r2[s]; gv[u] = D.key_g[s];
+        if (clone) load_from(D.ps, s, ql[u][0], ql[u][1], ql[u][2]);
+        else { const double *q = D.q_loc + 3 * (size_t)s; ql[u][0] = q[0]; ql[u][1] = q[1]; ql[u][2] = q[2]; }
       }
-      double dq = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
-      const double ks = 1.0 / (1.0 + 5.0 * dq * dq);
-      D.key_s[s] = ks;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * stride;
+      if (sl[u] == -2) continue;
+      if (sl[u] < 0) { D.key_g[s] = INFINITY; D.key_s[s] = INFINITY; continue; }
+      double uu = r2v[u] / scale2, bt = 0.0;
+      if (uu <= 16.0) { double temp = 1 - uu * 0.0625; bt = temp * temp; }
+      double wi = bt / scale2;
+      if (clone) D.w[s] = wi;  // the backward list itself keeps its Beaton-Tukey weights (cdcl sym .txx:665)
+      double key = INFINITY;
+      if (strength && wi != 0) {
+        double g = gv[u];  // strength_gain() of the pair, left here by F1
+        wi = wi * g;
+        key = g;
+        acc[0] += 1.0;
+      }
+      D.key_g[s] = key;
       if (FOLD) {
-        if (ks < lo_s) below[1] += 1.0;
-        else if (ks <= hi_s) { const int p = atomicAdd(&nstage[1], 1); if (p < kFoldStage) stage[1][p] = (unsigned long long)__double_as_longlong(ks); }
+        if (key < lo_g) below[0] += 1.0;
+        else if (key <= hi_g) { const int p = atomicAdd(&nstage[0], 1); if (p < kFoldStage) stage[0][p] = (unsigned long long)__double_as_longlong(key); }
       }
+      {  // weight_spatially's 1 / (1 + 5 |q~|^2) on the normalised to-location (clones: their from-location)
+        double q0, q1, q2;
+        if (clone) { q0 = (ql[u][0] - nm.cm[0]) / nm.rm; q1 = (ql[u][1] - nm.cm[1]) / nm.rm; q2 = (ql[u][2] - nm.cm[2]) / nm.rm; }
+        else { q0 = (ql[u][0] - nm.cf[0]) / nm.rf; q1 = (ql[u][1] - nm.cf[1]) / nm.rf; q2 = (ql[u][2] - nm.cf[2]) / nm.rf; }
+        double dq = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
+        const double ks = 1.0 / (1.0 + 5.0 * dq * dq);
+        D.key_s[s] = ks;
+        if (FOLD) {
+          if (ks < lo_s) below[1] += 1.0;
+          else if (ks <= hi_s) { const int p = atomicAdd(&nstage[1], 1); if (p < kFoldStage) stage[1][p] = (unsigned long long)__double_as_longlong(ks); }
+        }
+      }
+      wdst[s] = wi;
     }
-    wdst[s] = wi;
   }
   block_reduce_store<1, kWide / 64>(acc, P4);
   if (FOLD) {
@@ -2921,6 +2972,9 @@ inline int grid_wide(int64_t n) {  // blocks of kWide threads, a multiple of 8, 
   if (b < 8) b = 8;
   return (int)std::min<int64_t>(b, kWideBlocks);
 }
+// the same for a launch that serves both lists of a symmetric estimate: half of the chip's one round each, so that no
+// block waits for a compute unit to come free (1024-thread blocks: one per CU)
+inline int grid_wide_pair(int64_t n) { return std::min(grid_wide(n), kWideBlocks / 2); }
 inline int blocks_for(int64_t n) { return (int)std::max<int64_t>(1, (n + kBlock - 1) / kBlock); }
 
 XfD to_dev(const lrr_icp_xform *x) {
@@ -4273,7 +4327,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   double *SC = OUT, *SEL = OUT + SEL_OFF, *FIN = OUT + FIN_OFF;
   DirArgs aF = dir_args(F), aB = dir_args(B);
   const int nsF = aF.ps.nsrc, nsB = aB.ps.nsrc;
-  int nbF = grid_wide(nsF), nbB = grid_wide(nsB), nt = (int)F->to->n, nbT = grid_wide(nt);
+  int nbF = grid_wide_pair(nsF), nbB = grid_wide_pair(nsB), nt = (int)F->to->n, nbT = grid_wide(nt);
   int nb3 = std::max(nbF, nbT);
   NormD ident = to_dev((const lrr_icp_norm *)nullptr);
   // F1
