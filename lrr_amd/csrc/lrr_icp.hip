@@ -72,10 +72,12 @@ constexpr int kSelStates = 16;      // remembered results (window centres)
 constexpr int kSelHistBlocks = 128;  // blocks per job of the chip-wide select kernels (<= kSelPre keys per thread up to 262k keys)
 // fused scratch: P1 (2*kMaxBlocks x 5), P2 (kMaxBlocks x 4), P3 (kMaxBlocks x 2), P4 (2*kMaxBlocks x 1),
 // P6 (2*256 x 96), output block
-constexpr int kAccBlocks = 128;      // accumulate grid per direction (90 fp64 accumulators per thread: 2 waves/SIMD)
+constexpr int kAccBlocks = 128;      // accumulate grid per direction, generic form (90 fp64 accumulators per thread: 1 wave/SIMD)
+constexpr int kKronBlocks = 256;     // ... of the 12-dof Kronecker form (72 accumulators: two blocks per CU, 2 waves/SIMD)
+constexpr int kKron = 72;            // its sums: 10 (unique products of (l,1)(l,1)^T) x 6 (unique projector entries) + 12 (rhs)
 constexpr int kFusedP1 = 0, kFusedP2 = kFusedP1 + 2 * kMaxBlocks * 5, kFusedP3 = kFusedP2 + kMaxBlocks * 4,
               kFusedP4 = kFusedP3 + kMaxBlocks * 2, kFusedP6 = kFusedP4 + 2 * kMaxBlocks,
-              kFusedOut = kFusedP6 + 2 * kAccBlocks * 96, kFusedP5 = kFusedOut + 256,  // P5: per-block counts of keys below the two selection windows
+              kFusedOut = kFusedP6 + 2 * kKronBlocks * 96, kFusedP5 = kFusedOut + 256,  // P5: per-block counts of keys below the two selection windows
               kFusedDoubles = kFusedP5 + 2 * kMaxBlocks * 2;
 
 // one candidate of the search grid: 32 B = two 16-B loads
@@ -2529,6 +2531,117 @@ __global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, i
   block_reduce_store<NT + DOF>(acc, P6);
 }
 
+// The 12-dof (affine) normal equations as a Kronecker product.  The affine Jacobian has one non-zero per column
+// (J[d][3d+k] = l_k, J[d][9+d] = 1), so with x = (l0, l1, l2, 1)
+//     (J^T P J)[(d,k),(e,m)] = x_k x_m P_de        and        (J^T P b)[(d,k)] = x_k (P b)_d :
+// 10 unique products x_k x_m times 6 unique projector entries = 60 sums carry the whole 78-entry triangle (entries
+// (d,k),(e,m) and (e,k),(d,m) are the same number), a third fewer accumulators and operations than the generic form —
+// what lets two waves share a SIMD.  Sum s = 6 i + j: i over {00,01,02,11,12,22,03,13,23,33} of x x^T, j over
+// {xx,xy,xz,yy,yz,zz} of P; sums 60..71: the right-hand side in parameter order.  kron_expand rebuilds the matrix.
+// Rounding: x_k x_m is formed first, where the generic form multiplies (x_k P_de) x_m — same products, last-bit
+// differences; the weight enters through P w in both forms of the reference (PREMUL: (J^T (P w)) J; else (J^T P) J w).
+template <bool PREMUL>
+__device__ __forceinline__ void accumulate_pair_kron(double *acc, double wi, double jx, double jy, double jz, double b0,
+                                                     double b1, double b2, const double *P, double c0, double c1,
+                                                     double c2, int rigid_increment) {
+  if (rigid_increment) { b0 = b0 - jx; b1 = b1 - jy; b2 = b2 - jz; }
+  double Pw[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Pw[k] = P[k] * wi;
+  const double l0 = jx - c0, l1 = jy - c1, l2 = jz - c2;
+  const double X[9] = {l0 * l0, l0 * l1, l0 * l2, l1 * l1, l1 * l2, l2 * l2, l0, l1, l2};
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[6 * i + j] += X[i] * Pw[j];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) acc[54 + j] += Pw[j];
+  const double Pb[3] = {(Pw[0] * b0 + Pw[1] * b1) + Pw[2] * b2, (Pw[1] * b0 + Pw[3] * b1) + Pw[4] * b2, (Pw[2] * b0 + Pw[4] * b1) + Pw[5] * b2};
+  const double lt[3] = {l0, l1, l2};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[60 + 3 * d + k] += lt[k] * Pb[d];
+    acc[69 + d] += Pb[d];
+  }
+}
+
+// F6 for 12 degrees of freedom: as k_f_accumulate, Kronecker sums, two blocks per compute unit
+constexpr int kKronBatch = 2;
+template <bool PREMUL>
+__global__ __launch_bounds__(kBlock, 2) void k_f_accumulate_kron(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
+                                                                 const double *SC, const double *SEL, double c0, double c1,
+                                                                 double c2, int rigid_increment, double *P6) {
+  constexpr int U = kKronBatch;
+  const bool isF = (int)blockIdx.x < nbF;
+  const DirArgs &D = isF ? F : B;
+  const int nb = isF ? nbF : nbB, lb0 = isF ? blockIdx.x : blockIdx.x - nbF;
+  const int lb = (nb & 7) == 0 ? xcd_block(lb0, nb) : lb0;
+  NormD nm = norm_from_scalars(SC, !isF);
+  const bool clone = !o.rrl && !isF;
+  const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
+  const double fg = strength ? mad_factor(SEL + 4 * (o.rrl ? (isF ? 0 : 1) : 0)) : 1.0;
+  const double fs = mad_factor(SEL + 4 * (o.rrl ? (isF ? 2 : 3) : 1));
+  double *wbuf = clone ? D.wc : D.w;
+  const double *prec = isF ? D.ps.to_rec : D.ps.from_rec;  // whose error projector the term uses
+  double acc[kKron];
+#pragma unroll
+  for (int k = 0; k < kKron; ++k) acc[k] = 0.0;
+  const int stride = nb * kBlock;
+  for (int s0 = lb * kBlock + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
+    int mt[U];
+    double wi[U];
+    bool on[U];
+    {
+      int sl[U];
+      double wv[U], ks[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + u * stride;
+        const bool in = s < D.ps.nsrc;
+        sl[u] = in ? D.ps.slot[s] : -1;
+        wv[u] = in ? wbuf[s] : 0.0;
+        ks[u] = in ? D.key_s[s] : 0.0;
+        mt[u] = in ? D.ps.m_to[s] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        on[u] = sl[u] >= 0;
+        double v = wv[u];
+        if (strength) v = v * fg;
+        v = v * ks[u];
+        v = v * fs;
+        wi[u] = v;
+        if (on[u]) wbuf[s0 + u * stride] = v;
+        if (PREMUL && v < 1e-4) on[u] = false;
+      }
+    }
+    double pl[U][3], ql[U][3], Pq[U][6];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      const int s = s0 + u * stride;
+      load_from(D.ps, s, pl[u][0], pl[u][1], pl[u][2]);
+      const double *qr = D.q_loc + 3 * (size_t)s;  // cached by F1: the backward list needs no gather at all
+      ql[u][0] = qr[0]; ql[u][1] = qr[1]; ql[u][2] = qr[2];
+      const double *pr = prec + (size_t)(isF ? mt[u] : s) * kRecStride;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!on[u]) continue;
+      // normalised coordinates, oriented (backward list: role-reversed term)
+      double p0 = (pl[u][0] - nm.cm[0]) / nm.rm, p1 = (pl[u][1] - nm.cm[1]) / nm.rm, p2 = (pl[u][2] - nm.cm[2]) / nm.rm;
+      double q0 = (ql[u][0] - nm.cf[0]) / nm.rf, q1 = (ql[u][1] - nm.cf[1]) / nm.rf, q2 = (ql[u][2] - nm.cf[2]) / nm.rf;
+      const double j0 = isF ? p0 : q0, j1 = isF ? p1 : q1, j2 = isF ? p2 : q2;
+      const double b0 = isF ? q0 : p0, b1 = isF ? q1 : p1, b2 = isF ? q2 : p2;
+      accumulate_pair_kron<PREMUL>(acc, wi[u], j0, j1, j2, b0, b1, b2, Pq[u], c0, c1, c2, rigid_increment);
+    }
+  }
+  block_reduce_store<kKron>(acc, P6);
+}
+
 // ---------------------------------------------------------------------------------------------
 // post-convergence diagnostics of the verifier, on the matches where they live
 // ---------------------------------------------------------------------------------------------
@@ -4314,6 +4427,20 @@ int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, doub
   return LRR_ICP_OK;
 }
 
+// the 12 x 12 normal matrix and right-hand side from the kKron sums of accumulate_pair_kron
+static void kron_expand(const double *S, double *AtA, double *Atb) {
+  static const int sym4[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
+  static const int sym3[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+  for (int a = 0; a < 12; ++a) {
+    const int da = a < 9 ? a / 3 : a - 9, ka = a < 9 ? a % 3 : 3;
+    for (int b = 0; b < 12; ++b) {
+      const int db = b < 9 ? b / 3 : b - 9, kb = b < 9 ? b % 3 : 3;
+      AtA[a * 12 + b] = S[6 * sym4[ka][kb] + sym3[da][db]];
+    }
+    Atb[a] = S[60 + a];
+  }
+}
+
 int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xform *xfF, const lrr_icp_xform *xfB,
                                const lrr_icp_sym_opts *o, lrr_icp_sym_out *out) {
   if (!F || !B || !xfF || !xfB || !o || !out || (o->dof != 6 && o->dof != 12)) return LRR_ICP_ERR_ARG;
@@ -4392,11 +4519,13 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
     if (rc) return rc;
   }
   // F6 + final reduction
-  int nbAF = std::min(grid_for(nsF), kAccBlocks), nbAB = std::min(grid_for(nsB), kAccBlocks);
+  const bool kron = o->dof == 12;
+  const int acc_cap = kron ? kKronBlocks : kAccBlocks;
+  int nbAF = std::min(grid_for(nsF), acc_cap), nbAB = std::min(grid_for(nsB), acc_cap);
   const double *c = o->jac_centre;
-  const int nt2 = o->dof * (o->dof + 1) / 2, K = nt2 + o->dof;
-  if (o->dof == 12 && o->rrl) hipLaunchKernelGGL((k_f_accumulate<12, true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
-  else if (o->dof == 12) hipLaunchKernelGGL((k_f_accumulate<12, false>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  const int nt2 = o->dof * (o->dof + 1) / 2, K = kron ? kKron : nt2 + o->dof;
+  if (kron && o->rrl) hipLaunchKernelGGL((k_f_accumulate_kron<true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  else if (kron) hipLaunchKernelGGL((k_f_accumulate_kron<false>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   else if (o->rrl) hipLaunchKernelGGL((k_f_accumulate<6, true>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   else hipLaunchKernelGGL((k_f_accumulate<6, false>), dim3(nbAF + nbAB), dim3(kBlock), 0, st, aF, aB, nbAF, nbAB, wo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   HIPCHK(ctx, hipGetLastError());
@@ -4421,6 +4550,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   }
   ctx->sel_dirs[0] = F; ctx->sel_dirs[1] = B; ctx->sel_n[0] = F->n; ctx->sel_n[1] = B->n;
   if (ctx->sel_runs < 1000) ++ctx->sel_runs;
+  if (kron) { kron_expand(h + FIN_OFF, out->AtA, out->Atb); return LRR_ICP_OK; }
   int t = 0;
   for (int a = 0; a < o->dof; ++a)
     for (int b = a; b < o->dof; ++b) { out->AtA[a * o->dof + b] = h[FIN_OFF + t]; out->AtA[b * o->dof + a] = h[FIN_OFF + t]; ++t; }
