@@ -1884,6 +1884,48 @@ __device__ __forceinline__ unsigned long long radix_select_block(KeyAt key_at, i
   return prefix;
 }
 
+// Rank k among c keys that sit in LDS and all lie in [lo, hi] (bit patterns of positive doubles, so ordered like the
+// values): one histogram pass over the 2048 equal slices of the interval, then the few keys of the slice holding the
+// rank are ranked against each other.  Keys spread over an interval land a handful per slice; a slice with more than
+// kSelThreads keys (many equal keys) is handed to the generic radix select.  small: kSelThreads keys of LDS.
+__device__ __forceinline__ unsigned long long window_select_block(const unsigned long long *keys, int c, long long k,
+                                                                  unsigned long long lo, unsigned long long hi, int *hist,
+                                                                  int *wave_tot, int *sel, unsigned long long *small,
+                                                                  int *nsmall, unsigned long long *picked) {
+  const unsigned long long range = hi - lo;
+  const int nbits = range ? 64 - __clzll((long long)range) : 1;
+  const int shift = nbits > 11 ? nbits - 11 : 0;
+  for (int b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
+  if (threadIdx.x == 0) *nsmall = 0;
+  __syncthreads();
+  for (int base = 0; base < c; base += kSelThreads) {
+    const int i = base + threadIdx.x;
+    const bool act = i < c;
+    const int dgt = act ? (int)min((keys[i] - lo) >> shift, 2047ull) : 0;  // (keys lie inside the interval: the clamp never acts)
+    hist_add(hist, act, dgt);
+  }
+  __syncthreads();
+  pick_bin<kSelThreads>(hist, k, wave_tot, sel);
+  const int bin = sel[0], before = sel[1], cb = sel[2];
+  if (cb > kSelThreads) return radix_select_block([&](int i) { return keys[i]; }, c, k, hist, wave_tot, sel);
+  for (int base = 0; base < c; base += kSelThreads) {
+    const int i = base + threadIdx.x;
+    if (i < c) {
+      const unsigned long long key = keys[i];
+      if ((int)min((key - lo) >> shift, 2047ull) == bin) small[atomicAdd(nsmall, 1)] = key;
+    }
+  }
+  __syncthreads();
+  const long long kk = k - before;
+  const bool have = (int)threadIdx.x < cb;
+  const unsigned long long mine = have ? small[threadIdx.x] : ~0ull;
+  int less = 0, leq = 0;
+  for (int j = 0; j < cb; ++j) { const unsigned long long kj = small[j]; less += kj < mine; leq += kj <= mine; }
+  if (have && kk >= less && kk < leq) *picked = mine;  // equal keys store the same value
+  __syncthreads();
+  return *picked;
+}
+
 __global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
   __shared__ int hist[2048];
   __shared__ int wave_tot[kSelThreads / 64];
@@ -2378,6 +2420,8 @@ __global__ __launch_bounds__(kSelThreads) void k_selw_fold_final(SelPack jobs, d
   __shared__ int wave_tot[kSelThreads / 64];
   __shared__ int sel[3];
   __shared__ unsigned long long picked;
+  __shared__ unsigned long long small[kSelThreads];
+  __shared__ int nsmall;
   __shared__ double red[kSelThreads / 64][2];
   SelJob job = jobs.j[blockIdx.x];
   double part[2] = {0.0, 0.0};  // m (counted jobs), keys below the window: whole numbers, exact in any order
@@ -2409,20 +2453,12 @@ __global__ __launch_bounds__(kSelThreads) void k_selw_fold_final(SelPack jobs, d
   const bool hit = pv > 0.0 && pv < INFINITY && c <= kSelCap && below <= k && k < below + c;
   unsigned long long value;
   if (hit) {
-    const long long kk = k - below;
     for (int i = threadIdx.x; i < c; i += kSelThreads) keys[i] = coll[(size_t)blockIdx.x * kSelCap + i];
     __syncthreads();
-    if (c <= 256) {
-      const bool have = (int)threadIdx.x < c;
-      const unsigned long long mine = have ? keys[threadIdx.x] : ~0ull;
-      int less = 0, leq = 0;
-      for (int j = 0; j < c; ++j) { unsigned long long kj = keys[j]; less += kj < mine; leq += kj <= mine; }
-      if (have && kk >= less && kk < leq) picked = mine;
-      __syncthreads();
-      value = picked;
-    } else {
-      value = radix_select_block([&](int i) { return keys[i]; }, c, kk, lh, wave_tot, sel);
-    }
+    // the window the weight pass gathered with: prev * (1 -+ win), as it computed it
+    const double wlo = pv * (1.0 - pw), whi = pv * (1.0 + pw);
+    value = window_select_block(keys, c, k - below, (unsigned long long)__double_as_longlong(wlo), (unsigned long long)__double_as_longlong(whi),
+                                lh, wave_tot, sel, small, &nsmall, &picked);
   } else {
     value = radix_select_block([&](int i) { return job_key(job, i); }, n, k, lh, wave_tot, sel);
   }
