@@ -310,19 +310,22 @@ def main():
     # the timed region: K steps between barriers, repeated `reps` times; the MEDIAN repetition is reported
     reps = max(1, args.reps)
     times = []
-    timer.match_profile(enable=True, reset=True)
+    # K1's launch duration is taken live with HIP events, on the stream that runs it, around every k1_sample-th K1
+    # submission of the timed region (each timed submission costs two event records on the critical path)
+    k1_sample = int(os.environ.get("LRR_BENCH_K1_SAMPLE", "8"))
+    timer.match_profile(enable=k1_sample, reset=True)
     timer.cert_stats(reset=True)
     for _ in range(reps):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            est.one_iteration(it)
-            it += 1
+        est.iterate(it, args.steps)  # exactly K one_iteration() calls, in one C++ loop
+        it += args.steps
         barrier()
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
     match_ms, match_launches = timer.match_profile(enable=False, reset=False)
     cert_seen, cert_searched = timer.cert_stats()
+    event_pair_ms = timer.event_overhead(64)  # an empty event pair on the same stream: the markers' share of a timed submission
 
     A, t, c, _ = est.get_transform()
     row = multi_gpu.pack_result(rank, True, it, A, t, c, est.weighted_error(), est.RMS_error())
@@ -338,6 +341,9 @@ def main():
     if rank == 0:
         total_pairs = args.steps * n_pairs_step * world
         value = total_pairs / dt
+        # a timed submission = one event pair around the launch(es) serving BOTH directions; launches counts directions.
+        # The figure includes the markers' own cost (an empty pair alone reads event_pair_ms; part of that overlaps the
+        # kernel, so it is reported, not subtracted): rocprofv3's kernel duration is what profiles/ holds beside it.
         k1_ms = match_ms / max(match_launches, 1)
         n_dir = n_pairs_step // 2
         k1_bytes = n_dir * K1_BYTES_PER_PAIR_FIXED + 24.0 * n  # per launch: n_dir queries vs one n-point cloud
@@ -365,10 +371,12 @@ def main():
                        "parallelism": f"{world} independent problem(s), one per GPU; one all_gather of the final transforms"},
             "repetitions": reps, "seconds_all": times, "code_sha": code_stamp(),
             "roofline": {"bound": "hbm",
-                         "kernel": ("K1 find_closest_euclidean at the finest level = k_match_cert2 (certificate pass) + k_match_list2 + "
-                                    "k_match_hard2: every phase handles the forward and the backward search in one launch "
-                                    "(lrr_icp_match_pair); kernel_ms = HIP-event time of the pair / 2 = one direction"
+                         "kernel": ("K1 find_closest_euclidean at the finest level = k_match_cert_inline2 (certificate pass whose wavefronts "
+                                    "also search the few sources that fail it; k_match_cert2 + k_match_list2 + k_match_hard2 while the lists are "
+                                    "long): one launch serves the forward and the backward search (lrr_icp_match_pair); kernel_ms = HIP-event "
+                                    "time of the submission / 2 = one direction (markers included: see event_pair_ms)"
                                     if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
+                         "event_pair_ms": event_pair_ms, "timed_every": k1_sample,
                          "valu_frac": valu_frac,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -66,6 +66,8 @@ int  lrr_icp_timer_stop(lrr_icp_ctx *ctx, double *elapsed_ms);
 /* accumulated device time of the matching kernels since the last reset (HIP events around
  * every K1 launch when profiling is enabled) */
 int  lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_t *launches, int reset);
+/* elapsed time of an EMPTY event pair on the context's stream, mean of `pairs` (the markers' own cost inside a timed submission) */
+int  lrr_icp_event_overhead(lrr_icp_ctx *ctx, int pairs, double *ms_per_pair);
 
 /* K1 at the finest level skips the search of a source whose previous match is provably still its unique
  * nearest neighbour (second-nearest bound + triangle inequality, k_match_cert in lrr_icp.hip): sources seen by

@@ -331,6 +331,10 @@ int lrr_est_set_subset_order(lrr_est *e, int dir, const int64_t *order, int64_t 
 int lrr_est_set_nn_method(lrr_est *e, int m) { return guard([&] { E(e)->set_nn_method(m); }); }
 int lrr_est_find_closest_euclidean(lrr_est *e) { return guard([&] { E(e)->find_closest_euclidean(); }); }
 int lrr_est_one_iteration(lrr_est *e, unsigned it, int *converged) { return guard([&] { bool c = E(e)->one_iteration(it); if (converged) *converged = c ? 1 : 0; }); }
+// `count` iterations numbered from `first`, whatever they report (a benchmark's timed steps: no interpreter between them)
+int lrr_est_iterate(lrr_est *e, unsigned first, unsigned count, int *converged) {
+  return guard([&] { bool c = false; for (unsigned k = 0; k < count; ++k) c = E(e)->one_iteration(first + k); if (converged) *converged = c ? 1 : 0; });
+}
 int lrr_est_run(lrr_est *e, unsigned max_it, unsigned *done, int *converged) { return guard([&] { bool c = E(e)->run(max_it, done, nullptr); if (converged) *converged = c ? 1 : 0; }); }
 // same loop, also counting the matched pairs formed (sum over iterations of the active subset sizes)
 int lrr_est_run_counted(lrr_est *e, unsigned max_it, unsigned *done, int *converged, int64_t *pairs) { return guard([&] { if (pairs) *pairs = 0; bool c = E(e)->run(max_it, done, pairs); if (converged) *converged = c ? 1 : 0; }); }

@@ -153,6 +153,8 @@ struct lrr_icp_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // match-kernel profile (event pairs resolved lazily)
   bool prof = false;
+  unsigned prof_every = 1, prof_tick = 0;
+  int64_t cert_host_seen = 0, cert_host_listed = 0;
   std::vector<hipEvent_t> pe;
   int pe_used = 0;
   double match_ms = 0.0;
@@ -221,6 +223,7 @@ struct lrr_icp_dir {
   // followed read it back (-1: unknown): a short list goes straight to the wave-per-query kernel
   const int *cert_list_count = nullptr;
   int last_list_count = -1;
+  bool cert_inline = false;  // the last search was k_match_cert_inline2: its statistics are added on the host
 };
 
 namespace {
@@ -1028,6 +1031,7 @@ __device__ __forceinline__ float second_bound(double best_d2, double second_d2, 
 // (k_export).
 constexpr int kCertBlock = 256;
 constexpr int kShortList = 4096;  // listed sources up to which the wave-per-query kernel alone serves the list
+constexpr int kInlineList = 512;  // ... up to which the certificate kernel's own wavefronts serve it (k_match_cert_inline2)
 __device__ __forceinline__ void match_cert_body(const BallArgs &A) {
   const int per = (int)gridDim.x >> 3;
   const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
@@ -1172,6 +1176,40 @@ __device__ __forceinline__ void wave_scan_runs(const GridView &g, int (*seg_s)[6
   else second = fmin(fmin(second, l2), l.d);
 }
 
+// One wavefront settles a query that has a previous match: the rows of the ball of that radius (kBallMarginCells
+// wider: what is left out is provably farther than best + margin, second_bound), 64 at a time — exact whatever the
+// ball's size.  b: the nearest target (wave-uniform); second: smallest distance^2 among the others it saw.
+__device__ __forceinline__ void wave_ball_prev(const GridView &g, const GridPoint *to_pt, int (*seg_s)[64], int (*seg_pre)[64], int wv, int lane,
+                                               double yx, double yy, double yz, int prev, Best &b, double &second) {
+  const GridPoint pq = to_pt[prev];
+  b.d = dist2(yx, yy, yz, pq.x, pq.y, pq.z);
+  b.orig = pq.orig;
+  b.canon = prev;
+  const double margin = (double)kBallMarginCells * g.h;
+  double rad = sqrt(b.d) + 2.0 * g.tol + margin;
+  int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
+  int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
+  int nyb = yb - ya + 1, nitems = (zb - za + 1) * nyb;
+  for (int base = 0; base < nitems; base += 64) {
+    int t = base + lane, s0 = 0, e0 = 0;
+    const double bm = sqrt(b.d) + margin, bm2 = bm * bm;
+    if (t < nitems) {
+      int z = za + t / nyb, y = ya + t % nyb;
+      double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
+      double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
+      double dyz2 = gz_ * gz_ + gy_ * gy_;
+      if (dyz2 <= bm2) {
+        double rx = sqrt(bm2 - dyz2) + 2.0 * g.tol;
+        int xa = clampi((int)floor((yx - rx - g.lox) * g.inv_h), 0, g.dx - 1);
+        int xb = clampi((int)floor((yx + rx - g.lox) * g.inv_h), 0, g.dx - 1);
+        int row = (z * g.dy + y) * g.dx;
+        s0 = g.cell_start[row + xa]; e0 = g.cell_start[row + xb + 1];
+      }
+    }
+    wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b, prev, second);
+  }
+}
+
 struct HardArgs {  // one direction of the wave-per-query phase
   GridView g;
   QSrc q;
@@ -1213,38 +1251,8 @@ __device__ __forceinline__ void match_hard_body(const HardArgs &A) {
     int prev = use_prev ? m_to[s] : -1;
     double second = INFINITY;  // smallest distance^2 among the other targets seen (prev branch: certificate bound)
     if (prev >= 0) {
-      const GridPoint pq = A.to_pt[prev];
-      b.d = dist2(yx, yy, yz, pq.x, pq.y, pq.z);
-      b.orig = pq.orig;
-      b.canon = prev;
-      // the ball is searched kBallMarginCells wider than the best distance: what is left out is provably
-      // farther than best + margin (second_bound)
-      const double margin = (double)kBallMarginCells * g.h;
-      double rad = sqrt(b.d) + 2.0 * g.tol + margin;
-      int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
-      int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
-      int nyb = yb - ya + 1, nitems = (zb - za + 1) * nyb;
-      {  // the rows of the ball, 64 at a time: exact whatever its size, so a query with a previous match never overflows
-        for (int base = 0; base < nitems; base += 64) {
-          int t = base + lane, s0 = 0, e0 = 0;
-          const double bm = sqrt(b.d) + margin, bm2 = bm * bm;
-          if (t < nitems) {
-            int z = za + t / nyb, y = ya + t % nyb;
-            double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
-            double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
-            double dyz2 = gz_ * gz_ + gy_ * gy_;
-            if (dyz2 <= bm2) {
-              double rx = sqrt(bm2 - dyz2) + 2.0 * g.tol;
-              int xa = clampi((int)floor((yx - rx - g.lox) * g.inv_h), 0, g.dx - 1);
-              int xb = clampi((int)floor((yx + rx - g.lox) * g.inv_h), 0, g.dx - 1);
-              int row = (z * g.dy + y) * g.dx;
-              s0 = g.cell_start[row + xa]; e0 = g.cell_start[row + xb + 1];
-            }
-          }
-          wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b, prev, second);
-        }
-        done = true;
-      }
+      wave_ball_prev(g, A.to_pt, seg_s, seg_pre, wv, lane, yx, yy, yz, prev, b, second);
+      done = true;
       if (lane == 0 && A.d2lb) A.d2lb[s] = second_bound(b.d, second, g.h);
     }
     for (int r = 0; r <= kRingMax && !done; ++r) {
@@ -1295,6 +1303,62 @@ __global__ __launch_bounds__(kBlock) void k_match_hard(HardArgs A) { match_hard_
 __global__ __launch_bounds__(kBlock) void k_match_hard2(HardArgs A, HardArgs B) {
   if (blockIdx.y == 0) match_hard_body(A);
   else match_hard_body(B);
+}
+
+// The certificate kernel with the search inside: near convergence a few dozen of some hundred thousand sources fail the
+// certificate, and a kernel of its own for them costs several microseconds of launch, ramp and drain for microseconds of
+// work.  Here the wavefront that finds failing sources settles them itself, one after the other, all 64 lanes on one
+// query (wave_ball_prev: the search of the wave-per-query kernel, same result).  Used while the lists stay short
+// (lrr_icp_match_pair decides from the previous search's count); list_count still counts the failures.
+__device__ __forceinline__ void match_cert_inline_body(const BallArgs &A) {
+  __shared__ int seg_s[kCertBlock / 64][64], seg_pre[kCertBlock / 64][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int per = (int)gridDim.x >> 3;
+  const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int s = lblock * kCertBlock + threadIdx.x;
+  bool fail = false;
+  int prev = -1;
+  double yx = 0.0, yy = 0.0, yz = 0.0;
+  if (s < A.nsrc) {
+    const SrcPoint sp = A.src[s];
+    prev = A.m_to[s];
+    const float L = A.d2lb[s];
+    A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+    map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
+    fail = true;
+    if (prev >= 0 && L > 0.0f) {
+      const GridPoint q = A.to_pt[prev];
+      double ox, oy, oz;
+      map_loc(A.xf_prev, sp.x, sp.y, sp.z, ox, oy, oz);
+      const double u = sqrt(dist2(yx, yy, yz, ox, oy, oz));
+      const double d1 = sqrt(dist2(yx, yy, yz, q.x, q.y, q.z));
+      if ((d1 + u) * (1.0 + 1e-7) < (double)L) {
+        A.d2lb[s] = __double2float_rd(((double)L - u) * (1.0 - 1e-7));
+        fail = false;
+      }
+    }
+  }
+  unsigned long long todo = __ballot(fail);
+  if (todo == 0ull) return;
+  if (lane == 0) atomicAdd(A.list_count, (int)__popcll(todo));
+  while (todo) {
+    const int l = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const int qs = __shfl(s, l, 64), qprev = __shfl(prev, l, 64);
+    const double qx = __shfl(yx, l, 64), qy = __shfl(yy, l, 64), qz = __shfl(yz, l, 64);
+    if (qprev < 0) {  // (no source is without a match once bounds exist; kept for completeness: the wave-per-query kernel's list)
+      if (lane == 0) { A.hard[atomicAdd(A.hard_count, 1)] = qs; A.d2lb[qs] = 0.0f; }
+      continue;
+    }
+    Best b;
+    double second = INFINITY;
+    wave_ball_prev(A.g, A.to_pt, seg_s, seg_pre, wv, lane, qx, qy, qz, qprev, b, second);
+    if (lane == 0) { A.m_to[qs] = b.canon; A.d2lb[qs] = second_bound(b.d, second, A.g.h); }
+  }
+}
+__global__ __launch_bounds__(kCertBlock) void k_match_cert_inline2(BallArgs A, BallArgs B) {
+  if (blockIdx.y == 0) match_cert_inline_body(A);
+  else match_cert_inline_body(B);
 }
 
 // K1 phase 3: brute force for the (rare) queries still open after kRingMax rings: one block each
@@ -2233,6 +2297,14 @@ __global__ __launch_bounds__(kWide) void k_f_residual(DirArgs F, DirArgs B, int 
 __global__ __launch_bounds__(kWide) void k_f_radii(DirArgs F, int nbF, const double *P1, const double *P2,
                                                     int nbT, const double *to_rec, int nt, double *P3,
                                                     double *SC) {
+  // the first source and the first target of this thread travel while the prologue reduces the partial rows (for lists
+  // up to gridDim.x * kWide entries that is all of them)
+  const int first = blockIdx.x * kWide + threadIdx.x, step = gridDim.x * kWide;
+  int sl0 = -1;
+  unsigned fl0 = F.gen - 1u;
+  double p0 = 0.0, p1 = 0.0, p2 = 0.0, t0 = 0.0, t1 = 0.0, t2 = 0.0;
+  if (first < F.ps.nsrc) { sl0 = F.ps.slot[first]; load_from(F.ps, first, p0, p1, p2); }
+  if (first < nt) { fl0 = F.flag[first]; const double *q = to_rec + (size_t)first * kRecStride; t0 = q[0]; t1 = q[1]; t2 = q[2]; }
   double cm[3], cf[3];
   double tot[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // from-sums (3), distinct-to sums (3) and their count
   if ((int)threadIdx.x < nbF)  // at most kWideBlocks rows each: one per thread
@@ -2247,14 +2319,21 @@ __global__ __launch_bounds__(kWide) void k_f_radii(DirArgs F, int nbF, const dou
     SC[SC_ND] = nd;
   }
   double acc[2] = {0.0, 0.0};
-  for (int s = blockIdx.x * kWide + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kWide) {
+  if (sl0 >= 0) {
+    p0 -= cm[0]; p1 -= cm[1]; p2 -= cm[2];
+    acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
+  }
+  if (fl0 == F.gen) {
+    t0 -= cf[0]; t1 -= cf[1]; t2 -= cf[2];
+    acc[1] += sqrt((t0 * t0 + t1 * t1) + t2 * t2);
+  }
+  for (int s = first + step; s < F.ps.nsrc; s += step) {
     if (F.ps.slot[s] < 0) continue;
-    double p0, p1, p2;
     load_from(F.ps, s, p0, p1, p2);
     p0 -= cm[0]; p1 -= cm[1]; p2 -= cm[2];
     acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
   }
-  for (int j = blockIdx.x * kWide + threadIdx.x; j < nt; j += gridDim.x * kWide) {
+  for (int j = first + step; j < nt; j += step) {
     if (F.flag[j] == F.gen) {
       const double *q = to_rec + (size_t)j * kRecStride;
       double q0 = q[0] - cf[0], q1 = q[1] - cf[1], q2 = q[2] - cf[2];
@@ -2290,6 +2369,23 @@ __device__ __forceinline__ NormD norm_from_scalars(const double *SC, bool flippe
 // picks the exact rank among the gathered keys.  Used when the scales moved little over the last iterations (the host
 // decides); a window that misses the rank or overflows falls back to the full select inside the final kernel.
 struct FoldArgs { const double *prev, *win; unsigned long long *coll; int *cursor; double *P5; };
+// the streams of one batch of k_f_weights (slot -2: beyond the list)
+__device__ __forceinline__ void weights_load_batch(const DirArgs &D, bool clone, int s0, int stride, int (&sl)[kStreamBatch],
+                                                   double (&r2v)[kStreamBatch], double (&gv)[kStreamBatch], double (&ql)[kStreamBatch][3]) {
+#pragma unroll
+  for (int u = 0; u < kStreamBatch; ++u) {
+    const int s = s0 + u * stride;
+    sl[u] = -2; r2v[u] = 0.0; gv[u] = 0.0; ql[u][0] = ql[u][1] = ql[u][2] = 0.0;
+    if (s < D.ps.nsrc) {
+      sl[u] = D.ps.slot[s]; r2v[u] = D.r2[s]; gv[u] = D.key_g[s];
+      double a, b, c;
+      if (clone) load_from(D.ps, s, a, b, c);
+      else { const double *q = D.q_loc + 3 * (size_t)s; a = q[0]; b = q[1]; c = q[2]; }
+      ql[u][0] = a; ql[u][1] = b; ql[u][2] = c;
+    }
+  }
+}
+
 template <bool FOLD>
 __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
                                                       const double *P1, const double *P3, int nb3,
@@ -2301,33 +2397,22 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
   const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
   const int r0 = isF ? 0 : nbF, r1 = isF ? nbF : nbF + nbB;
   const int mode = isF ? o.mode_f : o.mode_b;
-  double tot[4] = {0.0, 0.0, 0.0, 0.0};  // S, W of this list's residuals; radius sums of both clouds
-  // (at most kWideBlocks rows: one per thread, no loop to unroll)
-  if (mode == LRR_ICP_SCALE_RMS && r0 + (int)threadIdx.x < r1) { const int b = r0 + threadIdx.x; tot[0] = P1[(size_t)b * 5]; tot[1] = P1[(size_t)b * 5 + 1]; }
-  if (o.normalize && (int)threadIdx.x < nb3) { const int b = threadIdx.x; tot[2] = P3[(size_t)b * 2]; tot[3] = P3[(size_t)b * 2 + 1]; }
-  block_sum_all<4, kWide / 64>(tot);
-  const double scale = mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : (isF ? o.inj_f : o.inj_b);
-  __shared__ double sc_norm[8];
-  if (o.normalize) {
-    double rm = tot[2] / (double)F.n;
-    double rf = tot[3] / SC[SC_ND];
-    if (threadIdx.x == 0) {
-      for (int k = 0; k < 3; ++k) { sc_norm[k] = SC[SC_CM + k]; sc_norm[4 + k] = SC[SC_CF + k]; }
-      sc_norm[3] = rm; sc_norm[7] = rf;
-      if (blockIdx.x == 0) { SC[SC_RM] = rm; SC[SC_RF] = rf; }
-    }
-  } else if (threadIdx.x == 0) {
-    for (int k = 0; k < 8; ++k) sc_norm[k] = (k == 3 || k == 7) ? 1.0 : 0.0;
-    if (blockIdx.x == 0) for (int k = 0; k < 8; ++k) SC[k] = sc_norm[k];
-  }
-  if (lb == 0 && threadIdx.x == 0) SC[isF ? SC_SIGF : SC_SIGB] = scale;
-  __syncthreads();
-  NormD nm = norm_from_scalars(sc_norm, !isF);
   const bool clone = !o.rrl && !isF;                 // cdcl: backward matches enter as role-reversed clones
-  const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
-  double *wdst = clone ? D.wc : D.w;
-  const double scale2 = scale * scale;
-  double acc[1] = {0.0};
+  // Every load that does not depend on the block sums below is issued first — the scalars earlier kernels left, the
+  // selection windows, and the first batch of this thread's sources — so that they travel while the prologue reduces
+  // the producers' partial rows: one memory round trip less on the kernel's critical path.
+  constexpr int U = kStreamBatch;
+  const int stride = nb * kWide;
+  int sl[U];
+  double r2v[U], gv[U], ql[U][3];
+  const int s_first = lb * kWide + threadIdx.x;
+  if (s_first < D.ps.nsrc) weights_load_batch(D, clone, s_first, stride, sl, r2v, gv, ql);
+  double sc_in[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0};  // cm, cf, nd as k_f_radii left them
+  if (o.normalize) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { sc_in[k] = SC[SC_CM + k]; sc_in[3 + k] = SC[SC_CF + k]; }
+    sc_in[6] = SC[SC_ND];
+  }
   // folded selection: jobs and windows of this list (slots as in lrr_icp_estimate_symmetric: rrl {F.g, B.g, F.s, B.s}; cdcl {g, s})
   const int jg = o.rrl ? (isF ? 0 : 1) : 0, js = o.rrl ? (isF ? 2 : 3) : 1;
   double lo_g = INFINITY, hi_g = INFINITY, lo_s = INFINITY, hi_s = INFINITY, below[2] = {0.0, 0.0};
@@ -2337,23 +2422,28 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
     if (vg > 0.0 && vg < INFINITY) { lo_g = vg * (1.0 - dg); hi_g = vg * (1.0 + dg); }
     if (vs > 0.0 && vs < INFINITY) { lo_s = vs * (1.0 - ds); hi_s = vs * (1.0 + ds); }
     if (threadIdx.x < 2) nstage[threadIdx.x] = 0;
-    __syncthreads();
   }
-  constexpr int U = kStreamBatch;
-  const int stride = nb * kWide;
-  for (int s0 = lb * kWide + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
-    int sl[U];
-    double r2v[U], gv[U], ql[U][3];
+  double tot[4] = {0.0, 0.0, 0.0, 0.0};  // S, W of this list's residuals; radius sums of both clouds
+  // (at most kWideBlocks rows: one per thread, no loop to unroll)
+  if (mode == LRR_ICP_SCALE_RMS && r0 + (int)threadIdx.x < r1) { const int b = r0 + threadIdx.x; tot[0] = P1[(size_t)b * 5]; tot[1] = P1[(size_t)b * 5 + 1]; }
+  if (o.normalize && (int)threadIdx.x < nb3) { const int b = threadIdx.x; tot[2] = P3[(size_t)b * 2]; tot[3] = P3[(size_t)b * 2 + 1]; }
+  block_sum_all<4, kWide / 64>(tot);  // (its barriers also publish nstage)
+  const double scale = mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : (isF ? o.inj_f : o.inj_b);
+  const double rm = o.normalize ? tot[2] / (double)F.n : 1.0, rf = o.normalize ? tot[3] / sc_in[6] : 1.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (o.normalize) { SC[SC_RM] = rm; SC[SC_RF] = rf; }
+    else for (int k = 0; k < 8; ++k) SC[k] = (k == 3 || k == 7) ? 1.0 : 0.0;
+  }
+  if (lb == 0 && threadIdx.x == 0) SC[isF ? SC_SIGF : SC_SIGB] = scale;
+  NormD nm;  // backward list: flipped centres and radii (rrl sym .txx:719-720)
 #pragma unroll
-    for (int u = 0; u < U; ++u) {  // all loads of the batch first: one memory round trip
-      const int s = s0 + u * stride;
-      sl[u] = -2; r2v[u] = 0.0; gv[u] = 0.0; ql[u][0] = ql[u][1] = ql[u][2] = 0.0;
-      if (s < D.ps.nsrc) {
-        sl[u] = D.ps.slot[s]; r2v[u] = D.r2[s]; gv[u] = D.key_g[s];
-        if (clone) load_from(D.ps, s, ql[u][0], ql[u][1], ql[u][2]);
-        else { const double *q = D.q_loc + 3 * (size_t)s; ql[u][0] = q[0]; ql[u][1] = q[1]; ql[u][2] = q[2]; }
-      }
-    }
+  for (int k = 0; k < 3; ++k) { nm.cm[k] = isF ? sc_in[k] : sc_in[3 + k]; nm.cf[k] = isF ? sc_in[3 + k] : sc_in[k]; }
+  nm.rm = isF ? rm : rf; nm.rf = isF ? rf : rm;
+  const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
+  double *wdst = clone ? D.wc : D.w;
+  const double scale2 = scale * scale;
+  double acc[1] = {0.0};
+  for (int s0 = s_first; s0 < D.ps.nsrc;) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int s = s0 + u * stride;
@@ -2389,6 +2479,8 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
       }
       wdst[s] = wi;
     }
+    s0 += U * stride;
+    if (s0 < D.ps.nsrc) weights_load_batch(D, clone, s0, stride, sl, r2v, gv, ql);
   }
   block_reduce_store<1, kWide / 64>(acc, P4);
   if (FOLD) {
@@ -2625,37 +2717,24 @@ __global__ __launch_bounds__(kBlock, 2) void k_f_accumulate_kron(DirArgs F, DirA
   for (int k = 0; k < kKron; ++k) acc[k] = 0.0;
   const int stride = nb * kBlock;
   for (int s0 = lb * kBlock + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
-    int mt[U];
-    double wi[U];
+    // two memory round trips per batch: the streams (list position, weight, spatial key, match), then the locations
+    // and the projector — fetched for every listed source, before its final weight says whether the pair counts
+    int sl[U], mt[U];
+    double wv[U], ks[U], wi[U];
     bool on[U];
-    {
-      int sl[U];
-      double wv[U], ks[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int s = s0 + u * stride;
-        const bool in = s < D.ps.nsrc;
-        sl[u] = in ? D.ps.slot[s] : -1;
-        wv[u] = in ? wbuf[s] : 0.0;
-        ks[u] = in ? D.key_s[s] : 0.0;
-        mt[u] = in ? D.ps.m_to[s] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        on[u] = sl[u] >= 0;
-        double v = wv[u];
-        if (strength) v = v * fg;
-        v = v * ks[u];
-        v = v * fs;
-        wi[u] = v;
-        if (on[u]) wbuf[s0 + u * stride] = v;
-        if (PREMUL && v < 1e-4) on[u] = false;
-      }
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * stride;
+      const bool in = s < D.ps.nsrc;
+      sl[u] = in ? D.ps.slot[s] : -1;
+      wv[u] = in ? wbuf[s] : 0.0;
+      ks[u] = in ? D.key_s[s] : 0.0;
+      mt[u] = in ? D.ps.m_to[s] : 0;
     }
     double pl[U][3], ql[U][3], Pq[U][6];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
+      if (sl[u] < 0) continue;
       const int s = s0 + u * stride;
       load_from(D.ps, s, pl[u][0], pl[u][1], pl[u][2]);
       const double *qr = D.q_loc + 3 * (size_t)s;  // cached by F1: the backward list needs no gather at all
@@ -2663,6 +2742,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_f_accumulate_kron(DirArgs F, DirA
       const double *pr = prec + (size_t)(isF ? mt[u] : s) * kRecStride;
 #pragma unroll
       for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      on[u] = sl[u] >= 0;
+      double v = wv[u];
+      if (strength) v = v * fg;
+      v = v * ks[u];
+      v = v * fs;
+      wi[u] = v;
+      if (on[u]) wbuf[s0 + u * stride] = v;
+      if (PREMUL && v < 1e-4) on[u] = false;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -3399,7 +3489,8 @@ struct ProfScope {  // HIP events around K1 submissions (all phases), recorded o
   int launches;
   bool on;
   ProfScope(lrr_icp_ctx *c, hipStream_t stream, int n_launches)
-      : ctx(c), st(stream), launches(n_launches), on(n_launches > 0 && c->prof && c->pe_used + 2 <= (int)c->pe.size()) {
+      : ctx(c), st(stream), launches(n_launches),
+        on(n_launches > 0 && c->prof && c->pe_used + 2 <= (int)c->pe.size() && (c->prof_tick++ % c->prof_every) == 0) {
     if (on) (void)hipEventRecord(ctx->pe[ctx->pe_used], st);
   }
   ~ProfScope() {
@@ -3417,6 +3508,15 @@ int resolve_profile(lrr_icp_ctx *ctx) {
   }
   ctx->pe_used = 0;
   return LRR_ICP_OK;
+}
+
+// certificate statistics of a search whose kernel had no wave-per-query kernel behind it to add them on the device
+void note_inline_cert(lrr_icp_ctx *ctx, lrr_icp_dir *d) {
+  if (!d->cert_inline) return;
+  d->cert_inline = false;
+  if (!ctx->prof || d->last_list_count < 0) return;
+  ctx->cert_host_seen += d->from->n;
+  ctx->cert_host_listed += d->last_list_count;
 }
 
 DirArgs dir_args(lrr_icp_dir *d) {
@@ -3554,6 +3654,29 @@ int lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_
     for (auto &ev : ctx->pe) HIPCHK(ctx, hipEventCreate(&ev));
   }
   ctx->prof = enable != 0;
+  ctx->prof_every = enable > 1 ? (unsigned)enable : 1u;  // enable = N > 1: every N-th submission is timed (two event records cost a few us)
+  ctx->prof_tick = 0;
+  return LRR_ICP_OK;
+}
+
+// what a pair of event records with NOTHING between them measures on the context's stream (the two marker packets
+// themselves): the part of a timed K1 submission that is not kernel time
+int lrr_icp_event_overhead(lrr_icp_ctx *ctx, int pairs, double *ms_per_pair) {
+  if (!ctx || pairs <= 0 || !ms_per_pair) return LRR_ICP_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<hipEvent_t> ev(2 * (size_t)pairs);
+  for (auto &e : ev) HIPCHK(ctx, hipEventCreate(&e));
+  for (int i = 0; i < pairs; ++i) {
+    // a trivial launch in front, as in the timed loop where other kernels precede the submission
+    hipLaunchKernelGGL(k_copy_w, dim3(1), dim3(64), 0, ctx->stream, (const double *)ctx->d_final, ctx->d_final, 0);
+    (void)hipEventRecord(ev[2 * i], ctx->stream);
+    (void)hipEventRecord(ev[2 * i + 1], ctx->stream);
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  for (int i = 0; i < pairs; ++i) { float ms = 0.f; HIPCHK(ctx, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tot += ms; }
+  for (auto &e : ev) (void)hipEventDestroy(e);
+  *ms_per_pair = tot / pairs;
   return LRR_ICP_OK;
 }
 
@@ -3563,9 +3686,9 @@ int lrr_icp_cert_stats(lrr_icp_ctx *ctx, int64_t *queries, int64_t *searched, in
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   unsigned long long v[2] = {0, 0};
   HIPCHK(ctx, hipMemcpy(v, ctx->d_cert_stats, sizeof v, hipMemcpyDeviceToHost));
-  if (queries) *queries = (int64_t)v[0];
-  if (searched) *searched = (int64_t)v[1];
-  if (reset) HIPCHK(ctx, hipMemset(ctx->d_cert_stats, 0, sizeof v));
+  if (queries) *queries = (int64_t)v[0] + ctx->cert_host_seen;
+  if (searched) *searched = (int64_t)v[1] + ctx->cert_host_listed;
+  if (reset) { HIPCHK(ctx, hipMemset(ctx->d_cert_stats, 0, sizeof v)); ctx->cert_host_seen = ctx->cert_host_listed = 0; }
   return LRR_ICP_OK;
 }
 
@@ -3882,6 +4005,7 @@ struct MatchPrep {
   bool voronoi = false;   // Voronoi-lookup semantics: searches the to-cloud's site cloud with voxel-rounded queries
   bool cert = false;      // finest level with second-nearest bounds from the previous search: certificate kernel
   bool short_list = false;  // ... whose list was short last time: the listed sources go straight to the wave-per-query kernel
+  bool inline_list = false; // ... or very short: the certificate kernel searches them itself
   lrr_icp_xform prev_xf;  // transform of that search
   int method = LRR_ICP_NN_GRID;
 };
@@ -3957,6 +4081,8 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   d->slot_lazy = P.cert;
   if (P.cert) { for (int r = 0; r < 4; ++r) d->slot_keys[r] = P.kk.k[r]; d->slot_half = P.half; }
   P.short_list = P.cert && d->last_list_count >= 0 && d->last_list_count <= kShortList;
+  P.inline_list = P.cert && d->last_list_count >= 0 && d->last_list_count <= kInlineList;
+  d->cert_inline = false;
   d->cert_list_count = P.cert ? P.counts + 2 : nullptr;
   d->last_list_count = -1;
   return LRR_ICP_OK;
@@ -4059,6 +4185,15 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     if (Pf.steady && Pb.steady) {
       ProfScope prof(ctx, st, 2);
       BallArgs af = ball_args(f, Pf, ctx->lane[0]), ab = ball_args(b, Pb, ctx->lane[1]);
+      // lists of a few hundred sources at most (as the previous search of each direction counted them): the certificate
+      // kernel settles its failures itself — K1 is this one launch
+      static const bool no_inline = std::getenv("LRR_ICP_NO_INLINE_CERT") != nullptr;
+      if (Pf.cert && Pb.cert && Pf.inline_list && Pb.inline_list && !no_inline) {
+        hipLaunchKernelGGL(k_match_cert_inline2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
+        HIPCHK(ctx, hipGetLastError());
+        f->cert_inline = b->cert_inline = true;  // the host adds this search to the certificate statistics when it learns the counts
+        return LRR_ICP_OK;
+      }
       if (Pf.cert && Pb.cert) {
         hipLaunchKernelGGL(k_match_cert2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
         HIPCHK(ctx, hipGetLastError());
@@ -4573,6 +4708,8 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   const double *h = ctx->h_fused;
   if (F->cert_list_count) F->last_list_count = (int)h[FIN_OFF + K];
   if (B->cert_list_count) B->last_list_count = (int)h[FIN_OFF + K + 1];
+  note_inline_cert(ctx, F);
+  note_inline_cert(ctx, B);
   F->cert_list_count = B->cert_list_count = nullptr;  // the counter slots are recycled
   for (int k = 0; k < 3; ++k) { out->norm.cm[k] = h[SC_CM + k]; out->norm.cf[k] = h[SC_CF + k]; }
   out->norm.rm = h[SC_RM]; out->norm.rf = h[SC_RF];
@@ -4759,6 +4896,7 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   { int rc = wait_results(ctx, seq); if (rc) return rc; }
   const double *h = ctx->h_fused;
   if (F->cert_list_count) F->last_list_count = (int)h[FIN_OFF + K];
+  note_inline_cert(ctx, F);
   F->cert_list_count = nullptr;
   for (int k = 0; k < 3; ++k) { out->norm.cm[k] = h[SC_CM + k]; out->norm.cf[k] = h[SC_CF + k]; }
   out->norm.rm = h[SC_RM]; out->norm.rf = h[SC_RF];

@@ -25,7 +25,7 @@ _ip = C.POINTER(C.c_int64)
 # every symbol include/lrr_icp.h declares
 ICP_SYMBOLS = [
     "lrr_icp_create", "lrr_icp_destroy", "lrr_icp_last_error", "lrr_icp_synchronize",
-    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile", "lrr_icp_cert_stats",
+    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile", "lrr_icp_event_overhead", "lrr_icp_cert_stats",
     "lrr_icp_cloud_create", "lrr_icp_cloud_destroy", "lrr_icp_cloud_size", "lrr_icp_cloud_build_voronoi",
     "lrr_icp_dir_create", "lrr_icp_dir_destroy", "lrr_icp_dir_set_from", "lrr_icp_dir_num_matches",
     "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
@@ -73,6 +73,7 @@ def hip_lib() -> C.CDLL:
         L.lrr_icp_timer_start.argtypes = [C.c_void_p]
         L.lrr_icp_timer_stop.argtypes = [C.c_void_p, _dp]
         L.lrr_icp_match_profile.argtypes = [C.c_void_p, C.c_int, _dp, _ip, C.c_int]
+        L.lrr_icp_event_overhead.argtypes = [C.c_void_p, C.c_int, _dp]
         L.lrr_icp_cert_stats.argtypes = [C.c_void_p, _ip, _ip, C.c_int]
         L.lrr_icp_cloud_create.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, _dp, C.c_int, C.POINTER(C.c_void_p)]
         L.lrr_icp_cloud_destroy.argtypes = [C.c_void_p]
@@ -116,6 +117,7 @@ def est_lib() -> C.CDLL:
         L.lrr_est_set_nn_method.argtypes = [C.c_void_p, C.c_int]
         L.lrr_est_find_closest_euclidean.argtypes = [C.c_void_p]
         L.lrr_est_one_iteration.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
+        L.lrr_est_iterate.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_int)]
         L.lrr_est_run.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
         L.lrr_est_run_counted.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_int), _ip]
         L.lrr_est_set_subset_seed.argtypes = [C.c_void_p, C.c_uint64]
@@ -198,6 +200,13 @@ class DeviceTimer:
         if self.L.lrr_icp_match_profile(self.ctx, int(enable), C.byref(ms), C.byref(n), int(reset)) != 0:
             raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
         return ms.value, n.value
+
+    def event_overhead(self, pairs=64):
+        """mean elapsed ms of an empty HIP-event pair on the context's stream"""
+        ms = C.c_double(0.0)
+        if self.L.lrr_icp_event_overhead(self.ctx, int(pairs), C.byref(ms)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+        return ms.value
 
     def synchronize(self):
         self.L.lrr_icp_synchronize(self.ctx)
@@ -346,6 +355,12 @@ class Estimator:
     def one_iteration(self, iteration=0):
         conv = C.c_int(0)
         self._ck(est_lib().lrr_est_one_iteration(self._h, iteration, C.byref(conv)))
+        return bool(conv.value)
+
+    def iterate(self, first, count):
+        """`count` iterations numbered from `first` in one call; returns what the last one reported"""
+        conv = C.c_int(0)
+        self._ck(est_lib().lrr_est_iterate(self._h, int(first), int(count), C.byref(conv)))
         return bool(conv.value)
 
     def run(self, max_iterations=30):
