@@ -14,8 +14,14 @@
 #define LRR_AMD_LOCATION_BATCH_H_
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "lrr_amd/icp_engine.h"
@@ -117,6 +123,78 @@ inline double sampled_transfer_max_trace(cdcl_trans<3, 12>::sptr const &T, vnl_v
   return maxTrace;
 }
 
+// The per-location host work of a lockstep iteration (solve, inverse, un-normalise: a couple of microseconds each,
+// independent across locations) spread over a few sleeping worker threads: parallel_for(n, f) runs f(i) for every i
+// exactly once, in chunks handed out through an atomic counter, the caller working along.  Workers block on a
+// condition variable between calls (no spinning: the device runtime's own threads share the cores).
+// LRR_BATCH_THREADS sets the number of workers (default: up to 6, fewer on small machines; 0 = caller only).
+class host_workers {
+ public:
+  host_workers() : stop_(false), generation_(0), n_(0), chunk_(1), next_(0), pending_(0) {
+    unsigned want = 6;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && hw / 2 < want + 1) want = hw / 2 > 0 ? hw / 2 - 1 : 0;
+    if (const char *e = std::getenv("LRR_BATCH_THREADS")) want = (unsigned)std::max(0, std::atoi(e));
+    for (unsigned t = 0; t < want; ++t) threads_.emplace_back([this] { work(); });
+  }
+  ~host_workers() {
+    { std::lock_guard<std::mutex> g(m_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+  host_workers(const host_workers &) = delete;
+  host_workers &operator=(const host_workers &) = delete;
+  template <class F> void parallel_for(size_t n, F f) {
+    if (threads_.empty() || n < 32) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    fn_ = [&f](size_t i) { f(i); };
+    {
+      std::lock_guard<std::mutex> g(m_);
+      n_ = n;
+      chunk_ = std::max<size_t>(4, n / (8 * (threads_.size() + 1)));
+      next_.store(0);
+      pending_ = threads_.size();
+      ++generation_;
+    }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return pending_ == 0; });
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const size_t b = next_.fetch_add(chunk_);
+      if (b >= n_) return;
+      const size_t e = std::min(n_, b + chunk_);
+      for (size_t i = b; i < e; ++i) fn_(i);
+    }
+  }
+  void work() {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+      }
+      drain();
+      std::lock_guard<std::mutex> g(m_);
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  bool stop_;
+  unsigned long generation_;
+  std::function<void(size_t)> fn_;
+  size_t n_, chunk_;
+  std::atomic<size_t> next_;
+  size_t pending_;
+};
+
 template <class FeatureT = cdcl_feature_ICP<3> >
 class rrl_location_batch {
  public:
@@ -207,14 +285,14 @@ class rrl_location_batch {
       check(lrr_icp_batch_estimate(batch_, loc.data(), &opts, est.data()), "batch estimate");
       tm.lap("estimate");
       // the host half of estimate_LS
-      for (long b = 0; b < (long)B; ++b) {
-        state &s = st[(size_t)b];
-        if (!s.running) continue;
+      workers_.parallel_for(B, [&](size_t b) {
+        state &s = st[b];
+        if (!s.running) return;
         s.scale_estimated[0] = s.scale_estimated[1] = true;
-        forward_update(s.F, est[(size_t)b]);
+        forward_update(s.F, est[b]);
         s.B = s.F->inverse();
-        fill_loc(loc[(size_t)b], s);
-      }
+        fill_loc(loc[b], s);
+      });
       tm.lap("solve");
       check(lrr_icp_batch_errors(batch_, loc.data(), sums.data()), "batch error metrics");
       tm.lap("errors");
@@ -365,16 +443,16 @@ class rrl_location_batch {
     for (size_t b = 0; b < B; ++b)
       if (loc[b].active) { loc[b].scale_mode_f = loc[b].scale_mode_b = LRR_ICP_SCALE_RMS; }
     check(lrr_icp_batch_estimate(batch_, loc.data(), &opts, est.data()), "batch backward estimate");
-    for (size_t b = 0; b < B; ++b)
-      if (loc[b].active) {
-        symmetric_apply_solution<dof>(st[b].B, st[b].F, est[b], true, false);
-        fill_loc(loc[b], st[b]);
-      }
+    workers_.parallel_for(B, [&](size_t b) {
+      if (!loc[b].active) return;
+      symmetric_apply_solution<dof>(st[b].B, st[b].F, est[b], true, false);
+      fill_loc(loc[b], st[b]);
+    });
     check(lrr_icp_batch_angles(batch_, loc.data(), sums.data()), "batch angles");
     std::vector<double> esums(6 * B);
     check(lrr_icp_batch_errors(batch_, loc.data(), esums.data()), "batch error metrics");
-    for (size_t b = 0; b < B; ++b) {
-      if (!loc[b].active) continue;
+    workers_.parallel_for(B, [&](size_t b) {
+      if (!loc[b].active) return;
       location_result &r = results[b];
       const double *a = &sums[8 * b + 4], *e = &esums[6 * b + 3];
       r.sheet_angles_backward = a[0] / a[1];
@@ -394,11 +472,12 @@ class rrl_location_batch {
       r.measurements[5] = std::min(maxTrace, maxTraceB);
       r.measurements[6] = std::min(sa, sab);
       r.measurements[7] = std::min(ta, tab);
-    }
+    });
   }
 
   device_cloud<FeatureT> moving_, fixed_;
   lrr_icp_batch *batch_;
+  host_workers workers_;
   unsigned max_iterations_, min_features_;
   bool diagnostics_, check_valid_;
   double voxel_spacing_, sample_interval_;

@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> None:
         subprocess.check_call(cmd)
     if force or not _newer(EST_SO, [EST_SRC, HIP_SO] + hdrs):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + INC,
-               "-o", EST_SO, EST_SRC, "-L" + HERE, "-llrr_icp_hip", "-lz", "-Wl,-rpath,$ORIGIN"]
+               "-pthread", "-o", EST_SO, EST_SRC, "-L" + HERE, "-llrr_icp_hip", "-lz", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
