@@ -3045,6 +3045,53 @@ __global__ __launch_bounds__(kBlock) void k_fw_accumulate(DirArgs F, FwdOpts o, 
   block_reduce_store<NT + DOF>(acc, P6);
 }
 
+// FW3 for 12 degrees of freedom: Kronecker sums (accumulate_pair_kron), two blocks per compute unit
+__global__ __launch_bounds__(kBlock, 2) void k_fw_accumulate_kron(DirArgs F, FwdOpts o, const double *SC, const double *SEL,
+                                                                  double c0, double c1, double c2, int rigid_increment,
+                                                                  double *P6) {
+  constexpr int U = kKronBatch;
+  const NormD nm = norm_from_scalars(SC, false);
+  const double fg = o.strength ? mad_factor(SEL) : 1.0;
+  double acc[kKron];
+#pragma unroll
+  for (int k = 0; k < kKron; ++k) acc[k] = 0.0;
+  const int stride = gridDim.x * kBlock;
+  const int lb = (gridDim.x & 7) == 0 ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  for (int s0 = lb * kBlock + threadIdx.x; s0 < F.ps.nsrc; s0 += U * stride) {
+    int sl[U], mt[U];
+    double wi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * stride;
+      const bool in = s < F.ps.nsrc;
+      sl[u] = in ? F.ps.slot[s] : -1;
+      wi[u] = in ? F.w[s] : 0.0;
+      mt[u] = in ? F.ps.m_to[s] : 0;
+    }
+    double pl[U][3], ql[U][3], Pq[U][6];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (sl[u] < 0) continue;
+      const int s = s0 + u * stride;
+      load_from(F.ps, s, pl[u][0], pl[u][1], pl[u][2]);
+      const double *qc = F.q_loc + 3 * (size_t)s;
+      ql[u][0] = qc[0]; ql[u][1] = qc[1]; ql[u][2] = qc[2];
+      const double *pr = F.ps.to_rec + (size_t)mt[u] * kRecStride;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (sl[u] < 0) continue;
+      if (o.strength) { wi[u] = wi[u] * fg; F.w[s0 + u * stride] = wi[u]; }
+      double p0 = (pl[u][0] - nm.cm[0]) / nm.rm, p1 = (pl[u][1] - nm.cm[1]) / nm.rm, p2 = (pl[u][2] - nm.cm[2]) / nm.rm;
+      double q0 = (ql[u][0] - nm.cf[0]) / nm.rf, q1 = (ql[u][1] - nm.cf[1]) / nm.rf, q2 = (ql[u][2] - nm.cf[2]) / nm.rf;
+      accumulate_pair_kron<false>(acc, wi[u], p0, p1, p2, q0, q1, q2, Pq[u], c0, c1, c2, rigid_increment);
+    }
+  }
+  block_reduce_store<kKron>(acc, P6);
+}
+
 // ---------------------------------------------------------------------------------------------
 // search-grid build on the device (lrr_icp_cloud_create): counting sort of the features by x-slice of
 // their cell (raster order, the search structure) and by (tile, cell) (canonical order), both with
@@ -4883,10 +4930,11 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
     int rc = launch_select_kth(ctx, 1);
     if (rc) return rc;
   }
-  const int nbA = std::min(grid_for(nsF), kAccBlocks);
+  const bool kron = o->dof == 12;
+  const int nbA = std::min(grid_for(nsF), kron ? 2 * kKronBlocks : kAccBlocks);
   const double *c = o->jac_centre;
-  const int nt2 = o->dof * (o->dof + 1) / 2, K = nt2 + o->dof;
-  if (o->dof == 12) hipLaunchKernelGGL((k_fw_accumulate<12>), dim3(nbA), dim3(kBlock), 0, st, aF, fo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
+  const int nt2 = o->dof * (o->dof + 1) / 2, K = kron ? kKron : nt2 + o->dof;
+  if (kron) hipLaunchKernelGGL(k_fw_accumulate_kron, dim3(nbA), dim3(kBlock), 0, st, aF, fo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   else hipLaunchKernelGGL((k_fw_accumulate<6>), dim3(nbA), dim3(kBlock), 0, st, aF, fo, SC, SEL, c[0], c[1], c[2], o->rigid_increment, P6);
   HIPCHK(ctx, hipGetLastError());
   const unsigned long long seq = ++ctx->seq;
@@ -4904,6 +4952,7 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   const double *sl = h + SEL_OFF;
   out->grad_scale[0] = out->grad_scale[1] = (o->strength && sl[3] > 1.0) ? 1.4826 * (1 + 5.0 / (sl[3] - 1.0)) * sl[0] : 0.0;
   out->spatial_scale[0] = out->spatial_scale[1] = 0.0;
+  if (kron) { kron_expand(h + FIN_OFF, out->AtA, out->Atb); return LRR_ICP_OK; }
   int t = 0;
   for (int a = 0; a < o->dof; ++a)
     for (int b = a; b < o->dof; ++b) { out->AtA[a * o->dof + b] = h[FIN_OFF + t]; out->AtA[b * o->dof + a] = h[FIN_OFF + t]; ++t; }
