@@ -145,6 +145,8 @@ struct lrr_icp_ctx {
   double *h_fused = nullptr, *h_fused_dev = nullptr;
   // completion word of the reduce kernels (mapped host memory) and their last-block counter
   unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr, seq = 0;
+  // block rows of k_errors, written by the blocks themselves: kWideBlocks rows of 8 doubles {s0, tag, s1, tag, s2, tag, -, -}
+  double *h_rows = nullptr, *h_rows_dev = nullptr;
   int *d_done = nullptr;
   unsigned long long *d_cert_stats = nullptr;  // {queries, searched} of the certificate kernel
   // K1 scratch: one set per submission lane.  Lane 0 runs on `stream`; lane 1 has its own stream so
@@ -1572,7 +1574,10 @@ __global__ void k_assign(const int *slot, const double *r2, double scale, int ns
 }
 
 // K4 (cdcl .txx:196-268)
-__global__ __launch_bounds__(kWide) void k_errors(PairSrc ps, XfD xf, NormD nm, const double *w, double *partials) {
+// host_rows (may be null): mapped host memory; the block then stores its three sums there itself, each in a 16-byte
+// chunk {sum, tag} written by ONE store instruction, and the host adds the rows (lrr_icp_errors) — no reduction launch
+// behind this kernel.  A chunk is valid once its tag is there: no ordering between stores is relied on.
+__global__ __launch_bounds__(kWide) void k_errors(PairSrc ps, XfD xf, NormD nm, const double *w, double *partials, double *host_rows, double tag) {
   double acc[3] = {0.0, 0.0, 0.0};
   for (int s = xcd_block(blockIdx.x, gridDim.x) * kWide + threadIdx.x; s < ps.nsrc; s += gridDim.x * kWide) {
     if (ps.slot[s] < 0) continue;
@@ -1583,6 +1588,11 @@ __global__ __launch_bounds__(kWide) void k_errors(PairSrc ps, XfD xf, NormD nm, 
     acc[2] += wi;
   }
   block_reduce_store<3, kWide / 64>(acc, partials);
+  if (host_rows && threadIdx.x < 3) {
+    // (the thread that stored partials[3 blockIdx + k] holds that sum: re-read its own store)
+    const double2 chunk = make_double2(partials[(size_t)blockIdx.x * 3 + threadIdx.x], tag);
+    *reinterpret_cast<double2 *>(host_rows + (size_t)blockIdx.x * 8 + 2 * threadIdx.x) = chunk;
+  }
 }
 
 // K5 statistics (cdcl .txx:1175-1213)
@@ -3612,6 +3622,9 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_fused_dev, ctx->h_fused, 0)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_rows, sizeof(double) * 8 * kWideBlocks, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
+  std::memset(ctx->h_rows, 0, sizeof(double) * 8 * kWideBlocks);
+  if ((e = hipHostGetDevicePointer((void **)&ctx->h_rows_dev, ctx->h_rows, 0)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_seq, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
   *ctx->h_seq = 0;
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_seq_dev, ctx->h_seq, 0)) != hipSuccess) return bail(e);
@@ -3659,6 +3672,7 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->h_jobs) (void)hipHostFree(ctx->h_jobs);
   if (ctx->h_fused) (void)hipHostFree(ctx->h_fused);
   if (ctx->h_seq) (void)hipHostFree(ctx->h_seq);
+  if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
   if (ctx->d_done) (void)hipFree(ctx->d_done);
   if (ctx->d_cert_stats) (void)hipFree(ctx->d_cert_stats);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -4634,10 +4648,28 @@ int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, doub
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PairSrc ps = pairs_of(d);
     int nb = grid_wide(ps.nsrc);
-    hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kWide), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, ctx->d_partials);
+    // the blocks write their rows into mapped host memory, tagged with this submission's number; the host adds them in
+    // row order as they arrive (after 50 ms without them: stream synchronisation, which also reports a failed kernel)
+    const unsigned long long seq = ++ctx->seq;
+    const double tag = (double)(seq & 0xfffffffffffffull);  // exact in a double
+    hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kWide), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, ctx->d_partials, ctx->h_rows_dev, tag);
     HIPCHK(ctx, hipGetLastError());
-    int rc = finish_reduce(ctx, nb, 3, r);
-    if (rc) return rc;
+    const volatile double *rows = ctx->h_rows;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    for (int b = 0; b < nb; ++b) {
+      for (int k = 0; k < 3; ++k) {
+        unsigned spin = 0;
+        while (rows[8 * b + 2 * k + 1] != tag) {
+          if ((++spin & 1023u) != 0 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) continue;
+          if (synced) return fail(ctx, LRR_ICP_ERR_HIP, "error sums did not arrive");
+          HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+          synced = true;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        r[k] += rows[8 * b + 2 * k];
+      }
+    }
   }
   if (sum_r2) *sum_r2 = r[0];
   if (sum_wr) *sum_wr = r[1];

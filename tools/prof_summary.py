@@ -38,12 +38,11 @@ def kernels(path, iters):
     acc = [r[0] for r in c.execute("select start from kernels where name like '%k_f_accumulate%' order by start")]
     if len(acc) < iters + 1:
         return
-    first = [r[0] for r in c.execute("select start from kernels where name like '%k_match_ball%' or name like '%k_match_tile%' "
-                                     "or name like '%k_match_direct%' order by start")]
+    first = [r[0] for r in c.execute("select start from kernels where name like '%k_match_%' or name like '%k_slots_%' order by start")]
     t0 = max(t for t in first if t < acc[-iters])  # a search kernel of that iteration ...
     t0 = min(t for t in first if t0 - t < 200_000 and t <= t0)  # ... and the first one of its pair
     rows = c.execute("select name, count(*), avg(end-start), sum(end-start) from kernels where start>=? group by name order by 4 desc", (t0,)).fetchall()
-    span = c.execute("select max(end)-? from kernels", (t0,)).fetchone()[0]
+    span = acc[-1] - acc[-iters - 1]  # accumulate launch to accumulate launch, `iters` iterations apart
     busy = sum(r[3] for r in rows)
     print(f"# last {iters} symmetric iterations: wall {span / iters / 1e3:.1f} us/iteration, sum of kernel durations {busy / iters / 1e3:.1f} us/iteration")
     print("kernel,launches_per_iteration,avg_us,us_per_iteration")
