@@ -204,13 +204,51 @@ inline void solve_normal_equations(typename cdcl_trans<3, dof>::sptr const &T, c
   }
 }
 
+// symmetric_apply_solution(F, B, r, normalize = true, estimate_parameters = true) for an AFFINE forward transform,
+// without the work whose results it overwrites: normalize() only zeroes the centre (its A, t and covariance are
+// replaced by the solution), and the caller replaces the backward transform by inverse(forward) right after.  What
+// remains: C = inverse(AtA), theta = C Atb (normalised coordinates), then unnormalize() (cdcl_trans_affine.txx:259-286):
+// A <- (rf/rm) A, t <- rf t + cf, covar <- D C D with the diagonal D = (rf/rm x 9, rf x 3), centre <- cm.  Same
+// operations in the same order: bit-identical results, without the four dense 12 x 12 products.
+inline void affine_forward_update(cdcl_trans<3, 12>::sptr const &F, const lrr_icp_sym_out &r) {
+  double C[144];
+  linalg::sym_inverse(12, r.AtA, C);
+  const double rm = r.norm.rm, rf = r.norm.rf, f = rf / rm;
+  vnl_vector<double> p(12, 0.0);
+  for (unsigned i = 0; i < 12; ++i) {
+    double s = 0.0;
+    for (unsigned k = 0; k < 12; ++k) s += C[i * 12 + k] * r.Atb[k];
+    p[i] = i < 9 ? s * f : rf * s + r.norm.cf[i - 9];
+  }
+  F->set_parameterization(p);
+  vnl_matrix_fixed<double, 12, 12> cov;
+  for (unsigned i = 0; i < 12; ++i)
+    for (unsigned j = 0; j < 12; ++j) cov(i, j) = ((i < 9 ? f : rf) * C[i * 12 + j]) * (j < 9 ? f : rf);
+  F->set_covariance(cov);
+  for (int d = 0; d < 3; ++d) F->center_moving_[d] = r.norm.cm[d];
+}
+template <unsigned dof> struct affine_shortcut {
+  static bool apply(typename cdcl_trans<3, dof>::sptr const &, const lrr_icp_sym_out &) { return false; }
+};
+template <> struct affine_shortcut<12> {
+  static bool apply(cdcl_trans<3, 12>::sptr const &F, const lrr_icp_sym_out &r) {
+    if (!F->is_type(cdcl_trans_affine<3, 12>::type_id())) return false;
+    affine_forward_update(F, r);
+    return true;
+  }
+};
+
 // Host half of the symmetric estimate_LS once the device has returned the statistics and the normal
 // equations (rrl sym .txx:713-721, 880-912; cdcl sym .txx:470-478, 643-695): normalise both transforms
 // (the backward one with flipped centres and radii), solve, un-normalise, backward = inverse(forward).
 // F / B: the transforms in the forward and the backward ROLE (estimate_LS_backward swaps them).
 template <unsigned dof>
 inline void symmetric_apply_solution(typename cdcl_trans<3, dof>::sptr const &F, typename cdcl_trans<3, dof>::sptr const &B,
-                                     const lrr_icp_sym_out &r, bool normalize, bool estimate_parameters) {
+                                     const lrr_icp_sym_out &r, bool normalize, bool estimate_parameters,
+                                     bool backward_is_replaced = false) {
+  // (the symmetric classes replace the backward transform by inverse(forward) after a parameter estimate: then the
+  // affine forward transform takes the short way)
+  if (normalize && estimate_parameters && backward_is_replaced && affine_shortcut<dof>::apply(F, r)) return;
   vnl_vector_fixed<double, 3> cm(0.0), cf(0.0);
   double rm = 0.0, rf = 0.0;
   if (normalize) {
@@ -841,7 +879,7 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     B.touch();
     for (unsigned i = 0; i < dof * dof; ++i) F.last_AtA_[i] = r.AtA[i];
     for (unsigned i = 0; i < dof; ++i) F.last_Atb_[i] = r.Atb[i];
-    symmetric_apply_solution<dof>(F.trans_, B.trans_, r, normalize_matches_, estimate_parameters);
+    symmetric_apply_solution<dof>(F.trans_, B.trans_, r, normalize_matches_, estimate_parameters, estimate_parameters);
     if (rigid) F.end_rigid_increment(forward_global);
     if (estimate_parameters) B.trans_ = F.trans_->inverse();
   }

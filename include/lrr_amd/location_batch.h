@@ -289,7 +289,7 @@ class rrl_location_batch {
         state &s = st[b];
         if (!s.running) return;
         s.scale_estimated[0] = s.scale_estimated[1] = true;
-        forward_update(s.F, est[b]);
+        affine_forward_update(s.F, est[b]);
         s.B = s.F->inverse();
         fill_loc(loc[b], s);
       });
@@ -392,30 +392,6 @@ class rrl_location_batch {
     L.injected_f = L.injected_b = 0.0;
     // the affine normalize() zeroes the centre before the accumulation (cdcl_trans_affine.txx:252)
     L.jac_centre[0] = L.jac_centre[1] = L.jac_centre[2] = 0.0;
-  }
-
-  // symmetric_apply_solution(F, B, r, normalize = true, estimate_parameters = true) for the affine forward
-  // transform, without the work whose results it overwrites: normalize() only zeroes the centre (its A, t and
-  // covariance are replaced by the solution), the backward transform is replaced by inverse(forward) right
-  // after.  What remains: C = inverse(AtA), theta = C Atb (normalised coordinates), then unnormalize()
-  // (cdcl_trans_affine.txx:259-286): A <- (rf/rm) A, t <- rf t + cf, covar <- D C D with the diagonal
-  // D = (rf/rm x 9, rf x 3), centre <- cm.  Same operations in the same order: bit-identical results.
-  static void forward_update(trans_sptr_type const &F, const lrr_icp_sym_out &r) {
-    double C[144];
-    linalg::sym_inverse(12, r.AtA, C);
-    const double rm = r.norm.rm, rf = r.norm.rf, f = rf / rm;
-    vnl_vector<double> p(12, 0.0);
-    for (unsigned i = 0; i < 12; ++i) {
-      double s = 0.0;
-      for (unsigned k = 0; k < 12; ++k) s += C[i * 12 + k] * r.Atb[k];
-      p[i] = i < 9 ? s * f : rf * s + r.norm.cf[i - 9];
-    }
-    F->set_parameterization(p);
-    vnl_matrix_fixed<double, 12, 12> cov;
-    for (unsigned i = 0; i < 12; ++i)
-      for (unsigned j = 0; j < 12; ++j) cov(i, j) = ((i < 9 ? f : rf) * C[i * 12 + j]) * (j < 9 ? f : rf);
-    F->set_covariance(cov);
-    for (int d = 0; d < 3; ++d) F->center_moving_[d] = r.norm.cm[d];
   }
 
   // ComputeDecisionMeasurements (:1816-1871) of every location that ran: forward angles and error, then
