@@ -1614,14 +1614,15 @@ __global__ void k_mark(const int *slot, const int *m_to, int nsrc, unsigned *fla
   if (s < nsrc && slot[s] >= 0) flag[m_to[s]] = gen;  // benign race: every writer stores the same stamp
 }
 
-__global__ __launch_bounds__(kWide) void k_to_sum(const double *to_rec, const unsigned *flag, unsigned gen, int nt,
+// (to_pt: the compact canonical points, 32 B each, streamed — same coordinates as the 80-B records; stamp and point
+// are loaded together: one memory round trip)
+__global__ __launch_bounds__(kWide) void k_to_sum(const GridPoint *to_pt, const unsigned *flag, unsigned gen, int nt,
                                                    double *partials) {
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   for (int j = blockIdx.x * kWide + threadIdx.x; j < nt; j += gridDim.x * kWide) {
-    if (flag[j] == gen) {
-      const double *q = to_rec + (size_t)j * kRecStride;
-      acc[0] += q[0]; acc[1] += q[1]; acc[2] += q[2]; acc[3] += 1.0;
-    }
+    const unsigned f = flag[j];
+    const GridPoint q = to_pt[j];
+    if (f == gen) { acc[0] += q.x; acc[1] += q.y; acc[2] += q.z; acc[3] += 1.0; }
   }
   block_reduce_store<4, kWide / 64>(acc, partials);
 }
@@ -2241,8 +2242,9 @@ enum { SC_CM = 0, SC_RM = 3, SC_CF = 4, SC_RF = 7, SC_ND = 8, SC_SIGF = 9, SC_SI
 // F1: residuals of both lists (un-normalised coordinates: rrl sym .txx:701-705), sums for the
 // RMS scale, centroid sums and distinct-target marks of the forward list
 __global__ __launch_bounds__(kWide) void k_f_residual(DirArgs F, DirArgs B, int nbF, int nbB, XfD xfF,
-                                                       XfD xfB, NormD ident, int want_stats, double *P1) {
+                                                       XfD xfB, NormD ident, int want_stats, int dist_f, int dist_b, double *P1) {
   const bool isF = (int)blockIdx.x < nbF;
+  const bool want_dist = isF ? dist_f != 0 : dist_b != 0;  // sqrt(r2) per match: only the MUSE scale reads it (first estimate)
   const DirArgs &D = isF ? F : B;
   const XfD &xf = isF ? xfF : xfB;
   const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
@@ -2278,7 +2280,7 @@ __global__ __launch_bounds__(kWide) void k_f_residual(DirArgs F, DirArgs B, int 
     for (int u = 0; u < U; ++u) {
       const int s = s0 + u * stride;
       if (sl[u] == -2) continue;
-      if (sl[u] < 0) { D.key_s[s] = INFINITY; continue; }
+      if (sl[u] < 0) { if (want_dist) D.key_s[s] = INFINITY; continue; }
       const double q0 = q[u][0], q1 = q[u][1], q2 = q[u][2];
       double y0, y1, y2;
       map_loc(xf, (p[u][0] - ident.cm[0]) / ident.rm, (p[u][1] - ident.cm[1]) / ident.rm, (p[u][2] - ident.cm[2]) / ident.rm, y0, y1, y2);
@@ -2293,7 +2295,7 @@ __global__ __launch_bounds__(kWide) void k_f_residual(DirArgs F, DirArgs B, int 
       acc[0] += wp[u] * r2;
       acc[1] += wp[u];
       D.r2[s] = r2;
-      D.key_s[s] = sqrt(r2);
+      if (want_dist) D.key_s[s] = sqrt(r2);
       if (isF && want_stats) {
         acc[2] += p[u][0]; acc[3] += p[u][1]; acc[4] += p[u][2];
         D.flag[mt[u]] = D.gen;
@@ -2305,7 +2307,7 @@ __global__ __launch_bounds__(kWide) void k_f_residual(DirArgs F, DirArgs B, int 
 
 // F3: mean radii about the centroids (cdcl .txx:1195-1213)
 __global__ __launch_bounds__(kWide) void k_f_radii(DirArgs F, int nbF, const double *P1, const double *P2,
-                                                    int nbT, const double *to_rec, int nt, double *P3,
+                                                    int nbT, const GridPoint *to_pt, int nt, double *P3,
                                                     double *SC) {
   // the first source and the first target of this thread travel while the prologue reduces the partial rows (for lists
   // up to gridDim.x * kWide entries that is all of them)
@@ -2314,7 +2316,7 @@ __global__ __launch_bounds__(kWide) void k_f_radii(DirArgs F, int nbF, const dou
   unsigned fl0 = F.gen - 1u;
   double p0 = 0.0, p1 = 0.0, p2 = 0.0, t0 = 0.0, t1 = 0.0, t2 = 0.0;
   if (first < F.ps.nsrc) { sl0 = F.ps.slot[first]; load_from(F.ps, first, p0, p1, p2); }
-  if (first < nt) { fl0 = F.flag[first]; const double *q = to_rec + (size_t)first * kRecStride; t0 = q[0]; t1 = q[1]; t2 = q[2]; }
+  if (first < nt) { fl0 = F.flag[first]; const GridPoint q = to_pt[first]; t0 = q.x; t1 = q.y; t2 = q.z; }
   double cm[3], cf[3];
   double tot[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // from-sums (3), distinct-to sums (3) and their count
   if ((int)threadIdx.x < nbF)  // at most kWideBlocks rows each: one per thread
@@ -2345,8 +2347,8 @@ __global__ __launch_bounds__(kWide) void k_f_radii(DirArgs F, int nbF, const dou
   }
   for (int j = first + step; j < nt; j += step) {
     if (F.flag[j] == F.gen) {
-      const double *q = to_rec + (size_t)j * kRecStride;
-      double q0 = q[0] - cf[0], q1 = q[1] - cf[1], q2 = q[2] - cf[2];
+      const GridPoint q = to_pt[j];
+      double q0 = q.x - cf[0], q1 = q.y - cf[1], q2 = q.z - cf[2];
       acc[1] += sqrt((q0 * q0 + q1 * q1) + q2 * q2);
     }
   }
@@ -4465,7 +4467,7 @@ int lrr_icp_normalize_stats(lrr_icp_dir *d, lrr_icp_norm *out) {
   hipLaunchKernelGGL(k_mark, dim3(blocks_for(ps.nsrc)), dim3(kBlock), 0, ctx->stream, d->slot, d->m_to, ps.nsrc, d->flag, gen);
   HIPCHK(ctx, hipGetLastError());
   int nbt = grid_wide(nt);
-  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kWide), 0, ctx->stream, d->to->rec, d->flag, gen, (int)nt, ctx->d_partials);
+  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kWide), 0, ctx->stream, d->to->cpt, d->flag, gen, (int)nt, ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   rc = finish_reduce(ctx, nbt, 4, r);
   if (rc) return rc;
@@ -4504,7 +4506,7 @@ int lrr_icp_normalize_stats_merged(lrr_icp_dir *own, lrr_icp_dir *rev, lrr_icp_n
   if ((rc = next_flag_gen(own, &gen))) return rc;
   hipLaunchKernelGGL(k_mark, dim3(blocks_for(po.nsrc)), dim3(kBlock), 0, ctx->stream, own->slot, own->m_to, po.nsrc, own->flag, gen);
   HIPCHK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kWide), 0, ctx->stream, own->to->rec, own->flag, gen, nt, ctx->d_partials);
+  hipLaunchKernelGGL(k_to_sum, dim3(nbt), dim3(kWide), 0, ctx->stream, own->to->cpt, own->flag, gen, nt, ctx->d_partials);
   HIPCHK(ctx, hipGetLastError());
   if ((rc = finish_reduce(ctx, nbt, 4, r))) return rc;
   const double nd = r[3];
@@ -4709,7 +4711,8 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   NormD ident = to_dev((const lrr_icp_norm *)nullptr);
   // F1
   if (o->normalize) { int rc = next_flag_gen(F, &aF.gen); if (rc) return rc; }
-  hipLaunchKernelGGL(k_f_residual, dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, to_dev(xfF), to_dev(xfB), ident, o->normalize, P1);
+  hipLaunchKernelGGL(k_f_residual, dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, to_dev(xfF), to_dev(xfB), ident, o->normalize,
+                     o->scale_mode_f == LRR_ICP_SCALE_MUSE ? 1 : 0, o->scale_mode_b == LRR_ICP_SCALE_MUSE ? 1 : 0, P1);
   HIPCHK(ctx, hipGetLastError());
   // scale modes; MUSE needs the sorted residuals: its tables and argmin stay on the host (first
   // estimate after set_transform only)
@@ -4719,9 +4722,9 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   if (wo.mode_f == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &wo.inj_f); if (rc) return rc; wo.mode_f = LRR_ICP_SCALE_INJECTED; }
   if (wo.mode_b == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(B, &wo.inj_b); if (rc) return rc; wo.mode_b = LRR_ICP_SCALE_INJECTED; }
   if (o->normalize) {
-    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kWide), 0, st, F->to->rec, F->flag, aF.gen, nt, P2);
+    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kWide), 0, st, F->to->cpt, F->flag, aF.gen, nt, P2);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kWide), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
+    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kWide), 0, st, aF, nbF, P1, P2, nbT, F->to->cpt, nt, P3, SC);
     HIPCHK(ctx, hipGetLastError());
   }
   // The order statistics ride along with the weight pass (FOLD) when the scales have settled: same lists and sizes as
@@ -4939,9 +4942,9 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
     if (rc) return rc;
     hipLaunchKernelGGL(k_fw_stats, dim3(nbF), dim3(kWide), 0, st, aF, P1);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kWide), 0, st, F->to->rec, F->flag, aF.gen, nt, P2);
+    hipLaunchKernelGGL(k_to_sum, dim3(nbT), dim3(kWide), 0, st, F->to->cpt, F->flag, aF.gen, nt, P2);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kWide), 0, st, aF, nbF, P1, P2, nbT, F->to->rec, nt, P3, SC);
+    hipLaunchKernelGGL(k_f_radii, dim3(nb3), dim3(kWide), 0, st, aF, nbF, P1, P2, nbT, F->to->cpt, nt, P3, SC);
     HIPCHK(ctx, hipGetLastError());
   }
   FwdOpts fo;
