@@ -143,6 +143,7 @@ struct lrr_icp_ctx {
   int *d_selcursor = nullptr;    // kMaxSelJobs, zero between selections
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
   double *h_fused = nullptr, *h_fused_dev = nullptr;
+  std::vector<double> fused_vals;  // the values of the last tagged result set (wait_chunks)
   // completion word of the reduce kernels (mapped host memory) and their last-block counter
   unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr, seq = 0;
   // block rows of k_errors, written by the blocks themselves: kWideBlocks rows of 8 doubles {s0, tag, s1, tag, s2, tag, -, -}
@@ -361,8 +362,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // (the normal equations: 90): a shuffle tree per value costs 12 cross-lane operations each, so the
 // wave transposes 16 values at a time through LDS instead — lane (part, k) adds value k of 16
 // lanes in lane order, two shuffles join the four parts — then the 4 waves in index order.
+// ld > 0: column-major destination (value k of block b at partials[k * ld + b]) — what k_reduce_partials reads
+// coalesced when there are hundreds of rows of many values
 template <int K, int NW = kBlock / 64>
-__device__ __forceinline__ void block_reduce_store(double (&v)[K], double *partials) {
+__device__ __forceinline__ void block_reduce_store(double (&v)[K], double *partials, int ld = 0) {
   __shared__ double red[NW][K];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if constexpr (K <= 8) {
@@ -395,7 +398,8 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[K], double *parti
     double s = red[0][k];
 #pragma unroll
     for (int w2 = 1; w2 < NW; ++w2) s += red[w2][k];
-    partials[(size_t)blockIdx.x * K + k] = s;
+    if (ld > 0) partials[(size_t)k * ld + blockIdx.x] = s;
+    else partials[(size_t)blockIdx.x * K + k] = s;
   }
 }
 
@@ -453,11 +457,25 @@ __device__ __forceinline__ void block_sum_all(double (&v)[K]) {
 __global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, int nblocks, int K, double *out,
                                                         const double *fwd, int head, double *host, int *done,
                                                         volatile unsigned long long *host_seq, unsigned long long seq,
-                                                        const int *cnt_a = nullptr, const int *cnt_b = nullptr) {
+                                                        const int *cnt_a = nullptr, const int *cnt_b = nullptr, int ld = 0,
+                                                        double tag = 0.0) {
   int k = blockIdx.x;
   double s = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * K + k];
+  if (ld > 0) for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)k * ld + b];  // column-major rows (block_reduce_store)
+  else for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * K + k];
   s = wave_sum(s);
+  if (tag != 0.0) {
+    // tagged results: value i travels as the 16-byte chunk {value, tag} at host[2 i], written by ONE store; the host takes
+    // a value once its tag is there (wait_chunks) — no fence, no counter, no last block
+    double2 *hc = reinterpret_cast<double2 *>(host);
+    if (threadIdx.x == 0) { out[k] = s; hc[head + k] = make_double2(s, tag); }
+    if (k == 0) {
+      for (int t = threadIdx.x; t < head; t += 64) hc[t] = make_double2(fwd[t], tag);
+      if (threadIdx.x == 0) hc[head + K] = make_double2(cnt_a ? (double)*cnt_a : -1.0, tag);
+      if (threadIdx.x == 1) hc[head + K + 1] = make_double2(cnt_b ? (double)*cnt_b : -1.0, tag);
+    }
+    return;
+  }
   if (threadIdx.x == 0) { out[k] = s; host[head + k] = s; }
   if (k == 0) for (int t = threadIdx.x; t < head; t += 64) host[t] = fwd[t];
   if (k == 0 && threadIdx.x == 0) {
@@ -2777,7 +2795,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_f_accumulate_kron(DirArgs F, DirA
       accumulate_pair_kron<PREMUL>(acc, wi[u], j0, j1, j2, b0, b1, b2, Pq[u], c0, c1, c2, rigid_increment);
     }
   }
-  block_reduce_store<kKron>(acc, P6);
+  block_reduce_store<kKron>(acc, P6, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3101,7 +3119,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_fw_accumulate_kron(DirArgs F, Fwd
       accumulate_pair_kron<false>(acc, wi[u], p0, p1, p2, q0, q1, q2, Pq[u], c0, c1, c2, rigid_increment);
     }
   }
-  block_reduce_store<kKron>(acc, P6);
+  block_reduce_store<kKron>(acc, P6, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3346,6 +3364,29 @@ int wait_results(lrr_icp_ctx *ctx, unsigned long long seq) {
   std::atomic_thread_fence(std::memory_order_acquire);
   return LRR_ICP_OK;
 }
+
+// waits until `count` tagged chunks {value, tag} (k_reduce_partials) have arrived in mapped host memory and copies
+// their values to ctx->fused_vals (the chunks stay as they are: a tag slot only ever holds tags, so a stale one never
+// equals the current tag); 50 ms without them: stream synchronisation (reports a failed kernel), then failure
+int wait_chunks(lrr_icp_ctx *ctx, const double *chunks, int count, double tag) {
+  const volatile double *c = chunks;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool synced = false;
+  for (int i = 0; i < count; ++i) {
+    unsigned spin = 0;
+    while (c[2 * i + 1] != tag) {
+      if ((++spin & 1023u) != 0 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) continue;
+      if (synced) return fail(ctx, LRR_ICP_ERR_HIP, "results did not arrive");
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      synced = true;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  ctx->fused_vals.resize((size_t)count);
+  for (int i = 0; i < count; ++i) ctx->fused_vals[(size_t)i] = c[2 * i];
+  return LRR_ICP_OK;
+}
+inline double seq_tag(unsigned long long seq) { return (double)(seq & 0xfffffffffffffull); }  // exact in a double, never 0 (seq >= 1)
 
 int finish_reduce(lrr_icp_ctx *ctx, int nblocks, int K, double *host_out) {
   const unsigned long long seq = ++ctx->seq;
@@ -3622,7 +3663,8 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   for (K1Lane &L : ctx->lane)
     if ((e = hipMalloc(&L.d_counts, kCountSlots * 4 * sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_fused, sizeof(double) * kFusedDoubles)) != hipSuccess) return bail(e);
-  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
+  if ((e = hipHostMalloc(&ctx->h_fused, sizeof(double) * 512, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
+  std::memset(ctx->h_fused, 0, sizeof(double) * 512);  // no chunk carries a valid tag yet
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_fused_dev, ctx->h_fused, 0)) != hipSuccess) return bail(e);
   if ((e = hipHostMalloc(&ctx->h_rows, sizeof(double) * 8 * kWideBlocks, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail(e);
   std::memset(ctx->h_rows, 0, sizeof(double) * 8 * kWideBlocks);
@@ -4653,7 +4695,7 @@ int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, doub
     // the blocks write their rows into mapped host memory, tagged with this submission's number; the host adds them in
     // row order as they arrive (after 50 ms without them: stream synchronisation, which also reports a failed kernel)
     const unsigned long long seq = ++ctx->seq;
-    const double tag = (double)(seq & 0xfffffffffffffull);  // exact in a double
+    const double tag = seq_tag(seq);
     hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kWide), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, ctx->d_partials, ctx->h_rows_dev, tag);
     HIPCHK(ctx, hipGetLastError());
     const volatile double *rows = ctx->h_rows;
@@ -4784,10 +4826,10 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   HIPCHK(ctx, hipGetLastError());
   const unsigned long long seq = ++ctx->seq;
   hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq,
-                     F->cert_list_count, B->cert_list_count);
+                     F->cert_list_count, B->cert_list_count, kron ? nbAF + nbAB : 0, seq_tag(seq));
   HIPCHK(ctx, hipGetLastError());
-  { int rc = wait_results(ctx, seq); if (rc) return rc; }
-  const double *h = ctx->h_fused;
+  { int rc = wait_chunks(ctx, ctx->h_fused, (int)FIN_OFF + K + 2, seq_tag(seq)); if (rc) return rc; }
+  const double *h = ctx->fused_vals.data();
   if (F->cert_list_count) F->last_list_count = (int)h[FIN_OFF + K];
   if (B->cert_list_count) B->last_list_count = (int)h[FIN_OFF + K + 1];
   note_inline_cert(ctx, F);
@@ -4974,10 +5016,10 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   HIPCHK(ctx, hipGetLastError());
   const unsigned long long seq = ++ctx->seq;
   hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbA, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq,
-                     F->cert_list_count, (const int *)nullptr);
+                     F->cert_list_count, (const int *)nullptr, kron ? nbA : 0, seq_tag(seq));
   HIPCHK(ctx, hipGetLastError());
-  { int rc = wait_results(ctx, seq); if (rc) return rc; }
-  const double *h = ctx->h_fused;
+  { int rc = wait_chunks(ctx, ctx->h_fused, (int)FIN_OFF + K + 2, seq_tag(seq)); if (rc) return rc; }
+  const double *h = ctx->fused_vals.data();
   if (F->cert_list_count) F->last_list_count = (int)h[FIN_OFF + K];
   note_inline_cert(ctx, F);
   F->cert_list_count = nullptr;
