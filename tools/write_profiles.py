@@ -26,19 +26,24 @@ u2 = json.load(open(f"{G}/pmc_util2_summary.json"))
 merged = {k: {"FETCH_SIZE_KB_avg_last20": f[k].get("FETCH_SIZE_avg_last20"),
               "WRITE_SIZE_KB_avg_last20": w.get(k, {}).get("WRITE_SIZE_avg_last20"),
               "dispatches": f[k].get("FETCH_SIZE_dispatches")} for k in f}
-json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline --no-schedule --reps 1 --steps 10 ; same with "
+json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline --no-schedule --reps 1 --steps 40 ; same with "
                       "--pmc WRITE_SIZE (separate passes); summarised by tools/prof_summary.py pmc",
            "code_sha": sha, "unit": "KB as reported (FETCH_SIZE uncorrected)", "kernels": merged},
           open(f"profiles/{out}_pmc_fetch_write_per_kernel.json", "w"), indent=1)
-# the kernels of a steady finest-level search: k_match_list2 runs only while the certificate list is long (the first searches
-# of the level), so it is counted only when it was dispatched about as often as the certificate kernel
-k1 = [k for k in ("k_match_cert2", "k_match_list2", "k_match_hard2")
-      if k in f and f[k].get("FETCH_SIZE_dispatches", 0) * 2 >= f["k_match_cert2"].get("FETCH_SIZE_dispatches", 1)]
+# the kernels of a steady finest-level search: the certificate kernel that searches its own failures (k_match_cert_inline2); the
+# separate certificate / list / wave-per-query kernels run only while the lists are long (the first searches of the level), so a
+# kernel is counted only when it was dispatched about as often as the most frequent one
+if f.get("k_match_cert_inline2", {}).get("FETCH_SIZE_dispatches", 0) >= 5:
+    k1 = ["k_match_cert_inline2"]  # the steady finest-level search is this one kernel (k_match_hard2 also serves the coarse levels)
+else:
+    cand = [k for k in ("k_match_cert2", "k_match_list2", "k_match_hard2") if k in f]
+    most = max(f[k].get("FETCH_SIZE_dispatches", 0) for k in cand)
+    k1 = [k for k in cand if f[k].get("FETCH_SIZE_dispatches", 0) * 2 >= most]
 fe = sum(f[k]["FETCH_SIZE_avg_last20"] for k in k1) / 2
 wr = sum(w[k]["WRITE_SIZE_avg_last20"] for k in k1) / 2
 traffic = (2 * fe + wr) * 1024
 json.dump({
-    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --no-cpu-baseline --no-schedule --reps 1 --steps 10, "
+    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --no-cpu-baseline --no-schedule --reps 1 --steps 40, "
               f"finest-level launches (last 20 dispatches per kernel); profiles/{out}_pmc_fetch_write_per_kernel.json",
     "code_sha": sha,
     "kernel": "K1 = (" + " + ".join(k1) + ") / 2: every launch handles both find_closest_euclidean directions "
@@ -64,15 +69,15 @@ for k in k1:
     a.update(u2.get(k, {}))
     util[k] = {n.replace("_avg_last20", ""): v for n, v in a.items() if n.endswith("_avg_last20")}
     util[k]["avg_us"] = dur.get(k)
-main = "k_match_cert2"
+main = k1[0]
 valu_q = util[main].get("SQ_ACTIVE_INST_VALU", 0.0)  # quad-cycles, summed over all SIMDs
 simd_cycles = dur.get(main, 0.0) * 1e-6 * 2.4e9 * 1024  # 256 CUs x 4 SIMDs at 2.4 GHz
 valu_frac = (4.0 * valu_q / simd_cycles) if simd_cycles else None
 json.dump({"source": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES | SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD "
-                     "SQ_THREAD_CYCLES_VALU (two passes), bench.py --no-cpu-baseline --no-schedule --reps 1 --steps 10, last 20 dispatches per kernel; "
+                     "SQ_THREAD_CYCLES_VALU (two passes), bench.py --no-cpu-baseline --no-schedule --reps 1 --steps 40, last 20 dispatches per kernel; "
                      "SQ cycle counters in quad-cycles, summed over all SIMDs",
            "code_sha": sha, "kernels": util,
-           "valu_frac_definition": "4 x SQ_ACTIVE_INST_VALU (quad-cycles -> cycles) of k_match_cert2 / (its average duration x 2.4 GHz x 1024 SIMDs): "
+           "valu_frac_definition": f"4 x SQ_ACTIVE_INST_VALU (quad-cycles -> cycles) of {main} / (its average duration x 2.4 GHz x 1024 SIMDs): "
                                    "the share of the chip's VALU issue time the dominant K1 kernel uses while it runs",
            "valu_frac": valu_frac},
           open("profiles/pmc_utilisation.json", "w"), indent=1)
