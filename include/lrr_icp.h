@@ -297,6 +297,35 @@ int  lrr_icp_cdc_compute_weights(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, co
                                  const double *param_covar, const uint32_t keys[4], int max_matches,
                                  int64_t *row_count, int64_t *to_idx, double *w, int64_t *overflow_rows);
 
+/* The same with the rows RESIDENT on the device (what the M-step reads): create for a cloud pair, compute_weights fills
+ * the rows, get copies them out. */
+typedef struct lrr_icp_cdc_set lrr_icp_cdc_set;
+int  lrr_icp_cdc_set_create(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, int max_matches, lrr_icp_cdc_set **out);
+void lrr_icp_cdc_set_destroy(lrr_icp_cdc_set *set);
+int  lrr_icp_cdc_set_compute_weights(lrr_icp_cdc_set *set, const lrr_icp_xform *xf, int dof, const double *param_covar,
+                                     const uint32_t keys[4], int64_t *overflow_rows);
+int  lrr_icp_cdc_set_get(lrr_icp_cdc_set *set, int64_t *row_count, int64_t *to_idx, double *w);
+/* M-step, parameters: cdcl_obj_fun_par::compute (cdcl/cdcl_obj_fun_par.txx:44-142; constructor :20-41) at the
+ * transform x over the resident rows: f = (1/R) sum w (rho(r) + ln det C_ij) and, when g != NULL, its gradient
+ * (dof values: 2 J_th^T C_ij^-1 e and the two correction terms of d C_ij / d theta), R = rows that are not empty.
+ * param_covar: the dof x dof parameter covariance the transfer-error term J_th C_theta J_th^T is built from (the
+ * objective's constructor takes it from the transform).  norm (may be NULL): the features as cdcl_normalize_matches
+ * leaves them (cdcl/cdcl_estimation_ICP.txx:751-833): locations (x - c) / r, covariances C / (r r); x is taken as
+ * given (the caller normalises the transform, cdcl/cdcl_estimation.txx:218-221).  The L-BFGS driver
+ * (cdcl_lbfgs / vnl_lbfgs, five evaluations per call, cdcl/cdcl_estimation.txx:230-239) stays with the caller. */
+int  lrr_icp_cdc_objective_par(lrr_icp_cdc_set *set, const lrr_icp_xform *x, int dof, const double *param_covar,
+                               const lrr_icp_norm *norm, double *f, double *g, int64_t *rows);
+
+/* cdcl_normalize_matches for the one-to-many rows (cdcl/cdcl_estimation_ICP.txx:751-795): centroid of the moving features
+ * whose row is not empty, centroid of the DISTINCT matched fixed features, mean radii about them */
+int  lrr_icp_cdc_normalize_stats(lrr_icp_cdc_set *set, lrr_icp_norm *out);
+/* M-step, covariance: cdcl_obj_fun_cov::compute (cdcl/cdcl_obj_fun_cov.txx:42-134; constructor :17-38) over the resident
+ * rows.  x_upper: the dof (dof + 1) / 2 entries of the upper-triangular Cholesky factor U of the parameter covariance,
+ * row by row (the optimiser's variables: cdcl/cdcl_estimation.txx:283-293); C_theta = U^T U.  f = (1/N) sum w (rho(r) +
+ * ln det C_ij) over all N pairs, g (may be NULL): its gradient in those entries.  x: the transform (not varied here). */
+int  lrr_icp_cdc_objective_cov(lrr_icp_cdc_set *set, const lrr_icp_xform *x, int dof, const double *x_upper,
+                               const lrr_icp_norm *norm, double *f, double *g, int64_t *pairs);
+
 /* stand-alone exact nearest neighbour of host query points (tests, diagnostics) */
 int  lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int method, int64_t *idx);
 

@@ -34,6 +34,7 @@ ICP_SYMBOLS = [
     "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_cloud_set_shape_vectors", "lrr_icp_angles", "lrr_icp_angles_unmapped", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
     "lrr_icp_nearest", "lrr_icp_cloud_set_covariances", "lrr_icp_cdc_compute_weights",
+    "lrr_icp_cdc_set_create", "lrr_icp_cdc_set_destroy", "lrr_icp_cdc_set_compute_weights", "lrr_icp_cdc_set_get", "lrr_icp_cdc_objective_par", "lrr_icp_cdc_objective_cov", "lrr_icp_cdc_normalize_stats",
     "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
     "lrr_icp_batch_match", "lrr_icp_batch_estimate", "lrr_icp_batch_errors", "lrr_icp_batch_angles",
     "lrr_icp_batch_num_matches", "lrr_icp_batch_get_matches",
@@ -275,6 +276,99 @@ def cdc_compute_weights(moving: "DeviceCloud", fixed: "DeviceCloud", dof, A, t, 
                                      ti.ctypes.data_as(_ip), _d(w), C.byref(over)) != 0:
         raise RuntimeError(L.lrr_icp_last_error(moving.ctx).decode())
     return rc, ti, w, over.value
+
+
+class CdcSet:
+    """Match rows of the covariance-driven EM estimator, resident on the device: compute_weights() = the E-step
+    (cdcl_estimation::compute_weights), objective_par() = cdcl_obj_fun_par::compute over those rows (the M-step's
+    parameter objective and gradient; the L-BFGS driver stays with the caller)."""
+
+    def __init__(self, moving: "DeviceCloud", fixed: "DeviceCloud", max_matches=100):
+        self.L = hip_lib()
+        self.moving, self.fixed, self.max_matches = moving, fixed, int(max_matches)
+        self.h = C.c_void_p()
+        self.L.lrr_icp_cdc_set_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        self.L.lrr_icp_cdc_set_destroy.argtypes = [C.c_void_p]
+        self.L.lrr_icp_cdc_set_destroy.restype = None
+        self.L.lrr_icp_cdc_set_compute_weights.argtypes = [C.c_void_p, C.POINTER(Xform), C.c_int, _dp, C.POINTER(C.c_uint32), _ip]
+        self.L.lrr_icp_cdc_set_get.argtypes = [C.c_void_p, _ip, _ip, _dp]
+        self.L.lrr_icp_cdc_objective_par.argtypes = [C.c_void_p, C.POINTER(Xform), C.c_int, _dp, C.POINTER(Norm), _dp, _dp, _ip]
+        self._ck(self.L.lrr_icp_cdc_set_create(moving.h, fixed.h, self.max_matches, C.byref(self.h)))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.moving.ctx).decode())
+
+    @staticmethod
+    def _xform(A, t, c):
+        x = Xform()
+        x.A[:] = np.asarray(A, dtype=np.float64).ravel()
+        x.t[:] = np.asarray(t, dtype=np.float64)
+        x.c[:] = np.asarray(c, dtype=np.float64)
+        return x
+
+    def compute_weights(self, dof, A, t, c, param_covar, seed):
+        x = self._xform(A, t, c)
+        cov = np.ascontiguousarray(param_covar, dtype=np.float64)
+        st = C.c_uint64(seed)
+        keys = (C.c_uint32 * 4)()
+        self.L.lrr_icp_perm_keys(C.byref(st), keys)
+        over = C.c_int64(0)
+        self._ck(self.L.lrr_icp_cdc_set_compute_weights(self.h, C.byref(x), dof, _d(cov), keys, C.byref(over)))
+        return over.value
+
+    def rows(self):
+        nm = self.L.lrr_icp_cloud_size(self.moving.h)
+        rc = np.zeros(nm, dtype=np.int64)
+        ti = np.zeros((nm, self.max_matches), dtype=np.int64)
+        w = np.zeros((nm, self.max_matches))
+        self._ck(self.L.lrr_icp_cdc_set_get(self.h, rc.ctypes.data_as(_ip), ti.ctypes.data_as(_ip), _d(w)))
+        return rc, ti, w
+
+    def objective_par(self, dof, A, t, c, param_covar, norm=None, want_grad=True):
+        """(f, g or None, rows that took part); norm = (cm[3], rm, cf[3], rf) or None"""
+        x = self._xform(A, t, c)
+        cov = np.ascontiguousarray(param_covar, dtype=np.float64)
+        nrm = None
+        if norm is not None:
+            nrm = Norm()
+            v = np.asarray(norm, dtype=np.float64)
+            nrm.cm[:] = v[0:3]; nrm.rm = v[3]; nrm.cf[:] = v[4:7]; nrm.rf = v[7]
+        f = C.c_double(0.0)
+        g = np.zeros(dof)
+        rows = C.c_int64(0)
+        self._ck(self.L.lrr_icp_cdc_objective_par(self.h, C.byref(x), dof, _d(cov), C.byref(nrm) if nrm is not None else None, C.byref(f),
+                                                  _d(g) if want_grad else None, C.byref(rows)))
+        return f.value, (g if want_grad else None), rows.value
+
+    def normalize_stats(self):
+        """cdcl_normalize_matches over the rows: (cm[3], rm, cf[3], rf) as one array of 8"""
+        nrm = Norm()
+        self.L.lrr_icp_cdc_normalize_stats.argtypes = [C.c_void_p, C.POINTER(Norm)]
+        self._ck(self.L.lrr_icp_cdc_normalize_stats(self.h, C.byref(nrm)))
+        return np.r_[np.array(nrm.cm[:]), nrm.rm, np.array(nrm.cf[:]), nrm.rf]
+
+    def objective_cov(self, dof, A, t, c, x_upper, norm=None, want_grad=True):
+        """cdcl_obj_fun_cov::compute: (f, g or None, pairs); x_upper = upper triangle of the Cholesky factor, row by row"""
+        x = self._xform(A, t, c)
+        xu = np.ascontiguousarray(x_upper, dtype=np.float64)
+        nrm = None
+        if norm is not None:
+            nrm = Norm()
+            v = np.asarray(norm, dtype=np.float64)
+            nrm.cm[:] = v[0:3]; nrm.rm = v[3]; nrm.cf[:] = v[4:7]; nrm.rf = v[7]
+        f = C.c_double(0.0)
+        g = np.zeros(dof * (dof + 1) // 2)
+        pairs = C.c_int64(0)
+        self.L.lrr_icp_cdc_objective_cov.argtypes = [C.c_void_p, C.POINTER(Xform), C.c_int, _dp, C.POINTER(Norm), _dp, _dp, _ip]
+        self._ck(self.L.lrr_icp_cdc_objective_cov(self.h, C.byref(x), dof, _d(xu), C.byref(nrm) if nrm is not None else None, C.byref(f),
+                                                  _d(g) if want_grad else None, C.byref(pairs)))
+        return f.value, (g if want_grad else None), pairs.value
+
+    def close(self):
+        if self.h:
+            self.L.lrr_icp_cdc_set_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 def subset_perm(n: int, seed: int):

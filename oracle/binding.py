@@ -139,6 +139,52 @@ def cdc_compute_weights(moving, fixed, dof, A, t, c, param_covar, seed, max_matc
     return rc, ti, w
 
 
+def cdc_obj_par(moving, fixed, dof, A, t, c, param_covar, row_count, to_idx, w, norm=None, want_grad=True):
+    """cdcl_obj_fun_par::compute over the match rows: (f, g, rows that took part); norm = (cm[3], rm, cf[3], rf) or None"""
+    L = lib()
+    keep = []
+    fm, ff = _features(moving, keep), _features(fixed, keep)
+    A, t, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, t, c))
+    cov = np.ascontiguousarray(param_covar, dtype=np.float64)
+    rc = np.ascontiguousarray(row_count, dtype=np.int64)
+    ti = np.ascontiguousarray(to_idx, dtype=np.int64)
+    ww = np.ascontiguousarray(w, dtype=np.float64)
+    nrm = None if norm is None else np.ascontiguousarray(norm, dtype=np.float64)
+    f = C.c_double(0.0)
+    g = np.zeros(dof)
+    i64p = C.POINTER(C.c_int64)
+    L.lrr_oracle_cdc_obj_par.restype = C.c_int64
+    L.lrr_oracle_cdc_obj_par.argtypes = [C.POINTER(_Features), C.POINTER(_Features), C.c_int, _dp, _dp, _dp, _dp, C.c_int, i64p, i64p, _dp, _dp,
+                                         C.POINTER(C.c_double), _dp]
+    rows = L.lrr_oracle_cdc_obj_par(C.byref(fm), C.byref(ff), dof, _d(A), _d(t), _d(c), _d(cov), ti.shape[1], rc.ctypes.data_as(i64p),
+                                    ti.ctypes.data_as(i64p), _d(ww), _d(nrm) if nrm is not None else None, C.byref(f),
+                                    _d(g) if want_grad else None)
+    return f.value, (g if want_grad else None), int(rows)
+
+
+def cdc_obj_cov(moving, fixed, dof, A, t, c, x_upper, row_count, to_idx, w, norm=None, want_grad=True):
+    """cdcl_obj_fun_cov::compute over the match rows: (f, g, pairs); x_upper = upper triangle of the Cholesky factor, row by row"""
+    L = lib()
+    keep = []
+    fm, ff = _features(moving, keep), _features(fixed, keep)
+    A, t, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, t, c))
+    xu = np.ascontiguousarray(x_upper, dtype=np.float64)
+    rc = np.ascontiguousarray(row_count, dtype=np.int64)
+    ti = np.ascontiguousarray(to_idx, dtype=np.int64)
+    ww = np.ascontiguousarray(w, dtype=np.float64)
+    nrm = None if norm is None else np.ascontiguousarray(norm, dtype=np.float64)
+    f = C.c_double(0.0)
+    g = np.zeros(dof * (dof + 1) // 2)
+    i64p = C.POINTER(C.c_int64)
+    L.lrr_oracle_cdc_obj_cov.restype = C.c_int64
+    L.lrr_oracle_cdc_obj_cov.argtypes = [C.POINTER(_Features), C.POINTER(_Features), C.c_int, _dp, _dp, _dp, _dp, C.c_int, i64p, i64p, _dp, _dp,
+                                         C.POINTER(C.c_double), _dp]
+    pairs = L.lrr_oracle_cdc_obj_cov(C.byref(fm), C.byref(ff), dof, _d(A), _d(t), _d(c), _d(xu), ti.shape[1], rc.ctypes.data_as(i64p),
+                                     ti.ctypes.data_as(i64p), _d(ww), _d(nrm) if nrm is not None else None, C.byref(f),
+                                     _d(g) if want_grad else None)
+    return f.value, (g if want_grad else None), int(pairs)
+
+
 def muse_scale(res):
     r = np.ascontiguousarray(res, dtype=np.float64)
     return lib().lrr_oracle_muse_scale(_d(r), r.shape[0])

@@ -946,6 +946,241 @@ int64_t lrr_oracle_cdc_compute_weights(const lrr_oracle_features *moving, const 
   return total;
 }
 
+/* rho() and rho_p() of cdcl/cdcl_utils.h:158-201 (modified Beaton-Tukey, b = 4, f = 2.9872; the residual is squared already) */
+static double cdc_rho(double residual) {
+  const double b_2 = 16.0, f = 2.9872, c = b_2 / 6.0;
+  if (residual > b_2) return f * c;
+  return f * c * (1 - pow(1 - residual / b_2, 3.0));
+}
+static double cdc_rho_p(double residual) {
+  const double b_2 = 16.0, f = 2.9872;
+  if (residual > b_2) return 0.0;
+  double temp = 1 - residual / b_2;
+  return f * 0.5 * temp * temp;
+}
+
+/* cdcl_obj_fun_par: the objective of the CDC-EM M-step's parameter estimate and its gradient
+ * (cdcl/cdcl_obj_fun_par.txx:20-41 constructor, :44-142 compute()).  Matches: rows of max_matches slots per moving
+ * feature (row_count, to_idx, w: what compute_weights left); a moving feature takes part when its row is not empty.
+ *   constructor: JCthJ_i = J_th(p_i) C_theta J_th(p_i)^T (:30-38)
+ *   compute():   J_p = jacobian_wrt_loc() = A (:54);  Mkl = jacobian_of_Jp() (:60: affine: the nine unit matrices in
+ *                parameter order, cdcl_trans_affine.txx:199-214; rigid: the three skew generators, cdcl_trans_rigid3d.cxx:230-255)
+ *                C_ij = JCthJ_i + J_p C_p J_p^T + C_q (:74-84), e = T(p) - q (:88), r = e^T C_ij^-1 e (:92), inlier = rho_p(r) > 0 (:101)
+ *                f += w (rho(r) + ln det C_ij) (:105);
+ *                g += w (rho_p(r) (2 J_th^T C_ij^-1 e + correct) + correctS) (:109-128), correct_f = -eC^T dC eC,
+ *                correctS_f = trace(C_ij^-1 dC), dC = J_p C_p Mkl^T + Mkl C_p J_p^T, eC = C_ij^-1 e
+ *                f /= #rows, g /= #rows (:133-141)
+ * norm (may be NULL): {cm[3], rm, cf[3], rf} — the features as cdcl_normalize_matches leaves them
+ * (cdcl/cdcl_estimation_ICP.txx:751-833): locations (x - c) / r, covariances C / (r r).  The transform is taken as given
+ * (the caller normalises it).  g may be NULL.  Returns the number of rows that took part. */
+int64_t lrr_oracle_cdc_obj_par(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int dof, const double *A,
+                               const double *t, const double *c, const double *param_covar, int max_matches,
+                               const int64_t *row_count, const int64_t *to_idx, const double *w, const double *norm,
+                               double *f_out, double *g_out) {
+  trans T;
+  trans_identity(&T, dof);
+  memcpy(T.A, A, sizeof T.A); memcpy(T.t, t, sizeof T.t); memcpy(T.c, c, sizeof T.c);
+  memcpy(T.covar, param_covar, sizeof(double) * (size_t)dof * (size_t)dof);
+  const int nrot = dof - 3;
+  double Mkl[9][9];
+  memset(Mkl, 0, sizeof Mkl);
+  if (dof == 12) {
+    for (int d1 = 0; d1 < 3; ++d1) for (int d2 = 0; d2 < 3; ++d2) Mkl[3 * d1 + d2][3 * d1 + d2] = 1.0;
+  } else {
+    Mkl[0][3 * 1 + 2] = -1.0; Mkl[0][3 * 2 + 1] = 1.0;
+    Mkl[1][3 * 0 + 2] = 1.0;  Mkl[1][3 * 2 + 0] = -1.0;
+    Mkl[2][3 * 0 + 1] = -1.0; Mkl[2][3 * 1 + 0] = 1.0;
+  }
+  double f = 0.0, g[MAXDOF];
+  for (int k = 0; k < dof; ++k) g[k] = 0.0;
+  int64_t rows = 0;
+  for (int64_t i = 0; i < moving->n; ++i) {
+    if (row_count[i] <= 0) continue;
+    ++rows;
+    double p[3], Cp[9];
+    for (int d = 0; d < 3; ++d) p[d] = moving->loc[3 * i + d];
+    for (int a = 0; a < 9; ++a) Cp[a] = moving->cov[9 * i + a];
+    if (norm) {
+      for (int d = 0; d < 3; ++d) { p[d] -= norm[d]; p[d] /= norm[3]; }
+      for (int a = 0; a < 9; ++a) Cp[a] /= (norm[3] * norm[3]);
+    }
+    double J[3 * MAXDOF], JC[3 * MAXDOF], Cij_p[9];
+    trans_jac(&T, p, J);
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < dof; ++cc) {
+        double s2 = 0.0;
+        for (int k = 0; k < dof; ++k) s2 += J[r * dof + k] * T.covar[k * dof + cc];
+        JC[r * dof + cc] = s2;
+      }
+    for (int r = 0; r < 3; ++r)
+      for (int e = 0; e < 3; ++e) {
+        double s2 = 0.0;
+        for (int k = 0; k < dof; ++k) s2 += JC[r * dof + k] * J[e * dof + k];
+        Cij_p[3 * r + e] = s2;
+      }
+    double JpC[9], At[9];  /* J_p C_p and J_p^T */
+    mat3_mul(T.A, Cp, JpC);
+    for (int r = 0; r < 3; ++r) for (int e = 0; e < 3; ++e) At[3 * r + e] = T.A[3 * e + r];
+    { double X[9]; mat3_mul(JpC, At, X); for (int a = 0; a < 9; ++a) Cij_p[a] += X[a]; }
+    double y[3];
+    trans_map(&T, p, y);
+    for (int64_t k = 0; k < row_count[i]; ++k) {
+      const int64_t j = to_idx[i * max_matches + k];
+      const double wj = w[i * max_matches + k];
+      double q[3], Cq[9];
+      for (int d = 0; d < 3; ++d) q[d] = fixed->loc[3 * j + d];
+      for (int a = 0; a < 9; ++a) Cq[a] = fixed->cov[9 * j + a];
+      if (norm) {
+        for (int d = 0; d < 3; ++d) { q[d] -= norm[4 + d]; q[d] /= norm[7]; }
+        for (int a = 0; a < 9; ++a) Cq[a] /= (norm[7] * norm[7]);
+      }
+      double Cij[9], Ci[9], e[3], eC[3];
+      for (int a = 0; a < 9; ++a) Cij[a] = Cij_p[a] + Cq[a];
+      inverse3_cofactor(Cij, Ci);
+      for (int d = 0; d < 3; ++d) e[d] = y[d] - q[d];
+      mat3_vec(Ci, e, eC);
+      const double residual = (e[0] * eC[0] + e[1] * eC[1]) + e[2] * eC[2];
+      const double rp = cdc_rho_p(residual), rh = cdc_rho(residual);
+      if (!(rp > 0)) continue;
+      const double det = Cij[0] * (Cij[4] * Cij[8] - Cij[5] * Cij[7]) - Cij[1] * (Cij[3] * Cij[8] - Cij[5] * Cij[6]) + Cij[2] * (Cij[3] * Cij[7] - Cij[4] * Cij[6]);
+      f += wj * (rh + log(det));
+      if (!g_out) continue;
+      double correct[MAXDOF], correctS[MAXDOF];
+      for (int k2 = 0; k2 < dof; ++k2) correct[k2] = correctS[k2] = 0.0;
+      for (int ff = 0; ff < nrot; ++ff) {
+        double Mt[9], X[9], Y[9], dC[9], CpAt[9], Z[9];
+        for (int r = 0; r < 3; ++r) for (int e2 = 0; e2 < 3; ++e2) Mt[3 * r + e2] = Mkl[ff][3 * e2 + r];
+        mat3_mul(JpC, Mt, X);        /* J_p C_p Mkl^T */
+        mat3_mul(Cp, At, CpAt);      /* C_p J_p^T */
+        mat3_mul(Mkl[ff], CpAt, Y);  /* Mkl C_p J_p^T */
+        for (int a = 0; a < 9; ++a) dC[a] = X[a] + Y[a];
+        double dv[3];
+        mat3_vec(dC, eC, dv);
+        correct[ff] = -((eC[0] * dv[0] + eC[1] * dv[1]) + eC[2] * dv[2]);
+        mat3_mul(Ci, dC, Z);
+        correctS[ff] = (Z[0] + Z[4]) + Z[8];
+      }
+      for (int k2 = 0; k2 < dof; ++k2) {
+        /* (J_th^T C_ij^-1 e)_k */
+        const double jt = (J[0 * dof + k2] * eC[0] + J[1 * dof + k2] * eC[1]) + J[2 * dof + k2] * eC[2];
+        g[k2] += wj * (rp * (jt * 2.0 + correct[k2]) + correctS[k2]);
+      }
+    }
+  }
+  if (rows > 0) {
+    f /= (double)rows;
+    for (int k = 0; k < dof; ++k) g[k] *= (1.0 / (double)rows);
+  }
+  *f_out = f;
+  if (g_out) for (int k = 0; k < dof; ++k) g_out[k] = g[k];
+  return rows;
+}
+
+/* cdcl_obj_fun_cov: the objective of the M-step's covariance estimate and its gradient (cdcl/cdcl_obj_fun_cov.txx:17-38
+ * constructor, :42-134 compute()).  x: the upper triangle of the Cholesky factor of the parameter covariance, row by row
+ * (:48-54); C_theta = U^T U (:57).
+ *   constructor: JCpJ_i = J_p C_p J_p^T (:24-37)
+ *   compute():   C_ij = JCpJ_i + J_th C_theta J_th^T + C_q (:71-80), e = q - T(p) (:84), r = e^T C_ij^-1 e;
+ *                f += w (rho(r) + ln det C_ij) for EVERY pair (:94-96: no inlier test here);
+ *                kl += w (-rho_p(r) temp temp^T + J_th^T C_ij^-1 J_th), temp = J_th^T C_ij^-1 e (:99-102);
+ *                g_ind = <kl, U^T se + se^T U> for the single-entry matrices se(d1, d2), d1 <= d2 (:106-118);
+ *                f /= #pairs, g /= #pairs (:122-131)
+ * norm as in lrr_oracle_cdc_obj_par.  g may be NULL.  Returns the number of pairs. */
+int64_t lrr_oracle_cdc_obj_cov(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int dof, const double *A,
+                               const double *t, const double *c, const double *x_upper, int max_matches,
+                               const int64_t *row_count, const int64_t *to_idx, const double *w, const double *norm,
+                               double *f_out, double *g_out) {
+  trans T;
+  trans_identity(&T, dof);
+  memcpy(T.A, A, sizeof T.A); memcpy(T.t, t, sizeof T.t); memcpy(T.c, c, sizeof T.c);
+  double U[MAXDOF * MAXDOF];
+  memset(U, 0, sizeof U);
+  { int ind = 0; for (int d1 = 0; d1 < dof; ++d1) for (int d2 = d1; d2 < dof; ++d2) U[d1 * dof + d2] = x_upper[ind++]; }
+  for (int a = 0; a < dof; ++a)
+    for (int b = 0; b < dof; ++b) {
+      double s2 = 0.0;
+      for (int k = 0; k < dof; ++k) s2 += U[k * dof + a] * U[k * dof + b];
+      T.covar[a * dof + b] = s2;
+    }
+  double kl[MAXDOF * MAXDOF];
+  memset(kl, 0, sizeof kl);
+  double f = 0.0, pairs = 0.0;
+  for (int64_t i = 0; i < moving->n; ++i) {
+    if (row_count[i] <= 0) continue;
+    double p[3], Cp[9];
+    for (int d = 0; d < 3; ++d) p[d] = moving->loc[3 * i + d];
+    for (int a = 0; a < 9; ++a) Cp[a] = moving->cov[9 * i + a];
+    if (norm) {
+      for (int d = 0; d < 3; ++d) { p[d] -= norm[d]; p[d] /= norm[3]; }
+      for (int a = 0; a < 9; ++a) Cp[a] /= (norm[3] * norm[3]);
+    }
+    double J[3 * MAXDOF], JC[3 * MAXDOF], Cij_p[9], At[9], X[9];
+    mat3_mul(T.A, Cp, X);
+    for (int r = 0; r < 3; ++r) for (int e = 0; e < 3; ++e) At[3 * r + e] = T.A[3 * e + r];
+    mat3_mul(X, At, Cij_p);  /* JCpJ */
+    trans_jac(&T, p, J);
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < dof; ++cc) {
+        double s2 = 0.0;
+        for (int k = 0; k < dof; ++k) s2 += J[r * dof + k] * T.covar[k * dof + cc];
+        JC[r * dof + cc] = s2;
+      }
+    for (int r = 0; r < 3; ++r)
+      for (int e = 0; e < 3; ++e) {
+        double s2 = 0.0;
+        for (int k = 0; k < dof; ++k) s2 += JC[r * dof + k] * J[e * dof + k];
+        Cij_p[3 * r + e] += s2;
+      }
+    double y[3];
+    trans_map(&T, p, y);
+    pairs += (double)row_count[i];
+    for (int64_t k = 0; k < row_count[i]; ++k) {
+      const int64_t j = to_idx[i * max_matches + k];
+      const double wj = w[i * max_matches + k];
+      double q[3], Cq[9];
+      for (int d = 0; d < 3; ++d) q[d] = fixed->loc[3 * j + d];
+      for (int a = 0; a < 9; ++a) Cq[a] = fixed->cov[9 * j + a];
+      if (norm) {
+        for (int d = 0; d < 3; ++d) { q[d] -= norm[4 + d]; q[d] /= norm[7]; }
+        for (int a = 0; a < 9; ++a) Cq[a] /= (norm[7] * norm[7]);
+      }
+      double Cij[9], Ci[9], e[3], eC[3];
+      for (int a = 0; a < 9; ++a) Cij[a] = Cij_p[a] + Cq[a];
+      inverse3_cofactor(Cij, Ci);
+      for (int d = 0; d < 3; ++d) e[d] = q[d] - y[d];
+      mat3_vec(Ci, e, eC);
+      const double residual = (e[0] * eC[0] + e[1] * eC[1]) + e[2] * eC[2];
+      const double det = Cij[0] * (Cij[4] * Cij[8] - Cij[5] * Cij[7]) - Cij[1] * (Cij[3] * Cij[8] - Cij[5] * Cij[6]) + Cij[2] * (Cij[3] * Cij[7] - Cij[4] * Cij[6]);
+      f += wj * (cdc_rho(residual) + log(det));
+      if (!g_out) continue;
+      const double rp = cdc_rho_p(residual);
+      double temp[MAXDOF], CiJ[3 * MAXDOF];
+      for (int a = 0; a < dof; ++a) temp[a] = (J[0 * dof + a] * eC[0] + J[1 * dof + a] * eC[1]) + J[2 * dof + a] * eC[2];
+      for (int r = 0; r < 3; ++r)
+        for (int a = 0; a < dof; ++a) CiJ[r * dof + a] = (Ci[3 * r] * J[a] + Ci[3 * r + 1] * J[dof + a]) + Ci[3 * r + 2] * J[2 * dof + a];
+      for (int a = 0; a < dof; ++a)
+        for (int b = 0; b < dof; ++b) {
+          const double jcj = (J[a] * CiJ[b] + J[dof + a] * CiJ[dof + b]) + J[2 * dof + a] * CiJ[2 * dof + b];
+          kl[a * dof + b] += wj * (-rp * temp[a] * temp[b] + jcj);
+        }
+    }
+  }
+  if (pairs > 0) f /= pairs;
+  *f_out = f;
+  if (g_out) {
+    int ind = 0;
+    for (int d1 = 0; d1 < dof; ++d1)
+      for (int d2 = d1; d2 < dof; ++d2) {
+        /* dC = U^T se + se^T U: row d2 of (U^T se) is column... (U^T se)[a][b] = U[d1][a] (b == d2); (se^T U)[a][b] = U[d1][b] (a == d2) */
+        double dot = 0.0;
+        for (int a = 0; a < dof; ++a) dot += kl[a * dof + d2] * U[d1 * dof + a];
+        for (int b = 0; b < dof; ++b) dot += kl[d2 * dof + b] * U[d1 * dof + b];
+        g_out[ind++] = pairs > 0 ? dot * (1.0 / pairs) : 0.0;
+      }
+  }
+  return (int64_t)pairs;
+}
+
 /* ------------------------------------------------------------------------- */
 /* forward estimator: cdcl_estimation_ICP_matching_all / rrl_estimation_ICP_matching_all */
 /* ------------------------------------------------------------------------- */

@@ -100,6 +100,16 @@ int     lrr_oracle_finest_level(lrr_oracle_est *e);
 int64_t lrr_oracle_cdc_compute_weights(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int dof,
                                        const double *A, const double *t, const double *c, const double *param_covar,
                                        const uint32_t keys[4], int max_matches, int64_t *row_count, int64_t *to_idx, double *w);
+/* cdcl_obj_fun_par (CDC-EM M-step, parameters): objective and gradient over the match rows (cdcl/cdcl_obj_fun_par.txx:20-142) */
+int64_t lrr_oracle_cdc_obj_par(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int dof, const double *A,
+                               const double *t, const double *c, const double *param_covar, int max_matches,
+                               const int64_t *row_count, const int64_t *to_idx, const double *w, const double *norm,
+                               double *f_out, double *g_out);
+/* cdcl_obj_fun_cov (CDC-EM M-step, covariance): objective and gradient in the Cholesky parameters (cdcl/cdcl_obj_fun_cov.txx:17-134) */
+int64_t lrr_oracle_cdc_obj_cov(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int dof, const double *A,
+                               const double *t, const double *c, const double *x_upper, int max_matches,
+                               const int64_t *row_count, const int64_t *to_idx, const double *w, const double *norm,
+                               double *f_out, double *g_out);
 
 /* stand-alone pieces (each is also used inside the estimators) */
 void   lrr_oracle_nn(const double *fixed_loc, int64_t nf, const double *query, int64_t nq,

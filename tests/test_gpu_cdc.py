@@ -84,3 +84,82 @@ def test_compute_weights_needs_covariances(E):
         E.cdc_compute_weights(a, b, 12, np.eye(3), np.zeros(3), np.zeros(3), np.eye(12) * 1e-6, seed=1)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("dof,n,normalize", [(12, 4000, False), (12, 3000, True), (6, 3000, False), (6, 2500, True)])
+def test_objective_par_equals_oracle(E, ob, dof, n, normalize):
+    """SURVEY.md section 8(f)4, M-step (parameters): cdcl_obj_fun_par::compute (cdcl/cdcl_obj_fun_par.txx:44-142) over the
+    resident match rows — value and gradient against the oracle's literal restatement, with and without the
+    normalisation of cdcl_normalize_matches; the oracle's gradient itself is checked against finite differences."""
+    pair = synth.make_pair(n, n - 400, 911, kind="rigid" if dof == 6 else "affine", extent=60.0)
+    mv = dataclasses.replace(pair.moving, cov=synth.covariances(pair.moving))
+    fx = dataclasses.replace(pair.fixed, cov=synth.covariances(pair.fixed))
+    T0 = synth.perturbed(pair.planted, 5, rot_deg=0.3, trans_mm=0.4)
+    rng = np.random.default_rng(4)
+    B = rng.normal(size=(dof, dof)) * 2e-3
+    B[(9 if dof == 12 else 3):] *= 50.0
+    Ct = B @ B.T
+    cm, cf = E.DeviceCloud(mv), E.DeviceCloud(fx)
+    cm.set_covariances(mv.cov)
+    cf.set_covariances(fx.cov)
+    S = E.CdcSet(cm, cf, max_matches=100)
+    assert S.compute_weights(dof, T0.A, T0.t, T0.c, Ct, seed=33) == 0
+    rc, ti, w = S.rows()
+    want_rows = ob.cdc_compute_weights(mv, fx, dof, T0.A, T0.t, T0.c, Ct, seed=33, max_matches=100)
+    assert np.array_equal(rc, want_rows[0])
+    # evaluate at a transform a little away from the one the rows were formed with (as the line search does)
+    T1 = synth.perturbed(pair.planted, 9, rot_deg=0.25, trans_mm=0.3)
+    norm = None
+    A1, t1, c1 = np.asarray(T1.A, float), np.asarray(T1.t, float), np.asarray(T1.c, float)
+    if normalize:
+        used = rc > 0
+        cmv = mv.loc[used].mean(axis=0)
+        tgt = np.unique(np.concatenate([ti[i, :rc[i]] for i in range(len(rc))]))
+        cfv = fx.loc[tgt].mean(axis=0)
+        rmv = np.linalg.norm(mv.loc[used] - cmv, axis=1).mean()
+        rfv = np.linalg.norm(fx.loc[tgt] - cfv, axis=1).mean()
+        norm = np.r_[cmv, rmv, cfv, rfv]
+        # the same statistics on the device (cdcl_normalize_matches over the one-to-many rows)
+        assert np.allclose(S.normalize_stats(), norm, rtol=1e-12, atol=0.0)
+        # the transform in normalised coordinates (cdcl_trans_affine.txx:220-231, cdcl_trans_rigid3d.cxx:260-270)
+        A1 = (rmv / rfv) * A1
+        t1 = t1 / rfv + (A1 @ (cmv - c1)) / rmv - cfv / rfv
+        if dof == 12:
+            c1 = np.zeros(3)
+    # rows sorted the oracle's way so that both sides see the same (order-independent up to rounding) sums
+    f_o, g_o, rows_o = ob.cdc_obj_par(mv, fx, dof, A1, t1, c1, Ct, rc, ti, w, norm=norm)
+    f_d, g_d, rows_d = S.objective_par(dof, A1, t1, c1, Ct, norm=norm)
+    assert rows_d == rows_o == int((rc > 0).sum())
+    assert np.isfinite(f_d) and abs(f_d - f_o) <= 1e-10 * abs(f_o)
+    assert np.allclose(g_d, g_o, rtol=1e-8, atol=1e-10 * np.abs(g_o).max())
+    # the covariance objective (cdcl_obj_fun_cov::compute, cdcl/cdcl_obj_fun_cov.txx:42-134) over the same rows
+    xu = np.linalg.cholesky(Ct).T[np.triu_indices(dof)]
+    fc_o, gc_o, pairs_o = ob.cdc_obj_cov(mv, fx, dof, A1, t1, c1, xu, rc, ti, w, norm=norm)
+    fc_d, gc_d, pairs_d = S.objective_cov(dof, A1, t1, c1, xu, norm=norm)
+    assert pairs_d == pairs_o == int(rc.sum())
+    assert abs(fc_d - fc_o) <= 1e-10 * abs(fc_o)
+    assert np.allclose(gc_d, gc_o, rtol=1e-8, atol=1e-10 * np.abs(gc_o).max())
+    fc_v, gc_v, _ = S.objective_cov(dof, A1, t1, c1, xu, norm=norm, want_grad=False)
+    assert gc_v is None and fc_v == fc_d
+    # value only
+    f_v, g_v, _ = S.objective_par(dof, A1, t1, c1, Ct, norm=norm, want_grad=False)
+    assert g_v is None and f_v == f_d
+    # deterministic
+    f_2, g_2, _ = S.objective_par(dof, A1, t1, c1, Ct, norm=norm)
+    assert f_2 == f_d and np.array_equal(g_2, g_d)
+    # the gradient is the derivative of the value (affine: the parameters are A row-major, then t)
+    if dof == 12 and not normalize:
+        x0 = np.r_[A1.ravel(), t1]
+        num = np.zeros(12)
+        for k in range(12):
+            h = 1e-6
+            xp, xm = x0.copy(), x0.copy()
+            xp[k] += h
+            xm[k] -= h
+            fp = S.objective_par(12, xp[:9].reshape(3, 3), xp[9:], c1, Ct, want_grad=False)[0]
+            fm = S.objective_par(12, xm[:9].reshape(3, 3), xm[9:], c1, Ct, want_grad=False)[0]
+            num[k] = (fp - fm) / (2 * h)
+        assert np.abs(num - g_d).max() <= 1e-6 * np.abs(g_d).max()
+    S.close()
+    cm.close()
+    cf.close()

@@ -114,3 +114,76 @@ def test_voronoi_volume_lookup_against_numpy(oracle_lib):
     got = ob.nn(loc, q, ob.NN_VORONOI)
     assert np.array_equal(got, want)
     assert 0 not in got
+
+
+@pytest.mark.parametrize("dof", [12, 6])
+def test_cdc_objective_gradient_is_the_derivative_of_the_value(dof):
+    """cdcl_obj_fun_par::compute (cdcl/cdcl_obj_fun_par.txx:44-142) as the oracle restates it: the analytic gradient
+    (2 J_th^T C_ij^-1 e and the two correction terms of d C_ij / d theta) equals central differences of the value in
+    the transform's parameters (affine: A row-major, t; rigid: the small-angle vector of R = I + [w]x, t)."""
+    import dataclasses
+    from lrr_amd import synth
+    n = 700
+    pair = synth.make_pair(n, n - 100, 717, kind="rigid" if dof == 6 else "affine", extent=40.0)
+    mv = dataclasses.replace(pair.moving, cov=synth.covariances(pair.moving))
+    fx = dataclasses.replace(pair.fixed, cov=synth.covariances(pair.fixed))
+    T0 = synth.perturbed(pair.planted, 5, rot_deg=0.3, trans_mm=0.4)
+    rng = np.random.default_rng(2)
+    B = rng.normal(size=(dof, dof)) * 2e-3
+    B[(9 if dof == 12 else 3):] *= 50.0
+    Ct = B @ B.T
+    rc, ti, w = ob.cdc_compute_weights(mv, fx, dof, T0.A, T0.t, T0.c, Ct, seed=33, max_matches=100)
+    assert rc.sum() > 1000
+
+    def skew(v):
+        return np.array([[0.0, -v[2], v[1]], [v[2], 0.0, -v[0]], [-v[1], v[0], 0.0]])
+
+    if dof == 12:
+        x0 = np.r_[np.asarray(T0.A, float).ravel(), T0.t]
+        unpack = lambda x: (x[:9].reshape(3, 3), x[9:])
+    else:
+        x0 = np.r_[0.004, -0.003, 0.002, T0.t]   # set_parameterization: R = I + [w]x (cdcl_trans_rigid3d.cxx:140-166)
+        unpack = lambda x: (np.eye(3) + skew(x[:3]), x[3:])
+    A0, t0 = unpack(x0)
+    f, g, rows = ob.cdc_obj_par(mv, fx, dof, A0, t0, T0.c, Ct, rc, ti, w)
+    assert rows == int((rc > 0).sum()) and np.isfinite(f)
+    num = np.zeros(dof)
+    for k in range(dof):
+        h = 1e-6
+        xp, xm = x0.copy(), x0.copy()
+        xp[k] += h
+        xm[k] -= h
+        fp = ob.cdc_obj_par(mv, fx, dof, *unpack(xp), T0.c, Ct, rc, ti, w, want_grad=False)[0]
+        fm = ob.cdc_obj_par(mv, fx, dof, *unpack(xm), T0.c, Ct, rc, ti, w, want_grad=False)[0]
+        num[k] = (fp - fm) / (2 * h)
+    assert np.abs(num - g).max() <= 1e-6 * np.abs(g).max()
+
+
+@pytest.mark.parametrize("dof", [12, 6])
+def test_cdc_covariance_objective_gradient_is_the_derivative_of_the_value(dof):
+    """cdcl_obj_fun_cov::compute (cdcl/cdcl_obj_fun_cov.txx:42-134) as the oracle restates it: the gradient in the entries
+    of the Cholesky factor of the parameter covariance equals central differences of the value."""
+    import dataclasses
+    from lrr_amd import synth
+    n = 600
+    pair = synth.make_pair(n, n - 100, 717, kind="rigid" if dof == 6 else "affine", extent=40.0)
+    mv = dataclasses.replace(pair.moving, cov=synth.covariances(pair.moving))
+    fx = dataclasses.replace(pair.fixed, cov=synth.covariances(pair.fixed))
+    T0 = synth.perturbed(pair.planted, 5, rot_deg=0.3, trans_mm=0.4)
+    rng = np.random.default_rng(2)
+    B = rng.normal(size=(dof, dof)) * 2e-3
+    B[(9 if dof == 12 else 3):] *= 50.0
+    Ct = B @ B.T
+    rc, ti, w = ob.cdc_compute_weights(mv, fx, dof, T0.A, T0.t, T0.c, Ct, seed=33, max_matches=100)
+    x0 = np.linalg.cholesky(Ct).T[np.triu_indices(dof)]
+    f, g, pairs = ob.cdc_obj_cov(mv, fx, dof, T0.A, T0.t, T0.c, x0, rc, ti, w)
+    assert pairs == int(rc.sum()) and np.isfinite(f)
+    h = 1e-6 * np.abs(x0).max()
+    num = np.zeros_like(x0)
+    for k in range(len(x0)):
+        xp, xm = x0.copy(), x0.copy()
+        xp[k] += h
+        xm[k] -= h
+        num[k] = (ob.cdc_obj_cov(mv, fx, dof, T0.A, T0.t, T0.c, xp, rc, ti, w, want_grad=False)[0]
+                  - ob.cdc_obj_cov(mv, fx, dof, T0.A, T0.t, T0.c, xm, rc, ti, w, want_grad=False)[0]) / (2 * h)
+    assert np.abs(num - g).max() <= 1e-6 * np.abs(g).max()
