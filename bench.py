@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--no-schedule", action="store_true", help="skip the faithful 1000 -> N schedule run")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on fewer GPUs)")
-    ap.add_argument("--workload", choices=["c3", "locations"], default="c3",
-                    help="c3: the BASELINE metric (default); locations: config 5, independent query locations sharded over the ranks")
+    ap.add_argument("--workload", choices=["c3", "locations", "cdc"], default="c3",
+                    help="c3: the BASELINE metric (default); locations: config 5, independent query locations sharded over the ranks; "
+                         "cdc: the covariance-driven EM step (SURVEY 8(f)4): E-step + the M-step's objective evaluations, one GPU")
     ap.add_argument("--locations", type=int, default=256)
     ap.add_argument("--workers", type=int, default=4, help="host threads (device contexts) per rank in the sequential locations workload")
     ap.add_argument("--locations-mode", choices=["batch", "sequential"], default="batch",
@@ -256,6 +257,90 @@ def bench_locations(args, rank, local_rank, world):
         dist.destroy_process_group()
 
 
+def bench_cdc(args):
+    """one EM step of cdcl_estimation on n x n features with covariances — compute_weights (E-step), then what
+    the two L-BFGS calls of the M-step evaluate (five objective + gradient evaluations each, cdcl/cdcl_estimation.txx:230-239,
+    298-304) — device time by HIP events, the CPU oracle on a bounded sample beside it."""
+    import dataclasses
+    from lrr_amd import estimation as E
+    from lrr_amd import synth
+    n, dof, mm = args.n, 12, 100
+    pair = synth.make_pair(n, n, 20246, kind="affine")
+    mv = dataclasses.replace(pair.moving, cov=synth.covariances(pair.moving))
+    fx = dataclasses.replace(pair.fixed, cov=synth.covariances(pair.fixed))
+    T0 = synth.perturbed(pair.planted, 5, rot_deg=0.3, trans_mm=0.4)
+    rng = np.random.default_rng(2)
+    B = rng.normal(size=(dof, dof)) * 2e-3
+    B[9:] *= 50.0
+    Ct = B @ B.T
+    xu = np.linalg.cholesky(Ct).T[np.triu_indices(dof)]
+    cm, cf = E.DeviceCloud(mv), E.DeviceCloud(fx)
+    cm.set_covariances(mv.cov)
+    cf.set_covariances(fx.cov)
+    S = E.CdcSet(cm, cf, max_matches=mm)
+    timer = E.DeviceTimer()
+    S.compute_weights(dof, T0.A, T0.t, T0.c, Ct, seed=33)  # warm-up
+    S.objective_par(dof, T0.A, T0.t, T0.c, Ct)
+    S.objective_cov(dof, T0.A, T0.t, T0.c, xu)
+
+    def timed(fn, reps):
+        out = []
+        for _ in range(reps):
+            timer.synchronize()
+            timer.start()
+            fn()
+            out.append(timer.stop())
+        return float(np.median(out))
+
+    reps = max(1, args.reps)
+    e_ms = timed(lambda: S.compute_weights(dof, T0.A, T0.t, T0.c, Ct, seed=33), reps)
+    norm = S.normalize_stats()
+    n_ms = timed(lambda: S.normalize_stats(), reps)
+    p_ms = timed(lambda: S.objective_par(dof, T0.A, T0.t, T0.c, Ct), reps)
+    c_ms = timed(lambda: S.objective_cov(dof, T0.A, T0.t, T0.c, xu), reps)
+    rc, ti, w = S.rows()
+    pairs = int(rc.sum())
+    step_ms = e_ms + n_ms + 5 * p_ms + 5 * c_ms
+    out = {"metric": "CDC-EM matched pairs/s (one EM step: E-step + 5 + 5 objective evaluations)", "value": pairs / (step_ms * 1e-3),
+           "unit": "pairs/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"{n}x{n} synthetic 3-D features with covariances, cdcl_estimation<3,12> EM step, <= {mm} matches per moving feature",
+                      "pairs": pairs, "rows": int((rc > 0).sum()), "mean_matches_per_row": float(rc[rc > 0].mean())},
+           "device_ms": {"compute_weights": e_ms, "normalize_stats": n_ms, "objective_par": p_ms, "objective_cov": c_ms},
+           "roofline": {"bound": "hbm", "kernel": "k_cdc_obj<12> (cdcl_obj_fun_par::compute): per pair 4 B index + 8 B weight + 32 B point + 72 B covariance, gathered",
+                        "achieved": pairs * 116.0 / (p_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": pairs * 116.0 / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": p_ms,
+                        "algorithmic_bytes_per_launch": pairs * 116.0},
+           "repetitions": reps}
+    if not args.no_cpu_baseline:
+        from oracle import binding as ob
+        ns = min(2000, n)  # the oracle's radius search is brute force: a sample of the moving set against the whole fixed set
+        sub = mv.subset(np.arange(ns))
+        t0 = time.perf_counter()
+        orc, oti, ow = ob.cdc_compute_weights(sub, fx, dof, T0.A, T0.t, T0.c, Ct, seed=33, max_matches=mm)
+        te = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ob.cdc_obj_par(sub, fx, dof, T0.A, T0.t, T0.c, Ct, orc, oti, ow)
+        tp = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ob.cdc_obj_cov(sub, fx, dof, T0.A, T0.t, T0.c, xu, orc, oti, ow)
+        tc = (time.perf_counter() - t0) / 3
+        op = int(orc.sum())
+        cpu_step = te + 5 * tp + 5 * tc
+        out["cpu_baseline"] = {"value": op / cpu_step, "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"the first {ns} moving features against all {n} fixed ones ({op} pairs): E-step {te:.2f} s (brute-force radius "
+                                         f"search, the oracle's stand-in for the kd-tree), objective_par {1e3 * tp:.1f} ms, objective_cov {1e3 * tc:.1f} ms",
+                               "objective_par_pairs_per_s": op / tp, "objective_cov_pairs_per_s": op / tc}
+        out["device_objective_par_pairs_per_s"] = pairs / (p_ms * 1e-3)
+        out["device_objective_cov_pairs_per_s"] = pairs / (c_ms * 1e-3)
+    print(json.dumps(out))
+    S.close()
+    cm.close()
+    cf.close()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -279,6 +364,10 @@ def main():
     E.set_device(local_rank)
     if args.workload == "locations":
         return bench_locations(args, rank, local_rank, world)
+    if args.workload == "cdc":
+        if world > 1:
+            raise SystemExit("--workload cdc is a one-GPU measurement")
+        return bench_cdc(args)
     n = args.n
     # independent problem per rank: same surfaces family, different seed
     pair = synth.make_pair(n, n, 20243 + rank, kind="affine")

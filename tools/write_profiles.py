@@ -89,7 +89,7 @@ r["valu_frac"] = valu_frac
 b["_note"] = ("traffic / valu_frac fields filled from the PMC passes of the same measurement set (profiles/pmc_traffic.json, "
               "profiles/pmc_utilisation.json); the line as printed carried null for them")
 json.dump(b, open(f"profiles/{out}_bench.json", "w"))
-for extra in ("locations", "bench_2m"):
+for extra in ("locations", "bench_2m", "cdc"):
     if os.path.exists(f"{G}/{extra}.json"):
         open(f"profiles/{out}_{extra}.json", "w").write(open(f"{G}/{extra}.json").read())
 with open(f"profiles/{out}_kernel_stats.csv", "w") as o:
