@@ -1366,13 +1366,16 @@ __device__ __forceinline__ void match_cert_inline_body(const BallArgs &A) {
     todo &= todo - 1ull;
     const int qs = __shfl(s, l, 64), qprev = __shfl(prev, l, 64);
     const double qx = __shfl(yx, l, 64), qy = __shfl(yy, l, 64), qz = __shfl(yz, l, 64);
-    if (qprev < 0) {  // (no source is without a match once bounds exist; kept for completeness: the wave-per-query kernel's list)
-      if (lane == 0) { A.hard[atomicAdd(A.hard_count, 1)] = qs; A.d2lb[qs] = 0.0f; }
-      continue;
-    }
     Best b;
     double second = INFINITY;
-    wave_ball_prev(A.g, A.to_pt, seg_s, seg_pre, wv, lane, qx, qy, qz, qprev, b, second);
+    if (qprev < 0) {
+      // no source is without a match once bounds exist (this kernel runs only then); should one be, the wavefront scans
+      // the whole target cloud as ONE run: exact, slow, and no other kernel has to follow this one
+      b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
+      wave_scan_runs(A.g, seg_s, seg_pre, wv, lane, 0, lane == 0 ? A.g.n : 0, qx, qy, qz, b, -1, second);
+    } else {
+      wave_ball_prev(A.g, A.to_pt, seg_s, seg_pre, wv, lane, qx, qy, qz, qprev, b, second);
+    }
     if (lane == 0) { A.m_to[qs] = b.canon; A.d2lb[qs] = second_bound(b.d, second, A.g.h); }
   }
 }
