@@ -144,6 +144,8 @@ struct lrr_icp_ctx {
   double *d_fused = nullptr;     // P1..P6 partial tables + the fused output block
   double *h_fused = nullptr, *h_fused_dev = nullptr;
   std::vector<double> fused_vals;  // the values of the last tagged result set (wait_chunks)
+  double *d_muse = nullptr;        // gathered keys of a coarse list (lrr_icp_muse_scale)
+  size_t muse_cap = 0;
   // completion word of the reduce kernels (mapped host memory) and their last-block counter
   unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr, seq = 0;
   // block rows of k_errors, written by the blocks themselves: kWideBlocks rows of 8 doubles {s0, tag, s1, tag, s2, tag, -, -}
@@ -1449,17 +1451,21 @@ __global__ void k_slots_sparse(const int *order, int use_keys, Keys keys, int ha
 // Coarse levels of a symmetric estimator (a few thousand of the sources active): every active source goes straight
 // to the wave-per-query kernel — a thousand queries are a thousand wavefronts, each scanning its candidates with 64
 // lanes, where the thread-per-slot ring search walks them one dependent round at a time.  This kernel assigns the
-// list positions of both directions and writes the two work lists (and their lengths).
-struct CoarseArgs { Keys keys; int half, nsrc, n; const int *canon_of; int *slot; double *w; int *list, *list_count; };
+// list positions of both directions and writes the two work lists: a thread per SOURCE inverts the keyed permutation
+// for its own feature (position < n: active), so every slot is written — nothing has to be cleared first — and the
+// active ones are appended to the work list (its order is the order of the work, not of the matches).
+struct CoarseArgs { const SrcPoint *src; Keys keys; int half, nsrc, n; int *slot; double *w; int *list, *list_count; };
 __global__ void k_slots_coarse2(CoarseArgs A, CoarseArgs B) {
   const CoarseArgs &C = blockIdx.y == 0 ? A : B;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *C.list_count = C.n;
-  if (i >= C.n) return;
-  int s = C.canon_of[subset_perm(i, C.nsrc, C.half, C.keys)];
-  C.slot[s] = i;
-  C.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-  C.list[i] = s;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= C.nsrc) return;
+  const int j = subset_perm_inv((int)C.src[s].orig, C.nsrc, C.half, C.keys);
+  const bool active = j < C.n;
+  C.slot[s] = active ? j : -1;
+  if (active) {
+    C.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
+    C.list[atomicAdd(C.list_count, 1)] = s;
+  }
 }
 
 // All-vs-all matcher: each block owns kBlock*Q queries (Q per thread, in registers) and streams
@@ -1753,6 +1759,14 @@ __global__ void k_copy_w(const double *src, double *dst, int n) {
 // matches_ in the reference's list order: (original from index, original to index, weight)
 // Voronoi-lookup search: the matches of the active sources are canonical indices of the SITE cloud (occupied
 // voxels); each site carries the feature whose index the reference's volume stores in that voxel
+// the keys of a list's active sources, gathered by list position (a bijection onto [0, n): no atomics, fixed layout)
+__global__ void k_compact_by_slot(const int *slot, const double *key, int nsrc, double *dense) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsrc) return;
+  const int j = slot[s];
+  if (j >= 0) dense[j] = key[s];
+}
+
 __global__ void k_vor_remap(const int *slot, int *m_to, const int *site_to_feature, int nsrc) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < nsrc && slot[s] >= 0) m_to[s] = site_to_feature[m_to[s]];
@@ -3720,6 +3734,7 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->h_fused) (void)hipHostFree(ctx->h_fused);
   if (ctx->h_seq) (void)hipHostFree(ctx->h_seq);
   if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
+  if (ctx->d_muse) (void)hipFree(ctx->d_muse);
   if (ctx->d_done) (void)hipFree(ctx->d_done);
   if (ctx->d_cert_stats) (void)hipFree(ctx->d_cert_stats);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -4352,14 +4367,12 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     if ((rc = match_prepare(f, xf_f, keys_f, order_f, n_f, method, ctx->lane[0], st, Pf))) return rc;
     if ((rc = match_prepare(b, xf_b, keys_b, order_b, n_b, method, ctx->lane[1], st, Pb))) return rc;
     ProfScope prof(ctx, st, 2);
-    HIPCHK(ctx, hipMemsetAsync(f->slot, 0xff, sizeof(int) * f->cap, st));
-    HIPCHK(ctx, hipMemsetAsync(b->slot, 0xff, sizeof(int) * b->cap, st));
     CoarseArgs cf, cb;
-    cf.keys = Pf.kk; cf.half = Pf.half; cf.nsrc = (int)Pf.N; cf.n = (int)n_f; cf.canon_of = f->from->canon_of; cf.slot = f->slot; cf.w = f->w;
+    cf.src = f->from->src; cf.keys = Pf.kk; cf.half = Pf.half; cf.nsrc = (int)Pf.N; cf.n = (int)n_f; cf.slot = f->slot; cf.w = f->w;
     cf.list = ctx->lane[0].d_hard; cf.list_count = Pf.counts;
-    cb.keys = Pb.kk; cb.half = Pb.half; cb.nsrc = (int)Pb.N; cb.n = (int)n_b; cb.canon_of = b->from->canon_of; cb.slot = b->slot; cb.w = b->w;
+    cb.src = b->from->src; cb.keys = Pb.kk; cb.half = Pb.half; cb.nsrc = (int)Pb.N; cb.n = (int)n_b; cb.slot = b->slot; cb.w = b->w;
     cb.list = ctx->lane[1].d_hard; cb.list_count = Pb.counts;
-    hipLaunchKernelGGL(k_slots_coarse2, dim3(blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, cf, cb);
+    hipLaunchKernelGGL(k_slots_coarse2, dim3(blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBlock), 0, st, cf, cb);
     HIPCHK(ctx, hipGetLastError());
     HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);
     HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
@@ -4449,6 +4462,22 @@ int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
   struct Cand { int64_t k; double ek, sd, div; };
   std::vector<Cand> cands;
   std::vector<SelJob> jobs;
+  // a coarse level's list: its few keys are gathered first, so the selections sweep n keys instead of the whole cloud's
+  // array (mostly +inf for the inactive sources) — the first estimate of a run dropped from 0.4 ms to microseconds per list
+  const double *keys = d->key_s;
+  int nkeys = (int)d->from->n;
+  if (n * 4 < d->from->n && !d->slot_lazy) {
+    if ((size_t)n > ctx->muse_cap) {
+      if (ctx->d_muse) (void)hipFree(ctx->d_muse);
+      ctx->d_muse = nullptr; ctx->muse_cap = 0;
+      HIPCHK(ctx, hipMalloc(&ctx->d_muse, sizeof(double) * (size_t)n));
+      ctx->muse_cap = (size_t)n;
+    }
+    hipLaunchKernelGGL(k_compact_by_slot, dim3(blocks_for(d->from->n)), dim3(kBlock), 0, ctx->stream, d->slot, d->key_s, (int)d->from->n, ctx->d_muse);
+    HIPCHK(ctx, hipGetLastError());
+    keys = ctx->d_muse;
+    nkeys = (int)n;
+  }
   for (double frac = 0.25; frac <= 0.95 + 0.00001; frac += 0.05) {
     int64_t k = (int64_t)std::floor(frac * (double)n + 0.5);
     if (k > n) k = n;
@@ -4464,7 +4493,7 @@ int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
     double div = (double)(n + 1) * std::sqrt(2.0 / M_PI) * (1.0 - std::exp(-Qk * Qk / 2.0));
     cands.push_back({k, Qk, sd, div});
     // keys of inactive sources are +inf and sort last
-    jobs.push_back(make_job(d->key_s, (int)d->from->n, nullptr, 0, k - 1, n));
+    jobs.push_back(make_job(keys, nkeys, nullptr, 0, k - 1, n));
   }
   std::vector<double> res(4 * jobs.size() + 4);
   int rc = run_select(ctx, jobs, res.data(), true);
