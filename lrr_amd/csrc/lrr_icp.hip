@@ -1453,19 +1453,21 @@ __global__ void k_slots_sparse(const int *order, int use_keys, Keys keys, int ha
 // to the wave-per-query kernel — a thousand queries are a thousand wavefronts, each scanning its candidates with 64
 // lanes, where the thread-per-slot ring search walks them one dependent round at a time.  This kernel assigns the
 // list positions of both directions and writes the two work lists: a thread per SOURCE inverts the keyed permutation
-// for its own feature (position < n: active), so every slot is written — nothing has to be cleared first — and the
-// active ones are appended to the work list (its order is the order of the work, not of the matches).
+// for its own feature (position < n: active), so every slot is written — nothing has to be cleared first — and an
+// active source enters the work list AT its list position (a bijection onto [0, n): no counter.  Appending through one
+// atomic counter, even once per wavefront, cost 30 us: same-address atomics serialise in the L2).
 struct CoarseArgs { const SrcPoint *src; Keys keys; int half, nsrc, n; int *slot; double *w; int *list, *list_count; };
 __global__ void k_slots_coarse2(CoarseArgs A, CoarseArgs B) {
   const CoarseArgs &C = blockIdx.y == 0 ? A : B;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s == 0) *C.list_count = C.n;
   if (s >= C.nsrc) return;
   const int j = subset_perm_inv((int)C.src[s].orig, C.nsrc, C.half, C.keys);
   const bool active = j < C.n;
   C.slot[s] = active ? j : -1;
   if (active) {
     C.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-    C.list[atomicAdd(C.list_count, 1)] = s;
+    C.list[j] = s; // the list position is a bijection onto [0, n): no counter, no atomics
   }
 }
 
