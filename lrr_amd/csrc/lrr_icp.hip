@@ -207,6 +207,7 @@ struct lrr_icp_dir {
   int64_t cap = 0;   // allocated length of the per-source arrays (>= from->n)
   int64_t n = 0;     // active matches
   int64_t prev_n = -1;  // subset size of the last grid match on this source cloud (-1: none): m_to is a valid bound for those
+  int64_t searches = 0; // grid searches on this source cloud so far (m_to holds the last match of every source ever active)
   int *slot = nullptr;   // list position of source s, -1 when s is not in the active subset
   int *m_to = nullptr;   // canonical target index
   double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
@@ -4078,6 +4079,7 @@ int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
   d->from = from;
   d->n = 0;
   d->prev_n = -1;
+  d->searches = 0;
   d->have_bounds = false;
   d->slot_lazy = false;
   d->from_is_copy = 0;
@@ -4200,9 +4202,9 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   // target is a valid bound for the ball search, a recent one a tight bound), the new ones go to the wave-per-query
   // and brute-force phases — cheaper than the tile kernel's search from scratch (135-160 -> 75-90 us per direction)
   static const bool tile_on_growth = std::getenv("LRR_ICP_TILE_ON_GROWTH") != nullptr;
-  P.growth = !tile_on_growth && P.method == LRR_ICP_NN_GRID && P.dense && d->prev_n > 0 && d->prev_n != n_points;
+  P.growth = !tile_on_growth && P.method == LRR_ICP_NN_GRID && P.dense && d->searches > 0 && d->prev_n != n_points;
   P.steady = P.method == LRR_ICP_NN_GRID && P.dense && (d->prev_n == n_points || P.growth);
-  if (P.method == LRR_ICP_NN_GRID) d->prev_n = P.dense ? n_points : -1;
+  if (P.method == LRR_ICP_NN_GRID) { d->prev_n = P.dense ? n_points : -1; ++d->searches; }
   // bounds are per source and refer to the transform of the search that wrote them: usable only when that
   // search covered every source (n_points == N twice in a row)
   static const bool no_cert = std::getenv("LRR_ICP_NO_CERT") != nullptr;
@@ -4312,7 +4314,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
   // Later iterations of a level (both directions in the ball-search state): every phase handles both
   // directions in ONE launch on the main stream (blockIdx.y = direction) — no fork/join at all.
   const bool both_steady = method != LRR_ICP_NN_BRUTE && method != LRR_ICP_NN_VORONOI && !order_f && !order_b && n_f > 0 && n_b > 0 &&
-                           n_f * 4 >= f->from->n && n_b * 4 >= b->from->n && f->prev_n > 0 && b->prev_n > 0;
+                           n_f * 4 >= f->from->n && n_b * 4 >= b->from->n && f->searches > 0 && b->searches > 0;
   if (both_steady) {
     MatchPrep Pf, Pb;
     hipStream_t st = ctx->stream;
