@@ -363,12 +363,22 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
   virtual bool one_iteration(void *caller, display_callback_type display_points, unsigned int iteration) {
     this->find_closest_euclidean();
     if (caller && display_points) display_points(caller, moving_[res_], fixed_[res_], this->matches(), trans_, iteration);
-    double RMS_before = this->RMS_error();
+    // RMS_before is needed only for the test at the end: its kernel is queued here, in the reference's place, and its
+    // sums are collected after the estimate (the device runs the two back to back, the host waits once)
+    lrr_icp_xform xf_before = xform_of(trans_);
+    check(lrr_icp_errors_launch(dir_, &xf_before), "error metrics");
     trans_sptr_type global_transform;
     const bool rigid = is_rigid();
     if (rigid) global_transform = begin_rigid_increment();
     this->estimate_LS(true);
     if (rigid) end_rigid_increment(global_transform);
+    double RMS_before = 0.0;
+    {
+      double s2 = 0, swr = 0, sw = 0;
+      check(lrr_icp_errors_collect(dir_, &s2, &swr, &sw), "error metrics");
+      int64_t count = lrr_icp_dir_num_matches(dir_);
+      RMS_before = RRL ? s2 : (count != 0 ? std::sqrt(s2 / double(count)) : s2);
+    }
     // NB rigid: from_ are still the pre-mapped copies, so they are mapped twice here, as in
     // the reference (cdcl .txx:499 against :477)
     double RMS_after = this->RMS_error();
@@ -517,6 +527,12 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     scale_estimated_ = true;
     last_scale_ = r.sigma_f;
     touch();
+    norm_ = identity_norm();
+    // affine transform, normalised, parameters estimated: normalize() -> solve -> unnormalize() without the dense
+    // products whose results the solution overwrites (affine_forward_update: same operations, same bits)
+    for (unsigned i = 0; i < dof * dof; ++i) last_AtA_[i] = r.AtA[i];
+    for (unsigned i = 0; i < dof; ++i) last_Atb_[i] = r.Atb[i];
+    if (normalize_matches_ && estimate_parameters && affine_shortcut<dof>::apply(trans_, r)) return;
     vec3 cm(0.0), cf(0.0);
     double rm = 0.0, rf = 0.0;
     if (normalize_matches_) {
@@ -527,7 +543,6 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     }
     solve_and_set(trans_, r.AtA, r.Atb, estimate_parameters);
     if (normalize_matches_) trans_->unnormalize(rm, rf, cm, cf);
-    norm_ = identity_norm();
   }
   // the same estimate step by step through the granular C-ABI calls (each with its own host round trip)
   void estimate_LS_stepwise(bool estimate_parameters = false) {

@@ -161,6 +161,10 @@ int  lrr_icp_accumulate(lrr_icp_dir *dir, int dof, const double jac_centre[3],
  * sum_r2 = sum r2_i, sum_wr = sum sqrt(r2_i) w_i, sum_w = sum w_i */
 int  lrr_icp_errors(lrr_icp_dir *dir, const lrr_icp_xform *xf, double *sum_r2, double *sum_wr,
                     double *sum_w);
+/* the same in two halves: launch queues the kernel and returns, collect waits for its sums; other work may be queued on the
+ * context in between (one launch outstanding per context: a second launch first completes the first) */
+int  lrr_icp_errors_launch(lrr_icp_dir *dir, const lrr_icp_xform *xf);
+int  lrr_icp_errors_collect(lrr_icp_dir *dir, double *sum_r2, double *sum_wr, double *sum_w);
 
 /* ---- post-convergence diagnostics (the verifier's inputs, rrl/itkLocationRegistration.cxx:1816-1871) --
  * shapes and directions of a cloud's features: shape[i] in {0 CORNER, 1 TUBE, 2 SHEET}

@@ -150,6 +150,9 @@ struct lrr_icp_ctx {
   unsigned long long *h_seq = nullptr, *h_seq_dev = nullptr, seq = 0;
   // block rows of k_errors, written by the blocks themselves: kWideBlocks rows of 8 doubles {s0, tag, s1, tag, s2, tag, -, -}
   double *h_rows = nullptr, *h_rows_dev = nullptr;
+  struct lrr_icp_dir *err_pending = nullptr;  // the direction whose k_errors rows are on their way (lrr_icp_errors_launch)
+  double err_tag = 0.0;
+  int err_nb = 0;
   int *d_done = nullptr;
   unsigned long long *d_cert_stats = nullptr;  // {queries, searched} of the certificate kernel
   // K1 scratch: one set per submission lane.  Lane 0 runs on `stream`; lane 1 has its own stream so
@@ -230,6 +233,8 @@ struct lrr_icp_dir {
   const int *cert_list_count = nullptr;
   int last_list_count = -1;
   bool cert_inline = false;  // the last search was k_match_cert_inline2: its statistics are added on the host
+  double err_stash[3] = {0.0, 0.0, 0.0};  // error sums collected on this direction's behalf (lrr_icp_errors_collect)
+  bool err_stashed = false;
 };
 
 namespace {
@@ -1383,6 +1388,7 @@ __device__ __forceinline__ void match_cert_inline_body(const BallArgs &A) {
     if (lane == 0) { A.m_to[qs] = b.canon; A.d2lb[qs] = second_bound(b.d, second, A.g.h); }
   }
 }
+__global__ __launch_bounds__(kCertBlock) void k_match_cert_inline(BallArgs A) { match_cert_inline_body(A); }
 __global__ __launch_bounds__(kCertBlock) void k_match_cert_inline2(BallArgs A, BallArgs B) {
   if (blockIdx.y == 0) match_cert_inline_body(A);
   else match_cert_inline_body(B);
@@ -3010,33 +3016,70 @@ __global__ __launch_bounds__(kWide) void k_fw_residual(DirArgs F, FwdOpts o, XfD
   block_reduce_store<2, kWide / 64>(acc, P1);
 }
 
-// FW2: scale, Beaton-Tukey weights (cdcl .txx:736-822), strength gain and its key (cdcl .txx:826-862)
+// FW2: scale, Beaton-Tukey weights (cdcl .txx:736-822), strength gain and its key (cdcl .txx:826-862).
+// FOLD: the first half of the strength keys' order statistic rides along, as in k_f_weights (one job, state slot 8).
+template <bool FOLD>
 __global__ __launch_bounds__(kWide) void k_fw_weights(DirArgs F, FwdOpts o, const double *P1, int nb1, double *SC,
-                                                       double *P4) {
+                                                       double *P4, FoldArgs fo) {
+  __shared__ unsigned long long stage[FOLD ? kFoldStage : 1];
+  __shared__ int nstage, gpos;
+  // loads that do not depend on the block sums first: the selection window and this thread's first batch
+  constexpr int U = kStreamBatch;
+  const int stride = gridDim.x * kWide;
+  double lo_g = INFINITY, hi_g = INFINITY, below[2] = {0.0, 0.0};
+  if (FOLD) {
+    const double vg = fo.prev[8], dg = fo.win[8];
+    if (vg > 0.0 && vg < INFINITY) { lo_g = vg * (1.0 - dg); hi_g = vg * (1.0 + dg); }
+    if (threadIdx.x == 0) nstage = 0;
+  }
   double tot[2] = {0.0, 0.0};
-  if (o.mode == LRR_ICP_SCALE_RMS)
-    for (int b = threadIdx.x; b < nb1; b += kWide) { tot[0] += P1[(size_t)b * 2]; tot[1] += P1[(size_t)b * 2 + 1]; }
-  block_sum_all<2, kWide / 64>(tot);
+  if (o.mode == LRR_ICP_SCALE_RMS && (int)threadIdx.x < nb1) { tot[0] = P1[(size_t)threadIdx.x * 2]; tot[1] = P1[(size_t)threadIdx.x * 2 + 1]; }
+  block_sum_all<2, kWide / 64>(tot);  // (its barriers also publish nstage)
   const double scale = o.mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : o.injected;
   if (blockIdx.x == 0 && threadIdx.x == 0) SC[SC_SIGF] = scale;
   const double scale2 = scale * scale;
   double acc[1] = {0.0};
-  for (int s = blockIdx.x * kWide + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kWide) {
-    if (F.ps.slot[s] < 0) { F.key_g[s] = INFINITY; continue; }
-    double u = F.r2[s] / scale2, bt = 0.0;
-    if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
-    double wi = bt / scale2;
-    double key = INFINITY;
-    if (o.strength && wi != 0) {
-      const double g = F.key_g[s];
-      wi = wi * g;
-      key = g;
-      acc[0] += 1.0;
+  for (int s0 = blockIdx.x * kWide + threadIdx.x; s0 < F.ps.nsrc; s0 += U * stride) {
+    int sl[U];
+    double r2v[U], gv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * stride;
+      sl[u] = -2; r2v[u] = 0.0; gv[u] = 0.0;
+      if (s < F.ps.nsrc) { sl[u] = F.ps.slot[s]; r2v[u] = F.r2[s]; gv[u] = F.key_g[s]; }
     }
-    F.key_g[s] = key;
-    F.w[s] = wi;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u * stride;
+      if (sl[u] == -2) continue;
+      if (sl[u] < 0) { F.key_g[s] = INFINITY; continue; }
+      double uu = r2v[u] / scale2, bt = 0.0;
+      if (uu <= 16.0) { double temp = 1 - uu * 0.0625; bt = temp * temp; }
+      double wi = bt / scale2;
+      double key = INFINITY;
+      if (o.strength && wi != 0) {
+        const double g = gv[u];
+        wi = wi * g;
+        key = g;
+        acc[0] += 1.0;
+      }
+      F.key_g[s] = key;
+      if (FOLD) {
+        if (key < lo_g) below[0] += 1.0;
+        else if (key <= hi_g) { const int p = atomicAdd(&nstage, 1); if (p < kFoldStage) stage[p] = (unsigned long long)__double_as_longlong(key); }
+      }
+      F.w[s] = wi;
+    }
   }
   block_reduce_store<1, kWide / 64>(acc, P4);
+  if (FOLD) {
+    block_reduce_store<2, kWide / 64>(below, fo.P5);  // (its barriers also publish the staged keys)
+    if (threadIdx.x == 0) gpos = atomicAdd(&fo.cursor[0], nstage > kFoldStage ? kSelCap + 1 : nstage);
+    __syncthreads();
+    const int n = min(nstage, kFoldStage), p0 = gpos;
+    if (nstage <= kFoldStage && p0 + n <= kSelCap)
+      for (int k = threadIdx.x; k < n; k += kWide) fo.coll[p0 + k] = stage[k];
+  }
 }
 
 // FW3: final weights and the normal equations (cdcl .txx:1039-1069)
@@ -4065,7 +4108,7 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
 
 void lrr_icp_dir_destroy(lrr_icp_dir *d) {
   if (!d) return;
-  if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
+  if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); if (d->ctx->err_pending == d) d->ctx->err_pending = nullptr; }
   void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->flag, d->d2lb};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete d;
@@ -4253,6 +4296,13 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     }
     HIPCHK(ctx, hipGetLastError());
     return launch_brute(ctx, L, st, d->to, P.g, P.q, L.d_active, P.x, (int)n_points, d->m_to);
+  }
+  static const bool no_inline = std::getenv("LRR_ICP_NO_INLINE_CERT") != nullptr;
+  if (P.cert && P.inline_list && !no_inline) {  // a short list last time: the certificate kernel serves its failures itself
+    hipLaunchKernelGGL(k_match_cert_inline, dim3(cert_blocks_for(N)), dim3(kCertBlock), 0, st, ball_args(d, P, L));
+    HIPCHK(ctx, hipGetLastError());
+    d->cert_inline = true;
+    return LRR_ICP_OK;
   }
   if (P.cert) {
     BallArgs a = ball_args(d, P, L);
@@ -4731,41 +4781,70 @@ int lrr_icp_accumulate(lrr_icp_dir *d, int dof, const double jac_centre[3], cons
   return LRR_ICP_OK;
 }
 
-int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, double *sum_wr, double *sum_w) {
-  if (!d || !xf) return LRR_ICP_ERR_ARG;
-  lrr_icp_ctx *ctx = d->ctx;
+// The error metrics in two halves: launch queues k_errors (its blocks store their rows in mapped host memory, tagged with
+// the submission's number) and returns; collect adds the rows in row order as they arrive (after 50 ms without them:
+// stream synchronisation, which also reports a failed kernel).  Between the two the caller may queue more work on the
+// context — the forward classes launch RMS_before, run the whole estimate, and collect it afterwards.  One launch is
+// outstanding per context: a second one first moves the first one's sums into its direction.
+static int errors_drain(lrr_icp_ctx *ctx) {
+  lrr_icp_dir *d = ctx->err_pending;
+  if (!d) return LRR_ICP_OK;
+  ctx->err_pending = nullptr;
+  const volatile double *rows = ctx->h_rows;
+  const double tag = ctx->err_tag;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool synced = false;
   double r[3] = {0.0, 0.0, 0.0};
-  if (d->n > 0) {
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    PairSrc ps = pairs_of(d);
-    int nb = grid_wide(ps.nsrc);
-    // the blocks write their rows into mapped host memory, tagged with this submission's number; the host adds them in
-    // row order as they arrive (after 50 ms without them: stream synchronisation, which also reports a failed kernel)
-    const unsigned long long seq = ++ctx->seq;
-    const double tag = seq_tag(seq);
-    hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kWide), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, ctx->d_partials, ctx->h_rows_dev, tag);
-    HIPCHK(ctx, hipGetLastError());
-    const volatile double *rows = ctx->h_rows;
-    const auto t0 = std::chrono::steady_clock::now();
-    bool synced = false;
-    for (int b = 0; b < nb; ++b) {
-      for (int k = 0; k < 3; ++k) {
-        unsigned spin = 0;
-        while (rows[8 * b + 2 * k + 1] != tag) {
-          if ((++spin & 1023u) != 0 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) continue;
-          if (synced) return fail(ctx, LRR_ICP_ERR_HIP, "error sums did not arrive");
-          HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-          synced = true;
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        r[k] += rows[8 * b + 2 * k];
+  for (int b = 0; b < ctx->err_nb; ++b) {
+    for (int k = 0; k < 3; ++k) {
+      unsigned spin = 0;
+      while (rows[8 * b + 2 * k + 1] != tag) {
+        if ((++spin & 1023u) != 0 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) continue;
+        if (synced) return fail(ctx, LRR_ICP_ERR_HIP, "error sums did not arrive");
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        synced = true;
       }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      r[k] += rows[8 * b + 2 * k];
     }
   }
-  if (sum_r2) *sum_r2 = r[0];
-  if (sum_wr) *sum_wr = r[1];
-  if (sum_w) *sum_w = r[2];
+  for (int k = 0; k < 3; ++k) d->err_stash[k] = r[k];
+  d->err_stashed = true;
   return LRR_ICP_OK;
+}
+
+int lrr_icp_errors_launch(lrr_icp_dir *d, const lrr_icp_xform *xf) {
+  if (!d || !xf) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  { int rc = errors_drain(ctx); if (rc) return rc; }
+  d->err_stashed = false;
+  if (d->n <= 0) { d->err_stash[0] = d->err_stash[1] = d->err_stash[2] = 0.0; d->err_stashed = true; return LRR_ICP_OK; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairSrc ps = pairs_of(d);
+  const int nb = grid_wide(ps.nsrc);
+  const unsigned long long seq = ++ctx->seq;
+  const double tag = seq_tag(seq);
+  hipLaunchKernelGGL(k_errors, dim3(nb), dim3(kWide), 0, ctx->stream, ps, to_dev(xf), to_dev((const lrr_icp_norm *)nullptr), d->w, ctx->d_partials, ctx->h_rows_dev, tag);
+  HIPCHK(ctx, hipGetLastError());
+  ctx->err_pending = d; ctx->err_tag = tag; ctx->err_nb = nb;
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_errors_collect(lrr_icp_dir *d, double *sum_r2, double *sum_wr, double *sum_w) {
+  if (!d) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  if (ctx->err_pending == d) { int rc = errors_drain(ctx); if (rc) return rc; }
+  if (!d->err_stashed) return fail(ctx, LRR_ICP_ERR_STATE, "errors_collect: no launch outstanding for this direction");
+  d->err_stashed = false;
+  if (sum_r2) *sum_r2 = d->err_stash[0];
+  if (sum_wr) *sum_wr = d->err_stash[1];
+  if (sum_w) *sum_w = d->err_stash[2];
+  return LRR_ICP_OK;
+}
+
+int lrr_icp_errors(lrr_icp_dir *d, const lrr_icp_xform *xf, double *sum_r2, double *sum_wr, double *sum_w) {
+  int rc = lrr_icp_errors_launch(d, xf);
+  return rc ? rc : lrr_icp_errors_collect(d, sum_r2, sum_wr, sum_w);
 }
 
 // the 12 x 12 normal matrix and right-hand side from the kKron sums of accumulate_pair_kron
@@ -5043,16 +5122,33 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   HIPCHK(ctx, hipGetLastError());
   // MUSE needs the sorted residuals: its tables and argmin stay on the host (first estimate only)
   if (fo.mode == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &fo.injected); if (rc) return rc; fo.mode = LRR_ICP_SCALE_INJECTED; }
-  hipLaunchKernelGGL(k_fw_weights, dim3(nbF), dim3(kWide), 0, st, aF, fo, P1, nbF, SC, P4);
+  // the order statistic rides along with the weight pass once the scale has settled (as in lrr_icp_estimate_symmetric)
+  const bool same = ctx->sel_dirs[0] == (const void *)F && ctx->sel_dirs[1] == nullptr && ctx->sel_n[0] == F->n;
+  if (!same) ctx->sel_runs = 0;
+  bool fold = o->strength && same && ctx->sel_runs >= 2 && std::getenv("LRR_ICP_NO_FOLD") == nullptr &&
+              std::fabs(ctx->sel_last[0] - ctx->sel_prev[0]) <= 1e-3 * std::fabs(ctx->sel_last[0]);
+  FoldArgs fa;
+  fa.prev = ctx->d_selprev; fa.win = ctx->d_selwin; fa.coll = ctx->d_selcoll; fa.cursor = ctx->d_selcursor; fa.P5 = ctx->d_fused + kFusedP5;
+  if (fold) hipLaunchKernelGGL((k_fw_weights<true>), dim3(nbF), dim3(kWide), 0, st, aF, fo, P1, nbF, SC, P4, fa);
+  else hipLaunchKernelGGL((k_fw_weights<false>), dim3(nbF), dim3(kWide), 0, st, aF, fo, P1, nbF, SC, P4, fa);
   HIPCHK(ctx, hipGetLastError());
   if (o->strength) {
     SelJob j = make_job(F->key_g, nsF, nullptr, 0, -1, 0);
     j.out = SEL;
     j.cnt = P4; j.cnt_a0 = 0; j.cnt_a1 = nbF; j.cnt_b0 = 0; j.cnt_b1 = 0;
+    j.row_a0 = 0; j.row_a1 = nbF; j.row_b0 = 0; j.row_b1 = 0; j.col = 0;
     j.state = 8;
     ctx->h_jobs[0] = j;
-    int rc = launch_select_kth(ctx, 1);
-    if (rc) return rc;
+    if (fold) {
+      SelPack pk;
+      for (int q = 0; q < kSelPack; ++q) pk.j[q] = j;
+      hipLaunchKernelGGL(k_selw_fold_final, dim3(1), dim3(kSelThreads), 0, st, pk, ctx->d_selprev, ctx->d_selwin, (const double *)(ctx->d_fused + kFusedP5),
+                         (const unsigned long long *)ctx->d_selcoll, ctx->d_selcursor);
+      HIPCHK(ctx, hipGetLastError());
+    } else {
+      int rc = launch_select_kth(ctx, 1);
+      if (rc) return rc;
+    }
   }
   const bool kron = o->dof == 12;
   const int nbA = std::min(grid_for(nsF), kron ? 2 * kKronBlocks : kAccBlocks);
@@ -5076,6 +5172,10 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   const double *sl = h + SEL_OFF;
   out->grad_scale[0] = out->grad_scale[1] = (o->strength && sl[3] > 1.0) ? 1.4826 * (1 + 5.0 / (sl[3] - 1.0)) * sl[0] : 0.0;
   out->spatial_scale[0] = out->spatial_scale[1] = 0.0;
+  ctx->sel_prev[0] = ctx->sel_last[0];
+  ctx->sel_last[0] = o->strength ? sl[0] : 0.0;
+  ctx->sel_dirs[0] = F; ctx->sel_dirs[1] = nullptr; ctx->sel_n[0] = F->n; ctx->sel_n[1] = 0;
+  if (ctx->sel_runs < 1000) ++ctx->sel_runs;
   if (kron) { kron_expand(h + FIN_OFF, out->AtA, out->Atb); return LRR_ICP_OK; }
   int t = 0;
   for (int a = 0; a < o->dof; ++a)

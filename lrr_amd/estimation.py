@@ -31,7 +31,7 @@ ICP_SYMBOLS = [
     "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
     "lrr_icp_residual_pass", "lrr_icp_muse_scale", "lrr_icp_assign_weights",
     "lrr_icp_normalize_stats", "lrr_icp_normalize_stats_merged", "lrr_icp_clone_weights", "lrr_icp_weight_by_strength",
-    "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_cloud_set_shape_vectors", "lrr_icp_angles", "lrr_icp_angles_unmapped", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
+    "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_errors_launch", "lrr_icp_errors_collect", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_cloud_set_shape_vectors", "lrr_icp_angles", "lrr_icp_angles_unmapped", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
     "lrr_icp_nearest", "lrr_icp_cloud_set_covariances", "lrr_icp_cdc_compute_weights",
     "lrr_icp_cdc_set_create", "lrr_icp_cdc_set_destroy", "lrr_icp_cdc_set_compute_weights", "lrr_icp_cdc_set_get", "lrr_icp_cdc_objective_par", "lrr_icp_cdc_objective_cov", "lrr_icp_cdc_normalize_stats",
