@@ -66,6 +66,13 @@ int  lrr_icp_timer_stop(lrr_icp_ctx *ctx, double *elapsed_ms);
 /* accumulated device time of the matching kernels since the last reset (HIP events around
  * every K1 launch when profiling is enabled) */
 int  lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_t *launches, int reset);
+/* how many searches (directions) each state of the grid matcher has served on this context since the last reset:
+ * certificate kernel that searches its own failures / certificate + list + wave-per-query kernels / ball search of a
+ * settled level / ball search right after a level grew / tile kernel (first dense search) / coarse pair path
+ * (wave-per-query) / thread-per-slot ring search.  Diagnostics and tests; no reference counterpart. */
+enum { LRR_ICP_K1_CERT_INLINE = 0, LRR_ICP_K1_CERT = 1, LRR_ICP_K1_BALL = 2, LRR_ICP_K1_BALL_GROWTH = 3, LRR_ICP_K1_TILE = 4,
+       LRR_ICP_K1_COARSE_PAIR = 5, LRR_ICP_K1_DIRECT = 6, LRR_ICP_K1_PATHS = 7 };
+int  lrr_icp_k1_path_counts(lrr_icp_ctx *ctx, int64_t counts[LRR_ICP_K1_PATHS], int reset);
 /* elapsed time of an EMPTY event pair on the context's stream, mean of `pairs` (the markers' own cost inside a timed submission) */
 int  lrr_icp_event_overhead(lrr_icp_ctx *ctx, int pairs, double *ms_per_pair);
 

@@ -163,6 +163,7 @@ struct lrr_icp_ctx {
   bool prof = false;
   unsigned prof_every = 1, prof_tick = 0;
   int64_t cert_host_seen = 0, cert_host_listed = 0;
+  int64_t k1_paths[LRR_ICP_K1_PATHS] = {0};  // searches (directions) served by each K1 state (lrr_icp_k1_path_counts)
   std::vector<hipEvent_t> pe;
   int pe_used = 0;
   double match_ms = 0.0;
@@ -3850,6 +3851,13 @@ int lrr_icp_event_overhead(lrr_icp_ctx *ctx, int pairs, double *ms_per_pair) {
   return LRR_ICP_OK;
 }
 
+int lrr_icp_k1_path_counts(lrr_icp_ctx *ctx, int64_t counts[LRR_ICP_K1_PATHS], int reset) {
+  if (!ctx || !counts) return LRR_ICP_ERR_ARG;
+  for (int k = 0; k < LRR_ICP_K1_PATHS; ++k) counts[k] = ctx->k1_paths[k];
+  if (reset) for (int k = 0; k < LRR_ICP_K1_PATHS; ++k) ctx->k1_paths[k] = 0;
+  return LRR_ICP_OK;
+}
+
 int lrr_icp_cert_stats(lrr_icp_ctx *ctx, int64_t *queries, int64_t *searched, int reset) {
   if (!ctx) return LRR_ICP_ERR_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -4299,6 +4307,7 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
   }
   static const bool no_inline = std::getenv("LRR_ICP_NO_INLINE_CERT") != nullptr;
   if (P.cert && P.inline_list && !no_inline) {  // a short list last time: the certificate kernel serves its failures itself
+    ctx->k1_paths[LRR_ICP_K1_CERT_INLINE] += 1;
     hipLaunchKernelGGL(k_match_cert_inline, dim3(cert_blocks_for(N)), dim3(kCertBlock), 0, st, ball_args(d, P, L));
     HIPCHK(ctx, hipGetLastError());
     d->cert_inline = true;
@@ -4306,15 +4315,19 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
   }
   if (P.cert) {
     BallArgs a = ball_args(d, P, L);
+    ctx->k1_paths[LRR_ICP_K1_CERT] += 1;
     hipLaunchKernelGGL(k_match_cert, dim3(cert_blocks_for(N)), dim3(kCertBlock), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     if (!P.short_list) hipLaunchKernelGGL(k_match_list, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, a);
   } else if (P.steady) {
+    ctx->k1_paths[P.growth ? LRR_ICP_K1_BALL_GROWTH : LRR_ICP_K1_BALL] += 1;
     hipLaunchKernelGGL(k_match_ball, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, ball_args(d, P, L));
   } else if (P.dense) {
+    ctx->k1_paths[LRR_ICP_K1_TILE] += 1;
     hipLaunchKernelGGL(k_match_tile, dim3(d->from->nchunks), dim3(kBlock), 0, st, P.g, d->from->src, d->from->chunks, P.kk, P.half, (int)N, (int)n_points, P.x, d->to->rec, d->to->orig_of, d->slot, d->m_to, d->w, L.d_hard, P.counts, kTileBudget);
   } else {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
+    ctx->k1_paths[LRR_ICP_K1_DIRECT] += 1;
     hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, P.counts);
   }
   HIPCHK(ctx, hipGetLastError());
@@ -4379,10 +4392,12 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       if (Pf.cert && Pb.cert && Pf.inline_list && Pb.inline_list && !no_inline) {
         hipLaunchKernelGGL(k_match_cert_inline2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
         HIPCHK(ctx, hipGetLastError());
+        ctx->k1_paths[LRR_ICP_K1_CERT_INLINE] += 2;
         f->cert_inline = b->cert_inline = true;  // the host adds this search to the certificate statistics when it learns the counts
         return LRR_ICP_OK;
       }
       if (Pf.cert && Pb.cert) {
+        ctx->k1_paths[LRR_ICP_K1_CERT] += 2;
         hipLaunchKernelGGL(k_match_cert2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
         HIPCHK(ctx, hipGetLastError());
         if (!(Pf.short_list && Pb.short_list)) {
@@ -4392,6 +4407,8 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       } else {
         // one of the two has no bounds yet: both take the plain ball search (which writes real slots)
         f->slot_lazy = b->slot_lazy = false;
+        ctx->k1_paths[LRR_ICP_K1_BALL] += (Pf.growth ? 0 : 1) + (Pb.growth ? 0 : 1);
+        ctx->k1_paths[LRR_ICP_K1_BALL_GROWTH] += (Pf.growth ? 1 : 0) + (Pb.growth ? 1 : 0);
         hipLaunchKernelGGL(k_match_ball2, dim3(ball_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBallBlock), 0, st, af, ab);
       }
       HIPCHK(ctx, hipGetLastError());
@@ -4437,6 +4454,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     cf.list = ctx->lane[0].d_hard; cf.list_count = Pf.counts;
     cb.src = b->from->src; cb.keys = Pb.kk; cb.half = Pb.half; cb.nsrc = (int)Pb.N; cb.n = (int)n_b; cb.slot = b->slot; cb.w = b->w;
     cb.list = ctx->lane[1].d_hard; cb.list_count = Pb.counts;
+    ctx->k1_paths[LRR_ICP_K1_COARSE_PAIR] += 2;
     hipLaunchKernelGGL(k_slots_coarse2, dim3(blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBlock), 0, st, cf, cb);
     HIPCHK(ctx, hipGetLastError());
     HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);

@@ -25,7 +25,7 @@ _ip = C.POINTER(C.c_int64)
 # every symbol include/lrr_icp.h declares
 ICP_SYMBOLS = [
     "lrr_icp_create", "lrr_icp_destroy", "lrr_icp_last_error", "lrr_icp_synchronize",
-    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile", "lrr_icp_event_overhead", "lrr_icp_cert_stats",
+    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile", "lrr_icp_event_overhead", "lrr_icp_cert_stats", "lrr_icp_k1_path_counts",
     "lrr_icp_cloud_create", "lrr_icp_cloud_destroy", "lrr_icp_cloud_size", "lrr_icp_cloud_build_voronoi",
     "lrr_icp_dir_create", "lrr_icp_dir_destroy", "lrr_icp_dir_set_from", "lrr_icp_dir_num_matches",
     "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
@@ -201,6 +201,16 @@ class DeviceTimer:
         if self.L.lrr_icp_match_profile(self.ctx, int(enable), C.byref(ms), C.byref(n), int(reset)) != 0:
             raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
         return ms.value, n.value
+
+    K1_PATHS = ("cert_inline", "cert", "ball", "ball_growth", "tile", "coarse_pair", "direct")
+
+    def k1_path_counts(self, reset=False):
+        """searches (directions) served by each state of the grid matcher since the last reset"""
+        v = (C.c_int64 * 7)()
+        self.L.lrr_icp_k1_path_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+        if self.L.lrr_icp_k1_path_counts(self.ctx, v, int(reset)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+        return dict(zip(self.K1_PATHS, [int(x) for x in v]))
 
     def event_overhead(self, pairs=64):
         """mean elapsed ms of an empty HIP-event pair on the context's stream"""

@@ -226,11 +226,16 @@ def test_symmetric_full_schedule_matches_oracle(E, ob, kind_name, dof):
     pair = synth.make_pair(12000, 11000, 20243, kind="rigid" if dof == 6 else "affine")
     T0 = synth.perturbed(pair.planted, 3)
     g, c = _both(E, ob, getattr(E, kind_name), dof, pair, T0, 13, True)
+    timer = E.DeviceTimer()
+    timer.k1_path_counts(reset=True)
     its = 0
     for it in range(40):
         its += 1
         if _compare_iteration(g, c, it, (0, 1)):
             break
+    if kind_name == "RRL_SYMMETRIC":
+        # near convergence few sources fail the certificate and the kernel that searches its own failures took over
+        assert timer.k1_path_counts()["cert_inline"] > 0, timer.k1_path_counts()
     assert g.finest_level() == c.finest_level()
     assert g.number_points(0) == c.number_points(0) and g.number_points(1) == c.number_points(1)
     assert abs(g.weighted_error(1) - c.weighted_error(1)) < 1e-8 * max(1.0, c.weighted_error(1))
@@ -529,16 +534,26 @@ def test_full_size_200k_schedule_against_oracle(E, ob, kind_name):
     pair = synth.make_pair(n, n, 20243, kind="affine")
     T0 = synth.perturbed(pair.planted, 3)
     g, c = _both(E, ob, getattr(E, kind_name), 12, pair, T0, 7, True)
+    timer = E.DeviceTimer()
+    timer.k1_path_counts(reset=True)
     at_finest = 0
     for it in range(60):
         _compare_iteration(g, c, it, (0, 1))
         assert g.finest_level() == c.finest_level()
         if g.finest_level():
             at_finest += 1
-            if at_finest >= 6:
+            if at_finest >= 8:
                 break
-    assert at_finest >= 6 and g.number_points(0) == n and c.number_points(0) == n
+    assert at_finest >= 8 and g.number_points(0) == n and c.number_points(0) == n
     assert abs(g.weighted_error(0) - c.weighted_error(0)) <= 1e-9 * max(1.0, c.weighted_error(0))
+    # every state of the grid matcher served searches of this run (and every one of them was compared above): the
+    # coarse pair path, the ring search of the 32k level, ball searches of settled and of freshly grown levels, the
+    # certificate with its separate list kernels (the tile kernel serves a first-ever dense search: the tests that
+    # start at the full level)
+    # (the certificate kernel that searches its own failures: see test_symmetric_full_schedule_matches_oracle)
+    paths = timer.k1_path_counts()
+    for name in ("coarse_pair", "direct", "ball", "ball_growth", "cert"):
+        assert paths[name] > 0, paths  # (cert_inline needs lists <= 512: test_symmetric_full_schedule_matches_oracle)
     g.close()
 
 
