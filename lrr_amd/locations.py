@@ -103,6 +103,17 @@ def _run_block(pair, rois, inits, indices, seed, est=None, diagnostics=True):
     return rows, pairs, est
 
 
+_WORKER_THREADS = []
+
+
+def _worker_thread(k: int):
+    """The k-th persistent single-thread executor of the sequential driver."""
+    from concurrent.futures import ThreadPoolExecutor
+    while len(_WORKER_THREADS) <= k:
+        _WORKER_THREADS.append(ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"lrr-loc-{len(_WORKER_THREADS)}"))
+    return _WORKER_THREADS[k]
+
+
 def register_locations_sequential(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1,
                                   seed: int = 7, gather_device=None, workers: int = 1, device_index=None,
                                   estimators=None, diagnostics=True):
@@ -126,15 +137,15 @@ def register_locations_sequential(pair: synth.VolumePair, rois, inits, rank: int
     if workers <= 1 or len(mine) <= 1:
         rows, pairs, estimators[0] = _run_block(pair, rois, inits, mine, seed, estimators[0], diagnostics)
     else:
-        from concurrent.futures import ThreadPoolExecutor
-
         def work(k):
             if device_index is not None:
                 E.set_device(device_index)  # contexts are per host thread
             return _run_block(pair, rois, inits, mine[k::workers], seed, estimators[k], diagnostics)
 
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            parts = list(pool.map(work, range(workers)))
+        # estimator k lives on worker thread k for as long as the process runs: a device context belongs to the host
+        # thread that made it, so the thread must outlive the call that keeps its estimator (`estimators`)
+        futures = [_worker_thread(k).submit(work, k) for k in range(workers)]
+        parts = [f.result() for f in futures]
         for k, part in enumerate(parts):
             estimators[k] = part[2]
         rows = [r for p in parts for r in p[0]]
