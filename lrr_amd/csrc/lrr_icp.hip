@@ -2540,15 +2540,31 @@ __global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int n
     s0 += U * stride;
     if (s0 < D.ps.nsrc) weights_load_batch(D, clone, s0, stride, sl, r2v, gv, ql);
   }
-  block_reduce_store<1, kWide / 64>(acc, P4);
-  if (FOLD) {
-    block_reduce_store<2, kWide / 64>(below, fo.P5);  // (its barriers also publish the staged keys)
+  if (!FOLD) { block_reduce_store<1, kWide / 64>(acc, P4); return; }
+  {
+    // the global reservations of the two gathered sets travel while the block reduces its three counts (one reduction
+    // for the number of strength keys, P4, and the keys below the two windows, P5)
+    __syncthreads();  // every key of the block is staged
     if (threadIdx.x < 2) {
       const int j = threadIdx.x == 0 ? jg : js, n = nstage[threadIdx.x];
       // a block that staged more than it holds makes the gathered set useless: push the cursor beyond the capacity
       gpos[threadIdx.x] = atomicAdd(&fo.cursor[j], n > kFoldStage ? kSelCap + 1 : n);
     }
-    __syncthreads();
+    __shared__ double red3[kWide / 64][3];
+    const double v3[3] = {acc[0], below[0], below[1]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double w2 = wave_sum(v3[k]);
+      if ((threadIdx.x & 63) == 0) red3[threadIdx.x >> 6][k] = w2;
+    }
+    __syncthreads();  // (also publishes gpos)
+    if (threadIdx.x < 3) {
+      double t3 = red3[0][threadIdx.x];
+#pragma unroll
+      for (int w2 = 1; w2 < kWide / 64; ++w2) t3 += red3[w2][threadIdx.x];
+      if (threadIdx.x == 0) P4[blockIdx.x] = t3;
+      else fo.P5[(size_t)blockIdx.x * 2 + (threadIdx.x - 1)] = t3;
+    }
     for (int t = 0; t < 2; ++t) {
       const int j = t == 0 ? jg : js, n = min(nstage[t], kFoldStage), p0 = gpos[t];
       if (nstage[t] <= kFoldStage && p0 + n <= kSelCap)
