@@ -430,9 +430,10 @@ def main():
     if rank == 0:
         total_pairs = args.steps * n_pairs_step * world
         value = total_pairs / dt
-        # a timed submission = one event pair around the launch(es) serving BOTH directions; launches counts directions.
-        # The figure includes the markers' own cost (an empty pair alone reads event_pair_ms; part of that overlaps the
-        # kernel, so it is reported, not subtracted): rocprofv3's kernel duration is what profiles/ holds beside it.
+        # a timed submission = one HIP-event pair for the launch(es) serving BOTH directions; launches counts directions.
+        # The steady state's single kernel carries its two events itself (hipExtLaunchKernelGGL: the kernel's own start
+        # and end timestamps, what rocprofv3 reports under profiles/); submissions of several kernels are bracketed by
+        # two recorded events, whose marker packets add ~2 us (an empty pair alone reads event_pair_ms).
         k1_ms = match_ms / max(match_launches, 1)
         n_dir = n_pairs_step // 2
         k1_bytes = n_dir * K1_BYTES_PER_PAIR_FIXED + 24.0 * n  # per launch: n_dir queries vs one n-point cloud
@@ -463,7 +464,7 @@ def main():
                          "kernel": ("K1 find_closest_euclidean at the finest level = k_match_cert_inline2 (certificate pass whose wavefronts "
                                     "also search the few sources that fail it; k_match_cert2 + k_match_list2 + k_match_hard2 while the lists are "
                                     "long): one launch serves the forward and the backward search (lrr_icp_match_pair); kernel_ms = HIP-event "
-                                    "time of the submission / 2 = one direction (markers included: see event_pair_ms)"
+                                    "time of that launch (events attached to the launch itself) / 2 = one direction"
                                     if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
                          "event_pair_ms": event_pair_ms, "timed_every": k1_sample,
                          "valu_frac": valu_frac,

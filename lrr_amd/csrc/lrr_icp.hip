@@ -28,6 +28,7 @@
 // handed back to the host.  Sums are order-independent up to rounding, so this changes nothing
 // observable beyond the last bits.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -3669,13 +3670,26 @@ struct ProfScope {  // HIP events around K1 submissions (all phases), recorded o
   hipStream_t st;
   int launches;
   bool on;
+  bool attached = false;  // the events were handed to the launch itself (attach): no marker packets
   ProfScope(lrr_icp_ctx *c, hipStream_t stream, int n_launches)
       : ctx(c), st(stream), launches(n_launches),
-        on(n_launches > 0 && c->prof && c->pe_used + 2 <= (int)c->pe.size() && (c->prof_tick++ % c->prof_every) == 0) {
-    if (on) (void)hipEventRecord(ctx->pe[ctx->pe_used], st);
+        on(n_launches > 0 && c->prof && c->pe_used + 2 <= (int)c->pe.size() && (c->prof_tick++ % c->prof_every) == 0) {}
+  // A submission that is ONE kernel gives its two events to the launch (hipExtLaunchKernelGGL): they then carry the
+  // kernel's own start and end timestamps — what rocprofv3 reports — instead of the completion times of two marker
+  // packets around it (which add ~2 us to a 9-us kernel).  Call before the launch; returns the event pair or nulls.
+  void attach(hipEvent_t *start, hipEvent_t *stop) {
+    *start = *stop = nullptr;
+    if (!on) return;
+    attached = true;
+    *start = ctx->pe[ctx->pe_used];
+    *stop = ctx->pe[ctx->pe_used + 1];
   }
+  void begin() { if (on && !attached) (void)hipEventRecord(ctx->pe[ctx->pe_used], st); }
   ~ProfScope() {
-    if (on) { (void)hipEventRecord(ctx->pe[ctx->pe_used + 1], st); ctx->pe_used += 2; ctx->match_launches += launches; }  // timed submissions only: the mean stays a mean when the event pool runs out
+    if (!on) return;
+    if (!attached) (void)hipEventRecord(ctx->pe[ctx->pe_used + 1], st);
+    ctx->pe_used += 2;
+    ctx->match_launches += launches;  // timed submissions only: the mean stays a mean when the event pool runs out
   }
 };
 
@@ -4369,6 +4383,7 @@ static int match_on(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t keys
   int rc = match_prepare(d, xf, keys, order, n_points, method, L, L.stream, P);
   if (rc) return rc;
   ProfScope prof(d->ctx, L.stream, profile && !P.empty ? 1 : 0);
+  prof.begin();
   return match_launch(d, P, L, L.stream);
 }
 
@@ -4406,12 +4421,16 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       // kernel settles its failures itself — K1 is this one launch
       static const bool no_inline = std::getenv("LRR_ICP_NO_INLINE_CERT") != nullptr;
       if (Pf.cert && Pb.cert && Pf.inline_list && Pb.inline_list && !no_inline) {
-        hipLaunchKernelGGL(k_match_cert_inline2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
+        hipEvent_t ev0, ev1;
+        prof.attach(&ev0, &ev1);
+        if (ev0) hipExtLaunchKernelGGL(k_match_cert_inline2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, ev0, ev1, 0, af, ab);
+        else hipLaunchKernelGGL(k_match_cert_inline2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
         HIPCHK(ctx, hipGetLastError());
         ctx->k1_paths[LRR_ICP_K1_CERT_INLINE] += 2;
         f->cert_inline = b->cert_inline = true;  // the host adds this search to the certificate statistics when it learns the counts
         return LRR_ICP_OK;
       }
+      prof.begin();
       if (Pf.cert && Pb.cert) {
         ctx->k1_paths[LRR_ICP_K1_CERT] += 2;
         hipLaunchKernelGGL(k_match_cert2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
@@ -4450,6 +4469,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     }
     // (not reached: the test above mirrors match_prepare's) fall through to separate launches
     ProfScope prof(ctx, st, 2);
+    prof.begin();
     rc = match_launch(f, Pf, ctx->lane[0], st);
     rc2 = match_launch(b, Pb, ctx->lane[1], st);
     return rc ? rc : rc2;
@@ -4465,6 +4485,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     if ((rc = match_prepare(f, xf_f, keys_f, order_f, n_f, method, ctx->lane[0], st, Pf))) return rc;
     if ((rc = match_prepare(b, xf_b, keys_b, order_b, n_b, method, ctx->lane[1], st, Pb))) return rc;
     ProfScope prof(ctx, st, 2);
+    prof.begin();
     CoarseArgs cf, cb;
     cf.src = f->from->src; cf.keys = Pf.kk; cf.half = Pf.half; cf.nsrc = (int)Pf.N; cf.n = (int)n_f; cf.slot = f->slot; cf.w = f->w;
     cf.list = ctx->lane[0].d_hard; cf.list_count = Pf.counts;
@@ -4482,7 +4503,8 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     return LRR_ICP_OK;
   }
   {
-    ProfScope prof(ctx, ctx->stream, 2);  // fork .. join on the main stream: both searches
+    ProfScope prof(ctx, ctx->stream, 2);
+    prof.begin();  // fork .. join on the main stream: both searches
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->lane[1].stream, ctx->ev_fork, 0));
     rc = match_on(f, xf_f, keys_f, order_f, n_f, method, ctx->lane[0], false);
@@ -5275,6 +5297,7 @@ int lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int m
     XfD x = identity_xf();
     if (method == LRR_ICP_NN_AUTO) method = LRR_ICP_NN_GRID;
     ProfScope prof(ctx, ctx->stream, 1);
+    prof.begin();
     if (rc) {
     } else if (method == LRR_ICP_NN_BRUTE) rc = launch_brute(ctx, L, ctx->stream, cloud, g, q, nullptr, x, (int)nq, dto);
     else {
