@@ -14,8 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 INC = os.path.join(ROOT, "include")
 HIP_SRC = os.path.join(HERE, "csrc", "lrr_icp.hip")
-HIP_INC = os.path.join(HERE, "csrc", "lrr_icp_batch.inc")
-HIP_INC2 = os.path.join(HERE, "csrc", "lrr_icp_cdc.inc")
+HIP_INCS = [os.path.join(HERE, "csrc", f) for f in ("lrr_icp_k1.inc", "lrr_icp_passes.inc", "lrr_icp_fused.inc", "lrr_icp_grid.inc",
+                                                  "lrr_icp_batch.inc", "lrr_icp_cdc.inc")]  # sections of the one translation unit
 HIP_SO = os.path.join(HERE, "liblrr_icp_hip.so")
 EST_SRC = os.path.join(HERE, "csrc", "lrr_est_capi.cpp")
 EST_SO = os.path.join(HERE, "liblrr_est.so")
@@ -38,7 +38,7 @@ def _headers():
 def build(force: bool = False, verbose: bool = False) -> None:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     hdrs = _headers()
-    if force or not _newer(HIP_SO, [HIP_SRC, HIP_INC, HIP_INC2] + hdrs):
+    if force or not _newer(HIP_SO, [HIP_SRC] + HIP_INCS + hdrs):
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-I" + INC, "-o", HIP_SO, HIP_SRC]
         if verbose:

@@ -537,2811 +537,10 @@ __device__ __forceinline__ bool ring_settled(double lb, double tol, double bd) {
   return lb > 0.0 && bd < lb * lb;
 }
 
-// ---------------------------------------------------------------------------------------------
-// K1: exact nearest neighbour
-// ---------------------------------------------------------------------------------------------
-// where the queries of a K1 launch come from: the canonical source array of a cloud (results are
-// canonical target indices, written at the source's canonical position) or raw host points
-// (stand-alone queries: results are ORIGINAL target indices)
-struct QSrc {
-  const SrcPoint *src;
-  const double *raw;   // xyz triples when src == nullptr
-  int want_orig;
-  // batched query locations: entry s of the batch segment is feature pidx[s] of the parent cloud and is
-  // mapped by the transform of its own location (bloc[loc_of[s]].xf[dir])
-  const int *pidx;
-  const BLoc *bloc;
-  const int *loc_of;
-  int dir;
-};
-__device__ __forceinline__ void query_point(const QSrc &q, int s, double &x, double &y, double &z) {
-  if (q.src) { SrcPoint p = q.src[q.pidx ? q.pidx[s] : s]; x = p.x; y = p.y; z = p.z; }
-  else { x = q.raw[3 * (size_t)s]; y = q.raw[3 * (size_t)s + 1]; z = q.raw[3 * (size_t)s + 2]; }
-}
-// the query point mapped by the launch's transform, or by its own location's in a batch
-__device__ __forceinline__ void mapped_query(const GridView &g, const QSrc &q, const XfD &xf, int s, double &yx, double &yy, double &yz) {
-  double x, y, z;
-  query_point(q, s, x, y, z);
-  if (q.bloc) map_loc(q.bloc[q.loc_of[s]].xf[q.dir], x, y, z, yx, yy, yz);
-  else map_loc(xf, x, y, z, yx, yy, yz);
-  vor_quantize(g, yx, yy, yz);
-}
-__device__ __forceinline__ int result_index(const QSrc &q, const Best &b) {
-  if (b.orig == 0x7fffffff) return 0;  // only reachable with non-finite input
-  return q.want_orig ? b.orig : b.canon;
-}
-
-// candidates [s, e) of the global search structure; kScanUnroll loads are issued before any is
-// compared, so a lane keeps that many 32-B requests in flight
-__device__ __forceinline__ void scan_range(const GridView &g, int s, int e, double yx, double yy,
-                                           double yz, Best &b) {
-  for (int j = s; j < e; j += kScanUnroll) {
-    GridPoint pt[kScanUnroll];
-#pragma unroll
-    for (int u = 0; u < kScanUnroll; ++u) pt[u] = g.gp[min(j + u, e - 1)];
-#pragma unroll
-    for (int u = 0; u < kScanUnroll; ++u)
-      if (j + u < e) consider(b, dist2(yx, yy, yz, pt[u].x, pt[u].y, pt[u].z), pt[u].orig, pt[u].canon);
-  }
-}
-
-// Thread-per-query search in GLOBAL memory, rings 0..1 (used when the active subset is sparse:
-// coarse levels, explicit orders, stand-alone queries).  The 4 cell_start entries around the
-// query's column are fetched for each of the 9 rows of the 3x3x3 block in one round trip; a row
-// or cell whose box is farther than the best so far is skipped (strictly farther: an equally
-// distant point with a lower index must still be seen).  Returns false (-> wave-per-query
-// kernel) when ring 1 does not settle the query or more than `budget` candidates would have to
-// be scanned by this lane (kernel time = slowest lane).
-__device__ __forceinline__ bool grid_search_easy(const GridView &g, double yx, double yy, double yz, int budget,
-                                                 Best &best) {
-  int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
-  int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
-  int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
-  int st[3][3][4];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      int z = cz - 1 + a, y = cy - 1 + b;
-      bool ok = z >= 0 && z < g.dz && y >= 0 && y < g.dy;
-      int row = ok ? (z * g.dy + y) * g.dx : 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) st[a][b][k] = ok ? g.cell_start[row + clampi(cx - 1 + k, 0, g.dx)] : 0;
-    }
-  best.d = INFINITY; best.orig = 0x7fffffff; best.canon = 0;
-#define LRR_SCAN(S, E)                                   \
-  {                                                      \
-    int s_ = (S), e_ = (E);                              \
-    budget -= e_ - s_;                                   \
-    if (budget < 0) return false;                        \
-    scan_range(g, s_, e_, yx, yy, yz, best);             \
-  }
-  LRR_SCAN(st[1][1][1], st[1][1][2])  // ring 0: the query's own cell
-  if (ring_settled(ring_bound(g, cx, cy, cz, 0, yx, yy, yz), g.tol, best.d)) return true;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    int z = cz - 1 + a;
-    if (z < 0 || z >= g.dz) continue;
-    double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
-    double dz2 = gz_ * gz_;
-    if (dz2 > best.d) continue;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      int y = cy - 1 + b;
-      if (y < 0 || y >= g.dy) continue;
-      double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
-      double dyz2 = dz2 + gy_ * gy_;
-      if (dyz2 > best.d) continue;
-      if (a != 1 || b != 1) {  // shell row: the x-run cx-1..cx+1, narrowed by the best distance
-        int xa = max(cx - 1, 0), xb = min(cx + 1, g.dx - 1);
-        if (best.d < INFINITY) {
-          double rad = sqrt(best.d - dyz2) + 2.0 * g.tol;
-          xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
-          xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
-        }
-        if (xa <= xb) LRR_SCAN(st[a][b][xa - (cx - 1)], st[a][b][xb + 1 - (cx - 1)])
-      } else {  // centre row: the two end cells
-        if (cx - 1 >= 0) {
-          double gx_ = slab_gap(yx, g.lox + (cx - 1) * g.h, g.lox + cx * g.h, g.tol);
-          if (dyz2 + gx_ * gx_ <= best.d) LRR_SCAN(st[1][1][0], st[1][1][1])
-        }
-        if (cx + 1 <= g.dx - 1) {
-          double gx_ = slab_gap(yx, g.lox + (cx + 1) * g.h, g.lox + (cx + 2) * g.h, g.tol);
-          if (dyz2 + gx_ * gx_ <= best.d) LRR_SCAN(st[1][1][2], st[1][1][3])
-        }
-      }
-    }
-  }
-#undef LRR_SCAN
-  return ring_settled(ring_bound(g, cx, cy, cz, 1, yx, yy, yz), g.tol, best.d);
-}
-
-// K1, sparse form: one thread per match-list slot i (explicit order, keyed permutation of a coarse
-// level, or a raw query point)
-__global__ __launch_bounds__(kBlock) void k_match_direct(GridView g, QSrc q, const int *order, int use_keys,
-                                                         Keys keys, int half, int nsrc, const int *canon_of,
-                                                         XfD xf, int n, int *slot, int *m_to, double *w,
-                                                         int *hard, int *hard_count) {
-  int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  int s = i;
-  if (q.src) {
-    int p = order ? order[i] : (use_keys ? subset_perm(i, nsrc, half, keys) : i);
-    s = canon_of[p];
-    slot[s] = i;
-    w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-  }
-  double x, y, z, yx, yy, yz;
-  query_point(q, s, x, y, z);
-  map_loc(xf, x, y, z, yx, yy, yz);
-  vor_quantize(g, yx, yy, yz);
-  Best b;
-  if (grid_search_easy(g, yx, yy, yz, kEasyBudget, b)) m_to[s] = result_index(q, b);
-  else hard[atomicAdd(hard_count, 1)] = s;  // m_to[s] keeps the previous match (cloud queries)
-}
-
-// K1, dense form (fine levels): one block per chunk of <= 256 consecutive canonical source
-// features, all from one 8x8x8-cell tile of the SOURCE grid, so their mapped positions fall into
-// a small box of the TARGET grid.  The block stages that box in LDS with coalesced row-run
-// copies, then every lane searches from LDS: the divergent, dependent accesses of the search cost
-// LDS latency instead of a memory round trip each.
-//
-// Search region of a lane.  m_to[s] still holds the source's match of the PREVIOUS iteration (any
-// target feature is a valid upper bound; under ICP's small updates it is nearly the new nearest
-// neighbour): with it, the nearest neighbour lies in the ball of that radius around the query,
-// so the lane scans exactly the cells meeting that ball (box-pruned by the running best) and
-// needs no stopping test.  Without a previous match it scans ring 0, then ring 1, with the usual
-// interior-face test.  slot[s] = perm^-1(original index) keeps the match LIST identical to the
-// direct form.  Lanes whose region is wide, chunks whose box does not fit, unsettled and
-// over-budget queries go to the wave-per-query kernel.
-__global__ __launch_bounds__(kBlock) void k_match_tile(GridView g, const SrcPoint *src, const Chunk *chunks,
-                                                       Keys keys, int half, int nsrc, int n_points, XfD xf,
-                                                       const double *to_rec, const int *to_orig_of, int *slot,
-                                                       int *m_to, double *w, int *hard, int *hard_count,
-                                                       int budget) {
-  __shared__ GridPoint lp[kTileCap];  // staged candidates, AoS: one candidate = two 16-B LDS reads
-  __shared__ int row_goff[kTileRows], row_loff[kTileRows + 1];
-  __shared__ unsigned short cso[kTileRows][kTileNx + 1];
-  __shared__ int box[6], wave_tot[kBlock / 64];
-  const Chunk ck = chunks[blockIdx.x];
-  const int t = threadIdx.x, s = ck.start + t;
-  bool active = false, has_prev = false, to_hard = false;
-  double yx = 0, yy = 0, yz = 0;
-  int cx = 0, cy = 0, cz = 0;
-  int ra[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, rb[3] = {-1, -1, -1};  // this lane's cell region
-  Best b;
-  b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
-  if (t == 0) { box[0] = box[2] = box[4] = 0x7fffffff; box[1] = box[3] = box[5] = -1; }
-  __syncthreads();
-  if (t < ck.count) {
-    SrcPoint sp = src[s];
-    int j = subset_perm_inv((int)sp.orig, nsrc, half, keys);
-    active = j < n_points;
-    int prev = m_to[s];
-    slot[s] = active ? j : -1;
-    if (active) {
-      w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-      map_loc(xf, sp.x, sp.y, sp.z, yx, yy, yz);
-      cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
-      cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
-      cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
-      double rad = g.h;  // no previous match: rings 0..1
-      if (prev >= 0) {
-        const double *q = to_rec + (size_t)prev * kRecStride;
-        b.d = dist2(yx, yy, yz, q[0], q[1], q[2]);
-        b.orig = to_orig_of[prev];
-        b.canon = prev;
-        has_prev = true;
-        rad = sqrt(b.d) + 2.0 * g.tol;
-      }
-      if (rad > 2.0 * g.h) to_hard = true;  // wide region (outlier): better served by a whole wavefront
-      else if (has_prev) {
-        ra[0] = clampi((int)floor((yx - rad - g.lox) * g.inv_h), 0, g.dx - 1); rb[0] = clampi((int)floor((yx + rad - g.lox) * g.inv_h), 0, g.dx - 1);
-        ra[1] = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1); rb[1] = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
-        ra[2] = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1); rb[2] = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
-      } else {
-        ra[0] = max(cx - 1, 0); rb[0] = min(cx + 1, g.dx - 1);
-        ra[1] = max(cy - 1, 0); rb[1] = min(cy + 1, g.dy - 1);
-        ra[2] = max(cz - 1, 0); rb[2] = min(cz + 1, g.dz - 1);
-      }
-    }
-  }
-  const bool searching = active && !to_hard;
-  {  // bounding box of the searching lanes' regions: wave min/max by shuffles, one LDS atomic per wave
-    int lo3[3], hi3[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { lo3[k] = searching ? ra[k] : 0x7fffffff; hi3[k] = searching ? rb[k] : -1; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        lo3[k] = min(lo3[k], __shfl_xor(lo3[k], off, 64));
-        hi3[k] = max(hi3[k], __shfl_xor(hi3[k], off, 64));
-      }
-    if ((t & 63) == 0)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { atomicMin(&box[2 * k], lo3[k]); atomicMax(&box[2 * k + 1], hi3[k]); }
-  }
-  __syncthreads();
-  if (active && to_hard) hard[atomicAdd(hard_count, 1)] = s;  // m_to[s] keeps the previous match: a bound for phase 2
-  if (box[1] < 0) return;  // no searching lane in this chunk (uniform)
-  const int x0 = box[0], x1 = box[1], y0 = box[2], y1 = box[3], z0 = box[4], z1 = box[5];
-  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1, nrows = ny * nz;
-  bool fits = nx <= kTileNx && nrows <= kTileRows;
-  // row table: global start and length of every (z,y) row's x-run, exclusive prefix -> LDS offsets
-  int cnt = 0;
-  if (fits && t < nrows) {
-    int row = ((z0 + t / ny) * g.dy + (y0 + t % ny)) * g.dx;
-    int gs = g.cell_start[row + x0];
-    cnt = g.cell_start[row + x1 + 1] - gs;
-    row_goff[t] = gs;
-  }
-  int incl = cnt;
-  const int lane = t & 63, wv = t >> 6;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) wave_tot[wv] = incl;
-  __syncthreads();
-  int before = 0;
-  for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
-  int total = 0;
-  for (int w2 = 0; w2 < kBlock / 64; ++w2) total += wave_tot[w2];
-  if (fits && t < nrows) row_loff[t] = before + incl - cnt;
-  if (t == 0) row_loff[fits ? nrows : 0] = total;
-  fits = fits && total <= kTileCap;
-  if (!fits) {  // uniform: hand every searching query of the chunk over
-    if (searching) hard[atomicAdd(hard_count, 1)] = s;
-    return;
-  }
-  // per-row cell boundaries relative to the row start; loads issued in batches so that several
-  // are in flight per lane
-  {
-    const int ncs = nrows * (nx + 1);
-    for (int base = t; base < ncs; base += 8 * kBlock) {
-      int v[8], rr[8], kk2[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        int idx = min(base + u * kBlock, ncs - 1);
-        rr[u] = idx / (nx + 1); kk2[u] = idx - rr[u] * (nx + 1);
-        int row = ((z0 + rr[u] / ny) * g.dy + (y0 + rr[u] % ny)) * g.dx;
-        v[u] = g.cell_start[row + x0 + kk2[u]];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (base + u * kBlock < ncs) cso[rr[u]][kk2[u]] = (unsigned short)(v[u] - row_goff[rr[u]]);
-    }
-  }
-  __syncthreads();
-  // stage the points: candidate c of the concatenated rows -> row by binary search over row_loff.
-  // total <= kTileCap = 8 * kBlock: every lane resolves its (up to) 8 addresses first, then issues
-  // the 8 loads back to back, then stores.
-  {
-    int addr[kTileCap / kBlock];
-#pragma unroll
-    for (int u = 0; u < kTileCap / kBlock; ++u) {
-      int c = t + u * kBlock;
-      addr[u] = -1;
-      if (c < total) {
-        int lo = 0, hi = nrows;  // last row with row_loff <= c
-        while (hi - lo > 1) {
-          int mid = (lo + hi) >> 1;
-          if (row_loff[mid] <= c) lo = mid; else hi = mid;
-        }
-        addr[u] = row_goff[lo] + (c - row_loff[lo]);
-      }
-    }
-    GridPoint pt[kTileCap / kBlock];
-#pragma unroll
-    for (int u = 0; u < kTileCap / kBlock; ++u) pt[u] = g.gp[max(addr[u], 0)];
-#pragma unroll
-    for (int u = 0; u < kTileCap / kBlock; ++u)
-      if (addr[u] >= 0) {
-        int c = t + u * kBlock;
-        lp[c] = pt[u];
-      }
-  }
-  __syncthreads();
-  if (!searching) return;
-  // search from LDS; 4 candidates are read before any is compared (LDS latency paid once per 4)
-  bool over_budget = false;
-#define LDS_SCAN(R, XA, XB)                                                          \
-  {                                                                                  \
-    int base_ = row_loff[R];                                                         \
-    int j_ = base_ + cso[R][(XA) - x0], e_ = base_ + cso[R][(XB) + 1 - x0];         \
-    budget -= e_ - j_;                                                               \
-    if (budget < 0) { over_budget = true; j_ = e_; }                                 \
-    for (; j_ < e_; j_ += 4) {                                                       \
-      GridPoint c_[4];                                                               \
-      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) c_[u_] = lp[min(j_ + u_, e_ - 1)]; \
-      _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)                               \
-        if (j_ + u_ < e_) consider(b, dist2(yx, yy, yz, c_[u_].x, c_[u_].y, c_[u_].z), c_[u_].orig, c_[u_].canon); \
-    }                                                                                \
-  }
-  // the query's own cell first: it usually holds the answer and tightens the pruning radius
-  LDS_SCAN((cz - z0) * ny + (cy - y0), cx, cx)
-  bool done = false;
-  if (!has_prev) done = ring_settled(ring_bound(g, cx, cy, cz, 0, yx, yy, yz), g.tol, b.d);
-  if (!done) {
-    for (int z = ra[2]; z <= rb[2]; ++z) {
-      double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
-      double dz2 = gz_ * gz_;
-      if (dz2 > b.d) continue;
-      for (int y = ra[1]; y <= rb[1]; ++y) {
-        double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
-        double dyz2 = dz2 + gy_ * gy_;
-        if (dyz2 > b.d) continue;
-        int r = (z - z0) * ny + (y - y0);
-        // x-run of the region narrowed by the best distance; the own cell is skipped
-        int xa = ra[0], xb = rb[0];
-        if (b.d < INFINITY) {
-          double rad = sqrt(b.d - dyz2) + 2.0 * g.tol;
-          xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
-          xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
-        }
-        if (z == cz && y == cy) {
-          if (xa <= cx - 1) LDS_SCAN(r, xa, cx - 1)
-          if (cx + 1 <= xb) LDS_SCAN(r, cx + 1, xb)
-        } else if (xa <= xb) LDS_SCAN(r, xa, xb)
-      }
-    }
-    // with a previous match the scanned ball provably holds the nearest neighbour
-    done = !over_budget && (has_prev || ring_settled(ring_bound(g, cx, cy, cz, 1, yx, yy, yz), g.tol, b.d));
-  }
-#undef LDS_SCAN
-  if (done) m_to[s] = (b.orig == 0x7fffffff) ? 0 : b.canon;
-  else hard[atomicAdd(hard_count, 1)] = s;
-}
-
-// K1, dense form with previous matches (later iterations of a level): one THREAD per canonical
-// source feature, searching global memory.  m_to[s] holds the match of the previous iteration
-// (any target feature is a valid upper bound; under ICP's small updates it is nearly the new
-// nearest neighbour): the nearest neighbour lies in the ball of that radius around the mapped
-// feature, so the lane needs no stopping test.  It walks the (z,y) rows of cells meeting the
-// ball — rows are h x h wide, so there are few — and in each row takes the x-run of the ball at
-// the resolution of the x-SLICES (h / fine): few candidates per row.  All slice bounds of up to
-// kBallRows rows are fetched in one round trip, then the candidates of the concatenated runs
-// kScanUnroll loads at a time.  Four dependent memory levels per query (source + previous index,
-// previous point, slice bounds, candidates) with every query of the launch resident at once.
-// Lanes without a previous match, with a ball wider than kBallCells cells or more than `budget`
-// candidates go to the wave-per-query kernel.
-constexpr int kBallBlock = 64;      // one wavefront per block: the scheduler packs and refills SIMDs wave by wave
-constexpr int kBallRows = 9;        // (z,y) rows whose cell bounds a lane fetches in one round trip
-constexpr int kBallBudget = 64;     // candidates a lane may scan before handing its query over
-constexpr double kBallCells = 3.0;  // widest ball (in cells) the thread-per-query search takes
-struct BallArgs {  // one direction of a ball search
-  GridView g;
-  const SrcPoint *src;
-  Keys keys;
-  int half, nsrc, n_points;
-  XfD xf;
-  const GridPoint *to_pt;  // target points in canonical order
-  int *slot, *m_to;
-  double *w;
-  int *hard, *hard_count;
-  int budget;
-  double max_rad;
-  // second-nearest bounds (the certificate of the next search, see k_match_cert): d2lb[s] = a lower bound of
-  // the distance from the mapped source to every target other than its match; xf_prev = the transform of
-  // the previous search (certificate kernel only)
-  float *d2lb;
-  XfD xf_prev;
-  int *list, *list_count;  // sources the certificate kernel could not settle
-};
-constexpr float kBallMarginCells = 0.01f;  // the ball is searched this much wider than the best distance (in cells):
-                                           // what lies beyond is provably farther than best + margin
-// The ball search of one query (yx, yy, yz) whose previous match `prev` (a canonical target index) bounds
-// the distance: true = b holds the exact nearest neighbour; false = ball wider than max_rad or more
-// than `budget` candidates (the caller hands the query to the wave-per-query phase).
-// `second` returns the smallest exact squared distance among the OTHER targets the search evaluated; every
-// target it did not evaluate is farther than the final best distance + kBallMarginCells * h (all pruning
-// bounds carry that margin), so min(sqrt(second), sqrt(b.d) + margin) bounds the second-nearest distance.
-__device__ __forceinline__ bool ball_search(const GridView &g, const GridPoint *to_pt, double yx, double yy, double yz,
-                                            int prev, int budget, double max_rad, Best &b, double &second) {
-  second = INFINITY;
-  {
-    const GridPoint q = to_pt[prev];  // one 32-B gather: location and original index of the previous match
-    b.d = dist2(yx, yy, yz, q.x, q.y, q.z);
-    b.orig = q.orig;
-    b.canon = prev;
-  }
-  const double rad = sqrt(b.d) + 2.0 * g.tol + (double)kBallMarginCells * g.h;
-  if (!(rad <= max_rad)) return false;  // outlier: a whole wavefront serves it better
-  const double inv_hx = g.inv_h * g.fine;
-  const int fdx = g.dx * g.fine;  // x-slices per row
-  const int xa0 = clampi((int)floor((yx - rad - g.lox) * inv_hx), 0, fdx - 1), xb0 = clampi((int)floor((yx + rad - g.lox) * inv_hx), 0, fdx - 1);
-  const int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
-  const int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
-  const int nyr = yb - ya + 1, nrows = nyr * (zb - za + 1);
-  // Row pruning runs in single precision on cell units and only has to be CONSERVATIVE: the query
-  // in cells (error < 1e-4 cell for grids of <= 512 cells), the radius rounded up plus 1e-3 cell.
-  const float uy = (float)((yy - g.loy) * g.inv_h), uz = (float)((yz - g.loz) * g.inv_h);
-  const float uxs = (float)((yx - g.lox) * inv_hx), finef = (float)g.fine;
-  const float inv_hf = (float)g.inv_h * 1.000001f;
-  const float qfx = (float)((yx - g.lox) * g.inv_h), qfy = uy, qfz = uz;  // the query in cell units
-  float thr2;
-  {
-    const float tb = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + (3e-4f + kBallMarginCells);
-    thr2 = tb * tb;
-  }
-  int yi = ya, zi = za;  // (z,y) of row r0: advanced without integer division
-  int row = (za * g.dy + ya) * fdx;
-  const int row_wrap = (g.dy - nyr) * fdx;
-  for (int r0 = 0; r0 < nrows; r0 += kBallRows) {
-    const float rc = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + (1e-3f + kBallMarginCells);
-    const float rc2 = rc * rc;
-    int rs[kBallRows], re[kBallRows];
-#pragma unroll
-    for (int u = 0; u < kBallRows; ++u) {
-      rs[u] = 0; re[u] = 0;
-      if (r0 + u < nrows) {
-        const float fy = (float)yi, fz = (float)zi;
-        const float gy_ = fmaxf(fmaxf(fy - uy, uy - (fy + 1.0f)), 0.0f);
-        const float gz_ = fmaxf(fmaxf(fz - uz, uz - (fz + 1.0f)), 0.0f);
-        const float dyz2 = gz_ * gz_ + gy_ * gy_;
-        if (dyz2 <= rc2) {  // farther rows cannot hold a better or an equal candidate
-          const float rxs = __builtin_amdgcn_sqrtf(rc2 - dyz2) * finef;  // half-width of the ball in this row, in slices
-          const int xa = max(xa0, (int)floorf(uxs - rxs)), xb = min(xb0, (int)floorf(uxs + rxs));
-          if (xa <= xb) {
-            rs[u] = g.fine_start[row + xa];
-            re[u] = g.fine_start[row + xb + 1];
-          }
-        }
-        row += fdx;
-        if (++yi > yb) { yi = ya; ++zi; row += row_wrap; }
-      }
-    }
-    // candidate c of the concatenated runs sits at c + off[u], off[u] = rs[u] - pre[u], for the last
-    // run u with pre[u] <= c: a telescoping sum of compare-selects, no register indexing
-    int pre[kBallRows], dl[kBallRows], total = 0;
-#pragma unroll
-    for (int u = 0; u < kBallRows; ++u) {
-      pre[u] = total;
-      dl[u] = (rs[u] - total) - (u ? rs[u - 1] - pre[u - 1] : 0);
-      total += re[u] - rs[u];
-    }
-    budget -= total;
-    if (budget < 0) return false;  // the caller hands the query over; m_to[s] keeps the previous match
-    // Single-precision pre-filter: a candidate is read as 16 B (location in cell units, canonical
-    // index) and its approximate distance compared with the best exact distance so far plus the
-    // error bound of the approximation (coordinates < 512 cells: |d~ - d| < 2e-4 cell).  Only a
-    // candidate that may beat or TIE the best is fetched in full and compared exactly, with the
-    // lexicographic (distance, lowest original index) rule; every other one is provably farther.
-    for (int c0 = 0; c0 < total; c0 += kScanUnroll) {
-      float4 pf[kScanUnroll];
-#pragma unroll
-      for (int v = 0; v < kScanUnroll; ++v) {
-        const int c = min(c0 + v, total - 1);
-        int addr = c + dl[0];
-#pragma unroll
-        for (int u = 1; u < kBallRows; ++u) addr += c >= pre[u] ? dl[u] : 0;
-        pf[v] = g.gpf[addr];
-      }
-#pragma unroll
-      for (int v = 0; v < kScanUnroll; ++v) {
-        if (c0 + v >= total) continue;
-        const float ex = pf[v].x - qfx, ey = pf[v].y - qfy, ez = pf[v].z - qfz;
-        const float a2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
-        if (a2 > thr2) continue;  // strictly farther than the best, whatever the rounding
-        const int cn = __float_as_int(pf[v].w);
-        if (cn == b.canon) continue;
-        const GridPoint pt = g.cpt[cn];
-        const double d2 = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
-        if (d2 < b.d || (d2 == b.d && pt.orig < b.orig)) {
-          second = fmin(second, b.d);  // the old best is now one of the others
-          b.d = d2; b.orig = pt.orig; b.canon = cn;
-          const float tb = __builtin_amdgcn_sqrtf((float)b.d) * 1.000001f * inv_hf + (3e-4f + kBallMarginCells);
-          thr2 = tb * tb;
-        } else {
-          second = fmin(second, d2);
-        }
-      }
-    }
-  }
-  return true;
-}
-
-// lower bound (rounded down, as float) of the distance from the query to every target other than its match
-__device__ __forceinline__ float second_bound(double best_d2, double second_d2, double h) {
-  const double lb = fmin(sqrt(second_d2), sqrt(best_d2) + (double)kBallMarginCells * h) * (1.0 - 1e-7);
-  return __double2float_rd(lb);
-}
-
-// K1 at the finest level once bounds exist: the CERTIFICATE kernel.  Between two ICP iterations the mapped
-// source moves by u = |T'(x) - T(x)|, tiny near convergence.  Every target other than the previous match p
-// was at least L away from T(x) (L = d2lb[s]), so it is at least L - u away from T'(x); if
-// |T'(x) - q_p| + u < L the previous match is still the unique nearest neighbour (triangle inequality,
-// strict: no tie case) and the search is skipped: one streamed source record, one gathered target point.
-// L - u is the bound for the next search.  The sources that fail — well under a percent near convergence —
-// are listed and searched by k_match_list (thread per listed source, same ball search), so this kernel
-// stays a streaming pass at full occupancy.  Slots are not rewritten here: at the finest level every source
-// stays active and its list position is re-derived from the permutation keys when matches are exported
-// (k_export).
-constexpr int kCertBlock = 256;
-constexpr int kShortList = 4096;  // listed sources up to which the wave-per-query kernel alone serves the list
-constexpr int kInlineList = 512;  // ... up to which the certificate kernel's own wavefronts serve it (k_match_cert_inline2)
-__device__ __forceinline__ void match_cert_body(const BallArgs &A) {
-  const int per = (int)gridDim.x >> 3;
-  const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  const int s = lblock * kCertBlock + threadIdx.x;
-  if (s >= A.nsrc) return;
-  const SrcPoint sp = A.src[s];
-  const int prev = A.m_to[s];
-  const float L = A.d2lb[s];
-  A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-  if (prev >= 0 && L > 0.0f) {
-    const GridPoint q = A.to_pt[prev];
-    double yx, yy, yz, ox, oy, oz;
-    map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
-    map_loc(A.xf_prev, sp.x, sp.y, sp.z, ox, oy, oz);
-    const double u = sqrt(dist2(yx, yy, yz, ox, oy, oz));
-    const double d1 = sqrt(dist2(yx, yy, yz, q.x, q.y, q.z));
-    if ((d1 + u) * (1.0 + 1e-7) < (double)L) {
-      A.d2lb[s] = __double2float_rd(((double)L - u) * (1.0 - 1e-7));
-      return;
-    }
-  }
-  A.list[atomicAdd(A.list_count, 1)] = s;
-}
-__global__ __launch_bounds__(kCertBlock) void k_match_cert(BallArgs A) { match_cert_body(A); }
-__global__ __launch_bounds__(kCertBlock) void k_match_cert2(BallArgs A, BallArgs B) {
-  if (blockIdx.y == 0) match_cert_body(A);
-  else match_cert_body(B);
-}
-
-// the sources the certificate kernel listed: thread per list entry, ball search around the previous match
-__device__ __forceinline__ void match_list_body(const BallArgs &A) {
-  const int e = blockIdx.x * kBallBlock + threadIdx.x;
-  if (e >= *A.list_count) return;
-  const int s = A.list[e];
-  const SrcPoint sp = A.src[s];
-  const int prev = A.m_to[s];
-  if (prev < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; A.d2lb[s] = 0.0f; return; }
-  double yx, yy, yz;
-  map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
-  Best b;
-  double second;
-  if (ball_search(A.g, A.to_pt, yx, yy, yz, prev, A.budget, A.max_rad, b, second)) {
-    A.m_to[s] = b.canon;
-    A.d2lb[s] = second_bound(b.d, second, A.g.h);
-  } else {
-    A.hard[atomicAdd(A.hard_count, 1)] = s;
-    A.d2lb[s] = 0.0f;
-  }
-}
-__global__ __launch_bounds__(kBallBlock) void k_match_list(BallArgs A) { match_list_body(A); }
-__global__ __launch_bounds__(kBallBlock) void k_match_list2(BallArgs A, BallArgs B) {
-  if (blockIdx.y == 0) match_list_body(A);
-  else match_list_body(B);
-}
-
-__device__ __forceinline__ void match_ball_body(const BallArgs &A) {
-  const GridView &g = A.g;
-  const SrcPoint *src = A.src;
-  const int nsrc = A.nsrc;
-  // workgroups go round robin over the 8 XCDs (each with its own L2): give every XCD one contiguous
-  // eighth of the canonical (spatially sorted) source range, so that its L2 holds one region of the
-  // target structures instead of a sample of all of them
-  const int per = (int)gridDim.x >> 3;  // the grid is a multiple of 8 blocks (ball_blocks_for)
-  const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  const int s = lblock * kBallBlock + threadIdx.x;
-  if (s >= nsrc) return;
-  const SrcPoint sp = src[s];
-  const int prev = A.m_to[s];
-  const int j = subset_perm_inv((int)sp.orig, nsrc, A.half, A.keys);
-  const bool active = j < A.n_points;
-  A.slot[s] = active ? j : -1;
-  if (!active) return;
-  A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-  if (prev < 0) { A.hard[atomicAdd(A.hard_count, 1)] = s; A.d2lb[s] = 0.0f; return; }
-  double yx, yy, yz;
-  map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
-  Best b;
-  double second;
-  if (ball_search(g, A.to_pt, yx, yy, yz, prev, A.budget, A.max_rad, b, second)) {
-    A.m_to[s] = b.canon;
-    A.d2lb[s] = second_bound(b.d, second, g.h);
-  } else {
-    A.hard[atomicAdd(A.hard_count, 1)] = s;  // m_to[s] keeps the previous match: a bound for phase 2
-    A.d2lb[s] = 0.0f;                        // phase 2 leaves no bound: the next search of s is a full one
-  }
-}
-__global__ __launch_bounds__(kBallBlock) void k_match_ball(BallArgs A) { match_ball_body(A); }
-// both directions of a symmetric estimator in one launch: blockIdx.y picks the direction
-__global__ __launch_bounds__(kBallBlock) void k_match_ball2(BallArgs A, BallArgs B) {
-  if (blockIdx.y == 0) match_ball_body(A);
-  else match_ball_body(B);
-}
-
-// K1 phase 2: the queries phase 1 handed over (far from any target feature, next to cells too
-// dense for one lane, without a previous match, or in a chunk whose box did not fit LDS).  One
-// WAVEFRONT per query.  Cell runs (an x-run of one (z,y) row) are taken 64 at a time: each lane
-// box-prunes one run and fetches its [start, end) range, a wave prefix sum turns the runs into one
-// candidate list, and the lanes stride over THAT list (binary search in LDS from candidate number
-// to run) — every lane busy whatever the point distribution; lanes are merged by a
-// lexicographic (distance, index) shuffle reduction.  With a previous match (use_prev) the runs
-// are the rows of the ball of that radius and the result is final; otherwise ring r = 0, 1, ...
-// with the interior-face stopping rule.  Same exact nearest neighbour either way.
-__device__ __forceinline__ void wave_scan_runs(const GridView &g, int (*seg_s)[64], int (*seg_pre)[64], int wv,
-                                               int lane, int s0, int e0, double yx, double yy, double yz,
-                                               Best &b, int skip_canon, double &second) {
-  int c0 = e0 - s0, incl = c0;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
-  int total = __shfl(incl, 63, 64);
-  if (total <= 0) return;
-  seg_s[wv][lane] = s0;
-  seg_pre[wv][lane] = incl - c0;
-  __builtin_amdgcn_wave_barrier();
-  Best l;  // this lane's best in the chunk
-  l.d = INFINITY; l.orig = 0x7fffffff; l.canon = 0;
-  double l2 = INFINITY;  // ... and the distance of its runner-up (second-nearest bound of the certificate)
-  for (int c = lane; c < total; c += 64) {
-    int lo = 0, hi = 64;  // last run whose exclusive prefix is <= c
-#pragma unroll
-    for (int step = 0; step < 6; ++step) {
-      int mid = (lo + hi) >> 1;
-      if (seg_pre[wv][mid] <= c) lo = mid; else hi = mid;
-    }
-    GridPoint pt = g.gp[seg_s[wv][lo] + (c - seg_pre[wv][lo])];
-    if (pt.canon == skip_canon) continue;  // the point the search was seeded with (already in b)
-    const double d2 = dist2(yx, yy, yz, pt.x, pt.y, pt.z);
-    if (d2 < l.d || (d2 == l.d && pt.orig < l.orig)) { l2 = fmin(l2, l.d); l.d = d2; l.orig = pt.orig; l.canon = pt.canon; }
-    else l2 = fmin(l2, d2);
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    double d2 = __shfl_xor(l.d, off, 64), s2 = __shfl_xor(l2, off, 64);
-    int o2 = __shfl_xor(l.orig, off, 64), c2 = __shfl_xor(l.canon, off, 64);
-    if (d2 < l.d || (d2 == l.d && o2 < l.orig)) { l2 = fmin(fmin(l2, s2), l.d); l.d = d2; l.orig = o2; l.canon = c2; }
-    else l2 = fmin(fmin(l2, s2), d2);
-  }
-  if (l.d < b.d || (l.d == b.d && l.orig < b.orig)) { second = fmin(fmin(second, l2), b.d); b = l; }
-  else second = fmin(fmin(second, l2), l.d);
-}
-
-// One wavefront settles a query that has a previous match: the rows of the ball of that radius (kBallMarginCells
-// wider: what is left out is provably farther than best + margin, second_bound), 64 at a time — exact whatever the
-// ball's size.  b: the nearest target (wave-uniform); second: smallest distance^2 among the others it saw.
-__device__ __forceinline__ void wave_ball_prev(const GridView &g, const GridPoint *to_pt, int (*seg_s)[64], int (*seg_pre)[64], int wv, int lane,
-                                               double yx, double yy, double yz, int prev, Best &b, double &second) {
-  const GridPoint pq = to_pt[prev];
-  b.d = dist2(yx, yy, yz, pq.x, pq.y, pq.z);
-  b.orig = pq.orig;
-  b.canon = prev;
-  const double margin = (double)kBallMarginCells * g.h;
-  double rad = sqrt(b.d) + 2.0 * g.tol + margin;
-  int za = clampi((int)floor((yz - rad - g.loz) * g.inv_h), 0, g.dz - 1), zb = clampi((int)floor((yz + rad - g.loz) * g.inv_h), 0, g.dz - 1);
-  int ya = clampi((int)floor((yy - rad - g.loy) * g.inv_h), 0, g.dy - 1), yb = clampi((int)floor((yy + rad - g.loy) * g.inv_h), 0, g.dy - 1);
-  int nyb = yb - ya + 1, nitems = (zb - za + 1) * nyb;
-  for (int base = 0; base < nitems; base += 64) {
-    int t = base + lane, s0 = 0, e0 = 0;
-    const double bm = sqrt(b.d) + margin, bm2 = bm * bm;
-    if (t < nitems) {
-      int z = za + t / nyb, y = ya + t % nyb;
-      double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
-      double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
-      double dyz2 = gz_ * gz_ + gy_ * gy_;
-      if (dyz2 <= bm2) {
-        double rx = sqrt(bm2 - dyz2) + 2.0 * g.tol;
-        int xa = clampi((int)floor((yx - rx - g.lox) * g.inv_h), 0, g.dx - 1);
-        int xb = clampi((int)floor((yx + rx - g.lox) * g.inv_h), 0, g.dx - 1);
-        int row = (z * g.dy + y) * g.dx;
-        s0 = g.cell_start[row + xa]; e0 = g.cell_start[row + xb + 1];
-      }
-    }
-    wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b, prev, second);
-  }
-}
-
-struct HardArgs {  // one direction of the wave-per-query phase
-  GridView g;
-  QSrc q;
-  XfD xf;
-  const int *hard, *hard_count;
-  int use_prev;
-  const GridPoint *to_pt;  // target points in canonical order
-  int *m_to, *overflow, *overflow_count;
-  float *d2lb;  // second-nearest bounds of the queries settled through their previous match (may be null)
-  unsigned long long *stats;  // certificate statistics (lrr_icp_cert_stats): {sources seen, sources listed}; null = none
-  unsigned long long seen;
-  const int *listed;          // the certificate kernel's list counter
-};
-__device__ __forceinline__ void match_hard_body(const HardArgs &A) {
-  __shared__ int seg_s[kBlock / 64][64], seg_pre[kBlock / 64][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const GridView &g = A.g;
-  const QSrc &q = A.q;
-  const XfD &xf = A.xf;
-  const int *hard = A.hard;
-  const int use_prev = A.use_prev;
-  int *m_to = A.m_to, *overflow = A.overflow, *overflow_count = A.overflow_count;
-  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
-  const int cnt = *A.hard_count;
-  if (A.stats && blockIdx.x == 0 && threadIdx.x == 0) {
-    atomicAdd(&A.stats[0], A.seen);
-    atomicAdd(&A.stats[1], (unsigned long long)*A.listed);
-  }
-  for (int o = wave; o < cnt; o += nwaves) {
-    int s = hard[o];
-    double yx, yy, yz;
-    mapped_query(g, q, xf, s, yx, yy, yz);
-    int cx = clampi((int)floor((yx - g.lox) * g.inv_h), 0, g.dx - 1);
-    int cy = clampi((int)floor((yy - g.loy) * g.inv_h), 0, g.dy - 1);
-    int cz = clampi((int)floor((yz - g.loz) * g.inv_h), 0, g.dz - 1);
-    Best b;  // wave-uniform best so far
-    b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
-    bool done = false;
-    int prev = use_prev ? m_to[s] : -1;
-    double second = INFINITY;  // smallest distance^2 among the other targets seen (prev branch: certificate bound)
-    if (prev < 0 && A.d2lb && lane == 0) A.d2lb[s] = 0.0f;  // the ring walk leaves no bound: the next search of s is a full one
-    if (prev >= 0) {
-      wave_ball_prev(g, A.to_pt, seg_s, seg_pre, wv, lane, yx, yy, yz, prev, b, second);
-      done = true;
-      if (lane == 0 && A.d2lb) A.d2lb[s] = second_bound(b.d, second, g.h);
-    }
-    for (int r = 0; r <= kRingMax && !done; ++r) {
-      const int side = 2 * r + 1, nitems = 2 * side * side;
-      for (int base = 0; base < nitems; base += 64) {
-        int t = base + lane, s0 = 0, e0 = 0;  // one cell run per lane
-        if (t < nitems) {
-          int rowi = t >> 1, which = t & 1;
-          int z = cz - r + rowi / side, y = cy - r + rowi % side;
-          if (z >= 0 && z < g.dz && y >= 0 && y < g.dy) {
-            double gz_ = slab_gap(yz, g.loz + z * g.h, g.loz + (z + 1) * g.h, g.tol);
-            double gy_ = slab_gap(yy, g.loy + y * g.h, g.loy + (y + 1) * g.h, g.tol);
-            double dyz2 = gz_ * gz_ + gy_ * gy_;
-            if (dyz2 <= b.d) {
-              int row = (z * g.dy + y) * g.dx;
-              bool shell = (z - cz == r) || (cz - z == r) || (y - cy == r) || (cy - y == r);
-              if (shell) {
-                if (which == 0) {
-                  int xa = max(cx - r, 0), xb = min(cx + r, g.dx - 1);
-                  if (b.d < INFINITY) {
-                    double rad = sqrt(b.d - dyz2) + 2.0 * g.tol;
-                    xa = max(xa, (int)floor((yx - rad - g.lox) * g.inv_h));
-                    xb = min(xb, (int)floor((yx + rad - g.lox) * g.inv_h));
-                  }
-                  if (xa <= xb) { s0 = g.cell_start[row + xa]; e0 = g.cell_start[row + xb + 1]; }
-                }
-              } else if (r > 0) {
-                int xc = which == 0 ? cx - r : cx + r;
-                if (xc >= 0 && xc <= g.dx - 1) {
-                  double gx_ = slab_gap(yx, g.lox + xc * g.h, g.lox + (xc + 1) * g.h, g.tol);
-                  if (dyz2 + gx_ * gx_ <= b.d) { s0 = g.cell_start[row + xc]; e0 = g.cell_start[row + xc + 1]; }
-                }
-              }
-            }
-          }
-        }
-        wave_scan_runs(g, seg_s, seg_pre, wv, lane, s0, e0, yx, yy, yz, b, -1, second);
-      }
-      done = ring_settled(ring_bound(g, cx, cy, cz, r, yx, yy, yz), g.tol, b.d);
-    }
-    if (lane == 0) {
-      if (done) m_to[s] = result_index(q, b);
-      else overflow[atomicAdd(overflow_count, 1)] = s;
-    }
-  }
-}
-__global__ __launch_bounds__(kBlock) void k_match_hard(HardArgs A) { match_hard_body(A); }
-__global__ __launch_bounds__(kBlock) void k_match_hard2(HardArgs A, HardArgs B) {
-  if (blockIdx.y == 0) match_hard_body(A);
-  else match_hard_body(B);
-}
-
-// The certificate kernel with the search inside: near convergence a few dozen of some hundred thousand sources fail the
-// certificate, and a kernel of its own for them costs several microseconds of launch, ramp and drain for microseconds of
-// work.  Here the wavefront that finds failing sources settles them itself, one after the other, all 64 lanes on one
-// query (wave_ball_prev: the search of the wave-per-query kernel, same result).  Used while the lists stay short
-// (lrr_icp_match_pair decides from the previous search's count); list_count still counts the failures.
-__device__ __forceinline__ void match_cert_inline_body(const BallArgs &A) {
-  __shared__ int seg_s[kCertBlock / 64][64], seg_pre[kCertBlock / 64][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int per = (int)gridDim.x >> 3;
-  const int lblock = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  const int s = lblock * kCertBlock + threadIdx.x;
-  bool fail = false;
-  int prev = -1;
-  double yx = 0.0, yy = 0.0, yz = 0.0;
-  if (s < A.nsrc) {
-    const SrcPoint sp = A.src[s];
-    prev = A.m_to[s];
-    const float L = A.d2lb[s];
-    A.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-    map_loc(A.xf, sp.x, sp.y, sp.z, yx, yy, yz);
-    fail = true;
-    if (prev >= 0 && L > 0.0f) {
-      const GridPoint q = A.to_pt[prev];
-      double ox, oy, oz;
-      map_loc(A.xf_prev, sp.x, sp.y, sp.z, ox, oy, oz);
-      const double u = sqrt(dist2(yx, yy, yz, ox, oy, oz));
-      const double d1 = sqrt(dist2(yx, yy, yz, q.x, q.y, q.z));
-      if ((d1 + u) * (1.0 + 1e-7) < (double)L) {
-        A.d2lb[s] = __double2float_rd(((double)L - u) * (1.0 - 1e-7));
-        fail = false;
-      }
-    }
-  }
-  unsigned long long todo = __ballot(fail);
-  if (todo == 0ull) return;
-  if (lane == 0) atomicAdd(A.list_count, (int)__popcll(todo));
-  while (todo) {
-    const int l = __ffsll((long long)todo) - 1;
-    todo &= todo - 1ull;
-    const int qs = __shfl(s, l, 64), qprev = __shfl(prev, l, 64);
-    const double qx = __shfl(yx, l, 64), qy = __shfl(yy, l, 64), qz = __shfl(yz, l, 64);
-    Best b;
-    double second = INFINITY;
-    if (qprev < 0) {
-      // no source is without a match once bounds exist (this kernel runs only then); should one be, the wavefront scans
-      // the whole target cloud as ONE run: exact, slow, and no other kernel has to follow this one
-      b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
-      wave_scan_runs(A.g, seg_s, seg_pre, wv, lane, 0, lane == 0 ? A.g.n : 0, qx, qy, qz, b, -1, second);
-    } else {
-      wave_ball_prev(A.g, A.to_pt, seg_s, seg_pre, wv, lane, qx, qy, qz, qprev, b, second);
-    }
-    if (lane == 0) { A.m_to[qs] = b.canon; A.d2lb[qs] = second_bound(b.d, second, A.g.h); }
-  }
-}
-__global__ __launch_bounds__(kCertBlock) void k_match_cert_inline(BallArgs A) { match_cert_inline_body(A); }
-__global__ __launch_bounds__(kCertBlock) void k_match_cert_inline2(BallArgs A, BallArgs B) {
-  if (blockIdx.y == 0) match_cert_inline_body(A);
-  else match_cert_inline_body(B);
-}
-
-// K1 phase 3: brute force for the (rare) queries still open after kRingMax rings: one block each
-struct OverArgs { GridView g; QSrc q; XfD xf; const int *overflow, *overflow_count; int *m_to; };
-__device__ __forceinline__ void match_overflow_body(const OverArgs &A) {
-  __shared__ double sd[kBlock];
-  __shared__ int so[kBlock], sc[kBlock];
-  const GridView &g = A.g;
-  const QSrc &q = A.q;
-  const XfD &xf = A.xf;
-  const int *overflow = A.overflow;
-  int *m_to = A.m_to;
-  int cnt = *A.overflow_count;
-  for (int o = blockIdx.x; o < cnt; o += gridDim.x) {
-    int s = overflow[o];
-    double yx, yy, yz;
-    mapped_query(g, q, xf, s, yx, yy, yz);
-    Best b;
-    b.d = INFINITY; b.orig = 0x7fffffff; b.canon = 0;
-    for (int j = threadIdx.x; j < g.n; j += kBlock) {
-      GridPoint pt = g.gp[j];
-      consider(b, dist2(yx, yy, yz, pt.x, pt.y, pt.z), pt.orig, pt.canon);
-    }
-    sd[threadIdx.x] = b.d; so[threadIdx.x] = b.orig; sc[threadIdx.x] = b.canon;
-    __syncthreads();
-    for (int st = kBlock / 2; st > 0; st >>= 1) {
-      if ((int)threadIdx.x < st) {
-        Best a; a.d = sd[threadIdx.x]; a.orig = so[threadIdx.x]; a.canon = sc[threadIdx.x];
-        consider(a, sd[threadIdx.x + st], so[threadIdx.x + st], sc[threadIdx.x + st]);
-        sd[threadIdx.x] = a.d; so[threadIdx.x] = a.orig; sc[threadIdx.x] = a.canon;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) { Best a; a.d = sd[0]; a.orig = so[0]; a.canon = sc[0]; m_to[s] = result_index(q, a); }
-    __syncthreads();
-  }
-}
-__global__ __launch_bounds__(kBlock) void k_match_overflow(OverArgs A) { match_overflow_body(A); }
-__global__ __launch_bounds__(kBlock) void k_match_overflow2(OverArgs A, OverArgs B) {
-  if (blockIdx.y == 0) match_overflow_body(A);
-  else match_overflow_body(B);
-}
-
-// slot assignment + active list for the all-vs-all matcher
-__global__ void k_slots_dense(const SrcPoint *src, Keys keys, int half, int nsrc, int n_points, int *slot,
-                              double *w, int *active, int *active_count) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nsrc) return;
-  int j = subset_perm_inv((int)src[s].orig, nsrc, half, keys);
-  bool a = j < n_points;
-  slot[s] = a ? j : -1;
-  if (a) { w[s] = 1.0; active[atomicAdd(active_count, 1)] = s; }
-}
-__global__ void k_slots_sparse(const int *order, int use_keys, Keys keys, int half, int nsrc, const int *canon_of,
-                               int n, int *slot, double *w, int *active) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int p = order ? order[i] : (use_keys ? subset_perm(i, nsrc, half, keys) : i);
-  int s = canon_of[p];
-  slot[s] = i;
-  w[s] = 1.0;
-  active[i] = s;
-}
-
-// Coarse levels of a symmetric estimator (a few thousand of the sources active): every active source goes straight
-// to the wave-per-query kernel — a thousand queries are a thousand wavefronts, each scanning its candidates with 64
-// lanes, where the thread-per-slot ring search walks them one dependent round at a time.  This kernel assigns the
-// list positions of both directions and writes the two work lists: a thread per SOURCE inverts the keyed permutation
-// for its own feature (position < n: active), so every slot is written — nothing has to be cleared first — and an
-// active source enters the work list AT its list position (a bijection onto [0, n): no counter.  Appending through one
-// atomic counter, even once per wavefront, cost 30 us: same-address atomics serialise in the L2).
-struct CoarseArgs { const SrcPoint *src; Keys keys; int half, nsrc, n; int *slot; double *w; int *list, *list_count; };
-__global__ void k_slots_coarse2(CoarseArgs A, CoarseArgs B) {
-  const CoarseArgs &C = blockIdx.y == 0 ? A : B;
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s == 0) *C.list_count = C.n;
-  if (s >= C.nsrc) return;
-  const int j = subset_perm_inv((int)C.src[s].orig, C.nsrc, C.half, C.keys);
-  const bool active = j < C.n;
-  C.slot[s] = active ? j : -1;
-  if (active) {
-    C.w[s] = 1.0;  // temporarily set weight to 1.0 (cdcl .txx:645)
-    C.list[j] = s; // the list position is a bijection onto [0, n): no counter, no atomics
-  }
-}
-
-// All-vs-all matcher: each block owns kBlock*Q queries (Q per thread, in registers) and streams
-// one chunk of the target cloud through LDS in tiles; every lane reads the same LDS address
-// (broadcast, conflict-free).  blockIdx.y splits the target cloud so that small query counts
-// still fill the chip; partial results are merged lexicographically by k_brute_merge.
-constexpr int kBruteQ = 2;
-constexpr int kBruteTile = 1024;
-
-__global__ __launch_bounds__(kBlock) void k_match_brute(GridView g, QSrc q, const int *active, XfD xf, int n,
-                                                        int chunk, double *pd, int *po, int *pc) {
-  __shared__ double sx[kBruteTile], sy[kBruteTile], sz[kBruteTile];
-  __shared__ int sorig[kBruteTile], scan[kBruteTile];
-  double yx[kBruteQ], yy[kBruteQ], yz[kBruteQ];
-  Best b[kBruteQ];
-  int qi[kBruteQ];
-#pragma unroll
-  for (int u = 0; u < kBruteQ; ++u) {
-    int i = (blockIdx.x * kBruteQ + u) * kBlock + threadIdx.x;
-    qi[u] = i;
-    b[u].d = INFINITY; b[u].orig = 0x7fffffff; b[u].canon = 0;
-    yx[u] = yy[u] = yz[u] = 0.0;
-    if (i < n) {
-      int s = active ? active[i] : i;
-      double x, y_, z_;
-      query_point(q, s, x, y_, z_);
-      map_loc(xf, x, y_, z_, yx[u], yy[u], yz[u]);
-      vor_quantize(g, yx[u], yy[u], yz[u]);
-    }
-  }
-  int begin = blockIdx.y * chunk, end = min(begin + chunk, g.n);
-  for (int base = begin; base < end; base += kBruteTile) {
-    int tn = min(kBruteTile, end - base);
-    __syncthreads();
-    for (int j = threadIdx.x; j < tn; j += kBlock) {
-      GridPoint pt = g.gp[base + j];
-      sx[j] = pt.x; sy[j] = pt.y; sz[j] = pt.z; sorig[j] = pt.orig; scan[j] = pt.canon;
-    }
-    __syncthreads();
-    for (int j = 0; j < tn; ++j) {
-      double ptx = sx[j], pty = sy[j], ptz = sz[j];
-      int oi = sorig[j], ci = scan[j];
-#pragma unroll
-      for (int u = 0; u < kBruteQ; ++u) consider(b[u], dist2(yx[u], yy[u], yz[u], ptx, pty, ptz), oi, ci);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < kBruteQ; ++u)
-    if (qi[u] < n) {
-      size_t o = (size_t)blockIdx.y * n + qi[u];
-      pd[o] = b[u].d; po[o] = b[u].orig; pc[o] = b[u].canon;
-    }
-}
-
-__global__ void k_brute_merge(const double *pd, const int *po, const int *pc, int n, int S, QSrc q,
-                              const int *active, int *m_to) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Best b;
-  b.d = pd[i]; b.orig = po[i]; b.canon = pc[i];
-  for (int s2 = 1; s2 < S; ++s2) consider(b, pd[(size_t)s2 * n + i], po[(size_t)s2 * n + i], pc[(size_t)s2 * n + i]);
-  m_to[active ? active[i] : i] = result_index(q, b);
-}
-
-// ---------------------------------------------------------------------------------------------
-// per-match passes.  Arrays are indexed by the canonical source position s; slot[s] < 0 marks a
-// source feature that is not in the active subset.
-// ---------------------------------------------------------------------------------------------
-struct PairSrc {
-  const SrcPoint *from_src;        // compact from-locations and ...
-  const double *from_str;          // ... from-strengths: 40 B per source instead of the 80-B record
-  const double *from_rec, *to_rec;
-  const int *slot, *m_to;
-  const double *from_loc;  // pre-mapped copies or nullptr
-  int nsrc;
-};
-
-__device__ __forceinline__ void load_from(const PairSrc &ps, int s, double &p0, double &p1, double &p2) {
-  if (ps.from_loc) {
-    p0 = ps.from_loc[3 * (size_t)s]; p1 = ps.from_loc[3 * (size_t)s + 1]; p2 = ps.from_loc[3 * (size_t)s + 2];
-  } else {
-    const SrcPoint r = ps.from_src[s];
-    p0 = r.x; p1 = r.y; p2 = r.z;
-  }
-}
-
-// rigid pre-map (cdcl .txx:467-482)
-__global__ void k_premap(PairSrc ps, XfD G, double *out) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ps.nsrc || ps.slot[s] < 0) return;
-  double p0, p1, p2, y0, y1, y2;
-  load_from(ps, s, p0, p1, p2);
-  map_loc(G, p0, p1, p2, y0, y1, y2);
-  out[3 * (size_t)s] = y0; out[3 * (size_t)s + 1] = y1; out[3 * (size_t)s + 2] = y2;
-}
-
-__device__ __forceinline__ double pair_residual2(const PairSrc &ps, int s, const XfD &xf, const NormD &nm) {
-  double p0, p1, p2;
-  load_from(ps, s, p0, p1, p2);
-  p0 = (p0 - nm.cm[0]) / nm.rm; p1 = (p1 - nm.cm[1]) / nm.rm; p2 = (p2 - nm.cm[2]) / nm.rm;
-  const double *q = ps.to_rec + (size_t)ps.m_to[s] * kRecStride;
-  double q0 = (q[0] - nm.cf[0]) / nm.rf, q1 = (q[1] - nm.cf[1]) / nm.rf, q2 = (q[2] - nm.cf[2]) / nm.rf;
-  double y0, y1, y2;
-  map_loc(xf, p0, p1, p2, y0, y1, y2);
-  return proj_residual2(y0, y1, y2, q0, q1, q2, q[3], q[4], q[5], q[6], q[7], q[8]);
-}
-
-// K2 pass 1 (cdcl .txx:677-708; rrl .txx:594-617)
-__global__ __launch_bounds__(kBlock) void k_residual(PairSrc ps, XfD xf, NormD nm, const double *w_prev,
-                                                     double *r2_out, double *dist_out, double *partials) {
-  double acc[2] = {0.0, 0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
-    if (ps.slot[s] < 0) { dist_out[s] = INFINITY; continue; }
-    double r2 = pair_residual2(ps, s, xf, nm);
-    double wp = w_prev[s];
-    acc[0] += wp * r2;
-    acc[1] += wp;
-    r2_out[s] = r2;
-    dist_out[s] = sqrt(r2);
-  }
-  block_reduce_store<2>(acc, partials);
-}
-
-// K2 pass 2 (cdcl .txx:744-765, weight_BT cdcl_utils.h:142-152)
-__global__ void k_assign(const int *slot, const double *r2, double scale, int nsrc, double *w) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nsrc || slot[s] < 0) return;
-  double scale2 = scale * scale;
-  double u = r2[s] / scale2;
-  double bt = 0.0;
-  if (u <= 16.0) { double temp = 1 - u * 0.0625; bt = temp * temp; }
-  w[s] = bt / scale2;
-}
-
-// K4 (cdcl .txx:196-268)
-// host_rows (may be null): mapped host memory; the block then stores its three sums there itself, each in a 16-byte
-// chunk {sum, tag} written by ONE store instruction, and the host adds the rows (lrr_icp_errors) — no reduction launch
-// behind this kernel.  A chunk is valid once its tag is there: no ordering between stores is relied on.
-__global__ __launch_bounds__(kWide) void k_errors(PairSrc ps, XfD xf, NormD nm, const double *w, double *partials, double *host_rows, double tag) {
-  double acc[3] = {0.0, 0.0, 0.0};
-  for (int s = xcd_block(blockIdx.x, gridDim.x) * kWide + threadIdx.x; s < ps.nsrc; s += gridDim.x * kWide) {
-    if (ps.slot[s] < 0) continue;
-    double r2 = pair_residual2(ps, s, xf, nm);
-    double wi = w[s];
-    acc[0] += r2;
-    acc[1] += sqrt(r2) * wi;
-    acc[2] += wi;
-  }
-  block_reduce_store<3, kWide / 64>(acc, partials);
-  if (host_rows && threadIdx.x < 3) {
-    // (the thread that stored partials[3 blockIdx + k] holds that sum: re-read its own store)
-    const double2 chunk = make_double2(partials[(size_t)blockIdx.x * 3 + threadIdx.x], tag);
-    *reinterpret_cast<double2 *>(host_rows + (size_t)blockIdx.x * 8 + 2 * threadIdx.x) = chunk;
-  }
-}
-
-// K5 statistics (cdcl .txx:1175-1213)
-__global__ __launch_bounds__(kBlock) void k_from_sum(PairSrc ps, double *partials) {
-  double acc[3] = {0.0, 0.0, 0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
-    if (ps.slot[s] < 0) continue;
-    double p0, p1, p2;
-    load_from(ps, s, p0, p1, p2);
-    acc[0] += p0; acc[1] += p1; acc[2] += p2;
-  }
-  block_reduce_store<3>(acc, partials);
-}
-
-// distinct matched targets: flag[j] == gen marks j for THIS call (the stamp changes per call, so the
-// array is never cleared)
-__global__ void k_mark(const int *slot, const int *m_to, int nsrc, unsigned *flag, unsigned gen) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < nsrc && slot[s] >= 0) flag[m_to[s]] = gen;  // benign race: every writer stores the same stamp
-}
-
-// (to_pt: the compact canonical points, 32 B each, streamed — same coordinates as the 80-B records; stamp and point
-// are loaded together: one memory round trip)
-__global__ __launch_bounds__(kWide) void k_to_sum(const GridPoint *to_pt, const unsigned *flag, unsigned gen, int nt,
-                                                   double *partials) {
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int j = blockIdx.x * kWide + threadIdx.x; j < nt; j += gridDim.x * kWide) {
-    const unsigned f = flag[j];
-    const GridPoint q = to_pt[j];
-    if (f == gen) { acc[0] += q.x; acc[1] += q.y; acc[2] += q.z; acc[3] += 1.0; }
-  }
-  block_reduce_store<4, kWide / 64>(acc, partials);
-}
-
-__global__ __launch_bounds__(kBlock) void k_radii(PairSrc ps, const double *to_rec, const unsigned *flag, unsigned gen, int nt,
-                                                  double cm0, double cm1, double cm2, double cf0, double cf1,
-                                                  double cf2, double *partials) {
-  double acc[2] = {0.0, 0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
-    if (ps.slot[s] < 0) continue;
-    double p0, p1, p2;
-    load_from(ps, s, p0, p1, p2);
-    p0 -= cm0; p1 -= cm1; p2 -= cm2;
-    acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
-  }
-  for (int j = blockIdx.x * kBlock + threadIdx.x; j < nt; j += gridDim.x * kBlock) {
-    if (flag[j] == gen) {
-      const double *q = to_rec + (size_t)j * kRecStride;
-      double q0 = q[0] - cf0, q1 = q[1] - cf1, q2 = q[2] - cf2;
-      acc[1] += sqrt((q0 * q0 + q1 * q1) + q2 * q2);
-    }
-  }
-  block_reduce_store<2>(acc, partials);
-}
-
-// per-match sums of a list whose to_ objects are all distinct (the role-reversed clones of add_constraints, cdcl sym
-// .txx:367-393): sum of from-locations, sum of to-locations, sum |from - c_from|, sum |to - c_to|
-__global__ __launch_bounds__(kBlock) void k_pair_stats(PairSrc ps, const double *to_rec, double cf0, double cf1, double cf2,
-                                                       double ct0, double ct1, double ct2, double *partials) {
-  double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
-    if (ps.slot[s] < 0) continue;
-    double p0, p1, p2;
-    load_from(ps, s, p0, p1, p2);
-    const double *q = to_rec + (size_t)ps.m_to[s] * kRecStride;
-    acc[0] += p0; acc[1] += p1; acc[2] += p2;
-    acc[3] += q[0]; acc[4] += q[1]; acc[5] += q[2];
-    const double a0 = p0 - cf0, a1 = p1 - cf1, a2 = p2 - cf2, b0 = q[0] - ct0, b1 = q[1] - ct1, b2 = q[2] - ct2;
-    acc[6] += sqrt((a0 * a0 + a1 * a1) + a2 * a2);
-    acc[7] += sqrt((b0 * b0 + b1 * b1) + b2 * b2);
-  }
-  block_reduce_store<8>(acc, partials);
-}
-
-__device__ __forceinline__ double strength_gain(const PairSrc &ps, int s, int float_product) {
-  double sp = ps.from_str[s];
-  double sq = ps.to_rec[(size_t)ps.m_to[s] * kRecStride + 9];
-  double g = float_product ? (double)((float)sp * (float)sq) : sp * sq;
-  return g > 90000.0 ? 90000.0 : g;
-}
-
-// weight_by_strength, first loop (cdcl .txx:832-851; rrl .txx:728-743)
-__global__ __launch_bounds__(kBlock) void k_strength(PairSrc ps, int float_product, double *w, double *key,
-                                                     double *partials) {
-  double acc[1] = {0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
-    double k = INFINITY;
-    if (ps.slot[s] >= 0) {
-      double wi = w[s];
-      if (wi != 0) {
-        double g = strength_gain(ps, s, float_product);
-        w[s] = wi * g;
-        k = g;
-        acc[0] += 1.0;
-      }
-    }
-    key[s] = k;
-  }
-  block_reduce_store<1>(acc, partials);
-}
-
-// spatial weight 1 / (1 + 5 |q~|^2) of the normalised to_ location (cdcl .txx:984-985); use_from:
-// the to_ of a role-reversed clone is this direction's from_
-__device__ __forceinline__ double spatial_weight(const PairSrc &ps, int s, const NormD &nm, int use_from) {
-  double q0, q1, q2;
-  if (use_from) {
-    load_from(ps, s, q0, q1, q2);
-    q0 = (q0 - nm.cm[0]) / nm.rm; q1 = (q1 - nm.cm[1]) / nm.rm; q2 = (q2 - nm.cm[2]) / nm.rm;
-  } else {
-    const double *q = ps.to_rec + (size_t)ps.m_to[s] * kRecStride;
-    q0 = (q[0] - nm.cf[0]) / nm.rf; q1 = (q[1] - nm.cf[1]) / nm.rf; q2 = (q[2] - nm.cf[2]) / nm.rf;
-  }
-  double d = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
-  return 1.0 / (1.0 + 5.0 * d * d);
-}
-
-// weight_spatially, first loop (cdcl .txx:977-990; rrl .txx:760-770)
-__global__ void k_spatial(PairSrc ps, NormD nm, int use_from, double *w, double *key) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ps.nsrc) return;
-  if (ps.slot[s] < 0) { key[s] = INFINITY; return; }
-  double sw = spatial_weight(ps, s, nm, use_from);
-  w[s] *= sw;
-  key[s] = sw;
-}
-
-__global__ void k_scale_w(const int *slot, double *w, int nsrc, double f) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < nsrc && slot[s] >= 0) w[s] *= f;
-}
-
-__global__ void k_copy_w(const double *src, double *dst, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i];
-}
-
-// matches_ in the reference's list order: (original from index, original to index, weight)
-// Voronoi-lookup search: the matches of the active sources are canonical indices of the SITE cloud (occupied
-// voxels); each site carries the feature whose index the reference's volume stores in that voxel
-// the keys of a list's active sources, gathered by list position (a bijection onto [0, n): no atomics, fixed layout)
-__global__ void k_compact_by_slot(const int *slot, const double *key, int nsrc, double *dense) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nsrc) return;
-  const int j = slot[s];
-  if (j >= 0) dense[j] = key[s];
-}
-
-__global__ void k_vor_remap(const int *slot, int *m_to, const int *site_to_feature, int nsrc) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < nsrc && slot[s] >= 0) m_to[s] = site_to_feature[m_to[s]];
-}
-
-// lazy: the last search ran at the finest level without materialising list positions (k_match_cert):
-// every source is active and its position is perm^-1(original index) under that search's keys
-__global__ void k_export(const int *slot, const int *m_to, const double *w, const int *from_orig,
-                         const int *to_orig, int nsrc, long long *out_from, long long *out_to, double *out_w,
-                         int lazy, Keys keys, int half) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nsrc) return;
-  int j = lazy ? subset_perm_inv(from_orig[s], nsrc, half, keys) : slot[s];
-  if (j < 0) return;
-  out_from[j] = from_orig[s];
-  out_to[j] = to_orig[m_to[s]];
-  out_w[j] = w[s];
-}
-
-// K3 — normal equations.  Upper triangle + rhs per thread in registers, grid-stride over the
-// sources, fixed-order block reduction.  Per-pair products follow the reference's operation
-// order (generic: (J^T P) J w, cdcl .txx:1061-1062; PREMUL: (J^T (P w)) J, rrl sym .txx:468-536)
-// so that only the ORDER of the sum differs from the CPU path.
-template <int DOF> struct Tri { static constexpr int N = DOF * (DOF + 1) / 2; };
-
-// per-pair update of the upper triangle (NT values) and the right-hand side (DOF values).
-// (jx,jy,jz): point the Jacobian is taken at; (b0,b1,b2): right-hand-side point; P: symmetric
-// projector (6 unique); (c0,c1,c2): centre of the transform.
-template <int DOF, bool PREMUL>
-__device__ __forceinline__ void accumulate_pair(double *acc, double wi, double jx, double jy, double jz,
-                                                double b0, double b1, double b2, double *P, double c0,
-                                                double c1, double c2, int rigid_increment) {
-  constexpr int NT = Tri<DOF>::N;
-  if (rigid_increment) { b0 = b0 - jx; b1 = b1 - jy; b2 = b2 - jz; }
-  if (PREMUL) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) P[k] = P[k] * wi;
-  }
-  const double Pm[3][3] = {{P[0], P[1], P[2]}, {P[1], P[3], P[4]}, {P[2], P[4], P[5]}};
-  double l0 = jx - c0, l1 = jy - c1, l2 = jz - c2;
-  if (DOF == 12) {
-    // affine Jacobian: J[d][3d+k] = l_k, J[d][9+d] = 1 (cdcl_trans_affine.txx:141-161);
-    // one non-zero per column, so (J^T P)[a][c] = lt[k_a] * P[d_a][c] exactly
-    const double lt[4] = {l0, l1, l2, 1.0};
-    int t = 0;
-#pragma unroll
-    for (int a = 0; a < 12; ++a) {
-      const int da = a < 9 ? a / 3 : a - 9, ka = a < 9 ? a % 3 : 3;
-      double Ma0 = lt[ka] * Pm[da][0], Ma1 = lt[ka] * Pm[da][1], Ma2 = lt[ka] * Pm[da][2];
-      const double Ma[3] = {Ma0, Ma1, Ma2};
-#pragma unroll
-      for (int b = a; b < 12; ++b) {
-        const int db = b < 9 ? b / 3 : b - 9, kb = b < 9 ? b % 3 : 3;
-        double v = Ma[db] * lt[kb];
-        acc[t++] += PREMUL ? v : v * wi;
-      }
-      double r = (Ma0 * b0 + Ma1 * b1) + Ma2 * b2;
-      acc[NT + a] += PREMUL ? r : r * wi;
-    }
-  } else {
-    // rigid small-angle Jacobian [-[l]x , I] (cdcl_trans_rigid3d.cxx:197-225)
-    const double J[3][6] = {{0.0, l2, -l1, 1.0, 0.0, 0.0}, {-l2, 0.0, l0, 0.0, 1.0, 0.0}, {l1, -l0, 0.0, 0.0, 0.0, 1.0}};
-    int t = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      double Ma[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Ma[c] = (J[0][a] * Pm[0][c] + J[1][a] * Pm[1][c]) + J[2][a] * Pm[2][c];
-#pragma unroll
-      for (int b = a; b < 6; ++b) {
-        double v = (Ma[0] * J[0][b] + Ma[1] * J[1][b]) + Ma[2] * J[2][b];
-        acc[t++] += PREMUL ? v : v * wi;
-      }
-      double r = (Ma[0] * b0 + Ma[1] * b1) + Ma[2] * b2;
-      acc[NT + a] += PREMUL ? r : r * wi;
-    }
-  }
-}
-
-// loads one match in normalised coordinates and orients it (reversed: role-reversed term)
-__device__ __forceinline__ void load_oriented(const PairSrc &ps, int s, const NormD &nm, int reversed,
-                                              double &jx, double &jy, double &jz, double &b0, double &b1,
-                                              double &b2, double *P) {
-  double p0, p1, p2;
-  load_from(ps, s, p0, p1, p2);
-  p0 = (p0 - nm.cm[0]) / nm.rm; p1 = (p1 - nm.cm[1]) / nm.rm; p2 = (p2 - nm.cm[2]) / nm.rm;
-  const double *qr = ps.to_rec + (size_t)ps.m_to[s] * kRecStride;
-  double q0 = (qr[0] - nm.cf[0]) / nm.rf, q1 = (qr[1] - nm.cf[1]) / nm.rf, q2 = (qr[2] - nm.cf[2]) / nm.rf;
-  if (!reversed) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) P[k] = qr[3 + k];
-    jx = p0; jy = p1; jz = p2;
-    b0 = q0; b1 = q1; b2 = q2;
-  } else {
-    const double *pr = ps.from_rec + (size_t)s * kRecStride;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) P[k] = pr[3 + k];
-    jx = q0; jy = q1; jz = q2;
-    b0 = p0; b1 = p1; b2 = p2;
-  }
-}
-
-template <int DOF, bool PREMUL>
-__global__ __launch_bounds__(kBlock) void k_accumulate(PairSrc ps, NormD nm, const double *w, double c0, double c1,
-                                                       double c2, int rigid_increment, int reversed,
-                                                       double *partials) {
-  constexpr int NT = Tri<DOF>::N;
-  double acc[NT + DOF];
-#pragma unroll
-  for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
-    if (ps.slot[s] < 0) continue;
-    double wi = w[s];
-    if (PREMUL && wi < 1e-4) continue;
-    double jx, jy, jz, b0, b1, b2, P[6];
-    load_oriented(ps, s, nm, reversed, jx, jy, jz, b0, b1, b2, P);
-    accumulate_pair<DOF, PREMUL>(acc, wi, jx, jy, jz, b0, b1, b2, P, c0, c1, c2, rigid_increment);
-  }
-  block_reduce_store<NT + DOF>(acc, partials);
-}
-
-// ---------------------------------------------------------------------------------------------
-// exact order statistics on the (non-negative) double bit patterns; stand in for
-// std::nth_element / std::sort.
-// k_select: one 1024-thread block per job, 6-pass MSB radix select with an LDS histogram; also
-// sums the keys below the k-th (needed by the trimmed MUSE scale; first estimate only).
-// k_selw_*: the per-iteration MAD scales in three launches.  The keys' bit patterns are binned in
-// a 2048-bin WINDOW around the job's previous result (the scales move little between ICP
-// iterations): 128 bins per binade, 8 binades either side, everything outside in the two end
-// bins.  hist: chip-wide histogram of the window.  collect: every block re-derives the bin holding
-// rank k and the keys of that bin are gathered (a few hundred).  final: one block per job selects
-// the exact k-th among them in LDS.  If the rank falls into an end bin or the bin is too full for
-// LDS, the final block runs the full radix select over all keys instead — slow, still exact.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long job_key(const SelJob &j, int i) {
-  double v = i < j.n0 ? j.k0[i] : j.k1[i - j.n0];
-  return (unsigned long long)__double_as_longlong(fabs(v));
-}
-
-// wave-aggregated LDS histogram update: keys of similar magnitude share their leading digits, so
-// one lane adds the whole group (two rounds), the stragglers use their own LDS atomic
-__device__ __forceinline__ void hist_add(int *hist, bool act, int dgt) {
-  int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int round = 0; round < 2; ++round) {
-    unsigned long long m = __ballot(act);
-    if (m == 0ull) break;
-    int leader = __ffsll((long long)m) - 1;
-    int d0 = __shfl(dgt, leader, 64);
-    unsigned long long same = __ballot(act && dgt == d0);
-    if (lane == leader) atomicAdd(&hist[d0], (int)__popcll(same));
-    if (dgt == d0) act = false;
-  }
-  if (act) atomicAdd(&hist[dgt], 1);
-}
-
-// Every thread owns B consecutive bins (v: their counts; B x blockDim.x = 2048): finds the bin
-// holding rank k.  sel[0] = bin, sel[1] = keys before it, sel[2] = keys in it; sel stays as preset
-// when k is out of range.
-template <int B>
-__device__ __forceinline__ void pick_from(const int (&v)[B], long long k, int *wave_tot, int *sel) {
-  int s = 0;
-#pragma unroll
-  for (int u = 0; u < B; ++u) s += v[u];
-  int incl = s;
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int x = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += x;
-  }
-  if (lane == 63) wave_tot[wv] = incl;
-  __syncthreads();
-  int before = 0;
-  for (int w2 = 0; w2 < wv; ++w2) before += wave_tot[w2];
-  int excl = before + incl - s;
-  if (s > 0 && k >= excl && k < excl + s) {
-#pragma unroll
-    for (int u = 0; u < B; ++u) {
-      if (k >= excl && k < excl + v[u]) { sel[0] = B * (int)threadIdx.x + u; sel[1] = excl; sel[2] = v[u]; }
-      excl += v[u];
-    }
-  }
-  __syncthreads();
-}
-template <int T>
-__device__ __forceinline__ void pick_bin(const int *h, long long k, int *wave_tot, int *sel) {
-  constexpr int B = 2048 / T;
-  int v[B];
-#pragma unroll
-  for (int u = 0; u < B; ++u) v[u] = h[B * threadIdx.x + u];
-  pick_from<B>(v, k, wave_tot, sel);
-}
-
-// 6-pass MSB radix select of rank k among n keys by one kSelThreads block; returns the key.
-// hist: 2048 ints, wave_tot: kSelThreads / 64 ints, sel: 3 ints of LDS.
-template <typename KeyAt>
-__device__ __forceinline__ unsigned long long radix_select_block(KeyAt key_at, int n, long long k, int *hist,
-                                                                 int *wave_tot, int *sel) {
-  unsigned long long prefix = 0, mask = 0;
-  const int shifts[6] = {53, 42, 31, 20, 9, 0};
-  const int widths[6] = {11, 11, 11, 11, 11, 9};
-  for (int pass = 0; pass < 6; ++pass) {
-    int shift = shifts[pass], bins = 1 << widths[pass];
-    for (int b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += kSelThreads) {
-      int i = base + threadIdx.x;
-      bool act = false;
-      int dgt = 0;
-      if (i < n) {
-        unsigned long long key = key_at(i);
-        act = (key & mask) == prefix;
-        dgt = (int)((key >> shift) & (unsigned long long)(bins - 1));
-      }
-      hist_add(hist, act, dgt);
-    }
-    __syncthreads();
-    pick_bin<kSelThreads>(hist, k, wave_tot, sel);
-    prefix |= (unsigned long long)sel[0] << shift;
-    mask |= (unsigned long long)(bins - 1) << shift;
-    k -= sel[1];
-    __syncthreads();
-  }
-  return prefix;
-}
-
-// Rank k among c keys that sit in LDS and all lie in [lo, hi] (bit patterns of positive doubles, so ordered like the
-// values): one histogram pass over the 2048 equal slices of the interval, then the few keys of the slice holding the
-// rank are ranked against each other.  Keys spread over an interval land a handful per slice; a slice with more than
-// kSelThreads keys (many equal keys) is handed to the generic radix select.  small: kSelThreads keys of LDS.
-__device__ __forceinline__ unsigned long long window_select_block(const unsigned long long *keys, int c, long long k,
-                                                                  unsigned long long lo, unsigned long long hi, int *hist,
-                                                                  int *wave_tot, int *sel, unsigned long long *small,
-                                                                  int *nsmall, unsigned long long *picked) {
-  const unsigned long long range = hi - lo;
-  const int nbits = range ? 64 - __clzll((long long)range) : 1;
-  const int shift = nbits > 11 ? nbits - 11 : 0;
-  for (int b = threadIdx.x; b < 2048; b += kSelThreads) hist[b] = 0;
-  if (threadIdx.x == 0) *nsmall = 0;
-  __syncthreads();
-  for (int base = 0; base < c; base += kSelThreads) {
-    const int i = base + threadIdx.x;
-    const bool act = i < c;
-    const int dgt = act ? (int)min((keys[i] - lo) >> shift, 2047ull) : 0;  // (keys lie inside the interval: the clamp never acts)
-    hist_add(hist, act, dgt);
-  }
-  __syncthreads();
-  pick_bin<kSelThreads>(hist, k, wave_tot, sel);
-  const int bin = sel[0], before = sel[1], cb = sel[2];
-  if (cb > kSelThreads) return radix_select_block([&](int i) { return keys[i]; }, c, k, hist, wave_tot, sel);
-  for (int base = 0; base < c; base += kSelThreads) {
-    const int i = base + threadIdx.x;
-    if (i < c) {
-      const unsigned long long key = keys[i];
-      if ((int)min((key - lo) >> shift, 2047ull) == bin) small[atomicAdd(nsmall, 1)] = key;
-    }
-  }
-  __syncthreads();
-  const long long kk = k - before;
-  const bool have = (int)threadIdx.x < cb;
-  const unsigned long long mine = have ? small[threadIdx.x] : ~0ull;
-  int less = 0, leq = 0;
-  for (int j = 0; j < cb; ++j) { const unsigned long long kj = small[j]; less += kj < mine; leq += kj <= mine; }
-  if (have && kk >= less && kk < leq) *picked = mine;  // equal keys store the same value
-  __syncthreads();
-  return *picked;
-}
-
-__global__ __launch_bounds__(kSelThreads) void k_select(const SelJob *jobs) {
-  __shared__ int hist[2048];
-  __shared__ int wave_tot[kSelThreads / 64];
-  __shared__ int sel[3];
-  __shared__ double red_s[kSelThreads / 64];
-  __shared__ double red_c[kSelThreads / 64];
-  SelJob job = jobs[blockIdx.x];
-  int n = job.n0 + job.n1;
-  long long k = job.k, m = job.m_fixed;
-  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
-  if (n <= 0 || k < 0 || k >= n) {
-    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m; }
-    return;
-  }
-  unsigned long long prefix = radix_select_block([&](int i) { return job_key(job, i); }, n, k, hist, wave_tot, sel);
-  double value = __longlong_as_double((long long)prefix);
-  double sum = 0.0, cnt = 0.0;
-  for (int i = threadIdx.x; i < n; i += kSelThreads) {
-    unsigned long long key = job_key(job, i);
-    if (key < prefix) { sum += __longlong_as_double((long long)key); cnt += 1.0; }
-  }
-  sum = wave_sum(sum); cnt = wave_sum(cnt);
-  if ((threadIdx.x & 63) == 0) { red_s[threadIdx.x >> 6] = sum; red_c[threadIdx.x >> 6] = cnt; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s2 = 0.0, c2 = 0.0;
-    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) { s2 += red_s[w2]; c2 += red_c[w2]; }
-    job.out[0] = value; job.out[1] = s2; job.out[2] = c2; job.out[3] = (double)m;
-  }
-}
-
-// window of a job: 2048 bins of 2^shift bit patterns, centred on the previous result of the job's
-// state slot, else on the job's first finite positive key.  Same value in every thread and in
-// every kernel of the three (the keys do not change in between).
-struct SelWindow { unsigned long long lo; int shift; };
-__device__ __forceinline__ SelWindow job_window(const SelJob &job, const double *prev) {
-  __shared__ unsigned long long centre;
-  __shared__ int first;
-  double c = job.state >= 0 ? prev[job.state] : 0.0;
-  const bool remembered = c > 0.0 && c < INFINITY;  // uniform
-  if (threadIdx.x == 0) { centre = (unsigned long long)__double_as_longlong(remembered ? c : 1.0); first = 0x7fffffff; }
-  __syncthreads();
-  if (!remembered) {  // lowest-index finite positive key among the first 4096
-    int n = min(job.n0 + job.n1, 4096);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      double v = __longlong_as_double((long long)job_key(job, i));
-      if (v > 0.0 && v < INFINITY) { atomicMin(&first, i); break; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && first != 0x7fffffff) centre = job_key(job, first);
-    __syncthreads();
-  }
-  const unsigned long long cbits = centre;
-  SelWindow w;
-  // 128 bins per binade up to 512k keys; narrower bins for longer key lists keep the bin of the
-  // median within the LDS capacity of the final block
-  long long n = (long long)job.n0 + job.n1;
-  w.shift = 45;
-  for (long long lim = 524288; n > lim && w.shift > 40; lim <<= 1) --w.shift;
-  unsigned long long half = 1024ull << w.shift;
-  w.lo = cbits > half ? cbits - half : 0ull;
-  return w;
-}
-__device__ __forceinline__ int window_bin(const SelWindow &w, unsigned long long key) {
-  if (key < w.lo) return 0;
-  unsigned long long b = (key - w.lo) >> w.shift;
-  return b > 2047ull ? 2047 : (int)b;
-}
-
-// the three kernels issue every load whose address they know (the block's first kSelPre keys per
-// thread, the remembered centre, the count partials, the histogram) before their first barrier: one
-// memory round trip instead of a chain of them
-constexpr int kSelPre = 8;
-struct KeySlice { int lo, hi; unsigned long long kv[kSelPre]; };
-__device__ __forceinline__ void load_slice(const SelJob &job, KeySlice &ks) {
-  int n = job.n0 + job.n1;
-  int per = (n + gridDim.x - 1) / gridDim.x;
-  ks.lo = blockIdx.x * per; ks.hi = min(ks.lo + per, n);
-#pragma unroll
-  for (int u = 0; u < kSelPre; ++u) {
-    int i = ks.lo + (int)threadIdx.x + u * kBlock;
-    ks.kv[u] = i < ks.hi ? job_key(job, i) : 0ull;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_selw_hist(SelPack jobs, const double *prev, int *hist) {
-  __shared__ int lh[2048];
-  SelJob job = jobs.j[blockIdx.y];
-  KeySlice ks;
-  load_slice(job, ks);
-  for (int b = threadIdx.x; b < 2048; b += kBlock) lh[b] = 0;
-  SelWindow w = job_window(job, prev);  // barriers inside: lh is clear after it
-#pragma unroll
-  for (int u = 0; u < kSelPre; ++u) {
-    bool act = ks.lo + (int)threadIdx.x + u * kBlock < ks.hi;
-    hist_add(lh, act, act ? window_bin(w, ks.kv[u]) : 0);
-  }
-  for (int base = ks.lo + kSelPre * kBlock; base < ks.hi; base += kBlock) {
-    int i = base + threadIdx.x;
-    bool act = i < ks.hi;
-    hist_add(lh, act, act ? window_bin(w, job_key(job, i)) : 0);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < 2048; b += kBlock) {
-    int v = lh[b];
-    if (v) atomicAdd(&hist[blockIdx.y * 2048 + b], v);  // integer: order-independent
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_selw_collect(SelPack jobs, const double *prev, const int *hist,
-                                                         SelState *st, unsigned long long *coll, int *cursor) {
-  __shared__ int wave_tot[kBlock / 64];
-  __shared__ int sel[3];
-  __shared__ double csh[kBlock / 64];
-  SelJob job = jobs.j[blockIdx.y];
-  KeySlice ks;
-  load_slice(job, ks);
-  int v[2048 / kBlock];
-#pragma unroll
-  for (int u = 0; u < 2048 / kBlock; ++u) v[u] = hist[blockIdx.y * 2048 + (2048 / kBlock) * threadIdx.x + u];
-  double csum = 0.0;  // counts are whole numbers: their sum is exact in any order
-  if (job.cnt) {
-    for (int b = job.cnt_a0 + (int)threadIdx.x; b < job.cnt_a1; b += kBlock) csum += job.cnt[b];
-    for (int b = job.cnt_b0 + (int)threadIdx.x; b < job.cnt_b1; b += kBlock) csum += job.cnt[b];
-  }
-  if (threadIdx.x == 0) { sel[0] = -1; sel[1] = 0; sel[2] = 0; }
-  SelWindow w = job_window(job, prev);
-  csum = wave_sum(csum);
-  if ((threadIdx.x & 63) == 0) csh[threadIdx.x >> 6] = csum;
-  __syncthreads();
-  long long m = job.m_fixed;
-  if (job.cnt) { double tot = 0.0; for (int w2 = 0; w2 < kBlock / 64; ++w2) tot += csh[w2]; m = (long long)tot; }
-  long long k = job.k;
-  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;  // rrel_util_median_abs_dev_scale's rank
-  if (k >= (long long)job.n0 + job.n1) k = -1;
-  if (k >= 0) pick_from<2048 / kBlock>(v, k, wave_tot, sel);  // k is uniform
-  const int bin = sel[0], before = sel[1], count = sel[2];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    SelState s0;
-    s0.bin = bin; s0.count = count; s0.k = k; s0.k_in_bin = k - before; s0.m = m;
-    st[blockIdx.y] = s0;
-  }
-  if (k < 0 || bin <= 0 || bin >= 2047 || count > kSelCap) return;  // nothing to gather: trivial or fallback
-  // gather the keys of that bin: the block counts its matches, reserves a range of the job's
-  // buffer with ONE global atomic and writes them there
-  int mine = 0;
-  unsigned hit = 0;
-#pragma unroll
-  for (int u = 0; u < kSelPre; ++u)
-    if (ks.lo + (int)threadIdx.x + u * kBlock < ks.hi && window_bin(w, ks.kv[u]) == bin) { hit |= 1u << u; ++mine; }
-  for (int i = ks.lo + kSelPre * kBlock + (int)threadIdx.x; i < ks.hi; i += kBlock) mine += window_bin(w, job_key(job, i)) == bin;
-  int incl = mine;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int x = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += x;
-  }
-  if (lane == 63) wave_tot[wv] = incl;  // pick_from's last barrier lies behind every thread
-  __syncthreads();
-  int pos = incl - mine, total = 0;
-  for (int w2 = 0; w2 < kBlock / 64; ++w2) { if (w2 < wv) pos += wave_tot[w2]; total += wave_tot[w2]; }
-  if (threadIdx.x == 0) sel[0] = total ? atomicAdd(&cursor[blockIdx.y], total) : 0;
-  __syncthreads();
-  unsigned long long *dst = coll + (size_t)blockIdx.y * kSelCap + sel[0] + pos;
-#pragma unroll
-  for (int u = 0; u < kSelPre; ++u)
-    if (hit & (1u << u)) *dst++ = ks.kv[u];
-  for (int i = ks.lo + kSelPre * kBlock + (int)threadIdx.x; i < ks.hi; i += kBlock) {
-    unsigned long long key = job_key(job, i);
-    if (window_bin(w, key) == bin) *dst++ = key;
-  }
-}
-
-__global__ __launch_bounds__(kSelThreads) void k_selw_final(SelPack jobs, double *prev, int *hist, const SelState *st,
-                                                           const unsigned long long *coll, int *cursor) {
-  __shared__ unsigned long long keys[kSelCap];
-  __shared__ int lh[2048];
-  __shared__ int wave_tot[kSelThreads / 64];
-  __shared__ int sel[3];
-  __shared__ unsigned long long picked;
-  SelJob job = jobs.j[blockIdx.x];
-  SelState s0 = st[blockIdx.x];
-  int *h = hist + blockIdx.x * 2048;
-  for (int b = threadIdx.x; b < 2048; b += kSelThreads) h[b] = 0;  // ready for the next selection
-  if (threadIdx.x == 0) cursor[blockIdx.x] = 0;
-  if (s0.k < 0) {
-    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m; }
-    return;
-  }
-  unsigned long long value;
-  if (s0.bin <= 0 || s0.bin >= 2047 || s0.count > kSelCap) {  // window missed or bin too full: full select
-    int n = job.n0 + job.n1;
-    value = radix_select_block([&](int i) { return job_key(job, i); }, n, s0.k, lh, wave_tot, sel);
-  } else {
-    for (int i = threadIdx.x; i < s0.count; i += kSelThreads) keys[i] = coll[(size_t)blockIdx.x * kSelCap + i];
-    __syncthreads();
-    if (s0.count <= 256) {
-      // few keys: every thread ranks its own by counting; keys[j] is a broadcast read
-      const bool have = (int)threadIdx.x < s0.count;
-      const unsigned long long mine = have ? keys[threadIdx.x] : ~0ull;
-      int less = 0, leq = 0;
-      for (int j = 0; j < s0.count; ++j) {
-        unsigned long long kj = keys[j];
-        less += kj < mine; leq += kj <= mine;
-      }
-      if (have && s0.k_in_bin >= less && s0.k_in_bin < leq) picked = mine;  // equal keys write the same value
-      __syncthreads();
-      value = picked;
-    } else {
-      value = radix_select_block([&](int i) { return keys[i]; }, s0.count, s0.k_in_bin, lh, wave_tot, sel);
-    }
-  }
-  if (threadIdx.x == 0) {
-    double v = __longlong_as_double((long long)value);
-    job.out[0] = v; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)s0.m;
-    if (job.state >= 0) prev[job.state] = v;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// fused symmetric estimate: nine kernels, no host round trip in between.  Scalars (scales,
-// normalisation statistics, MAD factors) are re-derived in each consumer kernel's prologue from
-// the producer's per-block partials, summed by every block in the same fixed order.
-// ---------------------------------------------------------------------------------------------
-struct DirArgs {
-  PairSrc ps;
-  int n;               // active matches
-  double *w, *wc, *r2, *key_s, *key_g;
-  double *q_loc;       // matched target locations: written by F1, streamed by F4 and F6 (no second and third gather)
-  unsigned *flag, gen;  // distinct-target stamps of this call
-  int float_product;
-};
-
-// scalar block layout (doubles) inside the fused output buffer
-enum { SC_CM = 0, SC_RM = 3, SC_CF = 4, SC_RF = 7, SC_ND = 8, SC_SIGF = 9, SC_SIGB = 10, SC_SIZE = 16,
-       SEL_OFF = 16, SEL_SIZE = 16, FIN_OFF = 32, FUSED_OUT = 32 + kMaxRed };
-
-// F1: residuals of both lists (un-normalised coordinates: rrl sym .txx:701-705), sums for the
-// RMS scale, centroid sums and distinct-target marks of the forward list
-__global__ __launch_bounds__(kWide) void k_f_residual(DirArgs F, DirArgs B, int nbF, int nbB, XfD xfF,
-                                                       XfD xfB, NormD ident, int want_stats, int dist_f, int dist_b, double *P1) {
-  const bool isF = (int)blockIdx.x < nbF;
-  const bool want_dist = isF ? dist_f != 0 : dist_b != 0;  // sqrt(r2) per match: only the MUSE scale reads it (first estimate)
-  const DirArgs &D = isF ? F : B;
-  const XfD &xf = isF ? xfF : xfB;
-  const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  // The grid is one resident round of blocks (grid_wide_pair), so a thread takes its sources kStreamBatch at a time and
-  // issues the loads of the whole batch level by level — the streams, then the gathers — before any arithmetic: two
-  // dependent memory round trips per batch.
-  constexpr int U = kStreamBatch;
-  const int stride = nb * kWide;
-  for (int s0 = lb * kWide + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
-    int sl[U], mt[U];
-    double p[U][3], sp[U], wp[U], q[U][10];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u * stride;
-      sl[u] = -2; mt[u] = 0; sp[u] = 0.0; wp[u] = 0.0; p[u][0] = p[u][1] = p[u][2] = 0.0;
-      if (s < D.ps.nsrc) {
-        sl[u] = D.ps.slot[s]; mt[u] = D.ps.m_to[s];
-        load_from(D.ps, s, p[u][0], p[u][1], p[u][2]);
-        sp[u] = D.ps.from_str[s]; wp[u] = D.w[s];
-      }
-    }
-    // the one gather of the matched target's record in this estimate: location and strength gain
-    // are kept per source for the weight and normal-equation passes
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (sl[u] < 0) continue;
-      const double *r = D.ps.to_rec + (size_t)mt[u] * kRecStride;
-#pragma unroll
-      for (int k = 0; k < 10; ++k) q[u][k] = r[k];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u * stride;
-      if (sl[u] == -2) continue;
-      if (sl[u] < 0) { if (want_dist) D.key_s[s] = INFINITY; continue; }
-      const double q0 = q[u][0], q1 = q[u][1], q2 = q[u][2];
-      double y0, y1, y2;
-      map_loc(xf, (p[u][0] - ident.cm[0]) / ident.rm, (p[u][1] - ident.cm[1]) / ident.rm, (p[u][2] - ident.cm[2]) / ident.rm, y0, y1, y2);
-      double r2 = proj_residual2(y0, y1, y2, (q0 - ident.cf[0]) / ident.rf, (q1 - ident.cf[1]) / ident.rf, (q2 - ident.cf[2]) / ident.rf,
-                                 q[u][3], q[u][4], q[u][5], q[u][6], q[u][7], q[u][8]);
-      D.q_loc[3 * (size_t)s] = q0; D.q_loc[3 * (size_t)s + 1] = q1; D.q_loc[3 * (size_t)s + 2] = q2;
-      {
-        const double sq = q[u][9];
-        const double g = D.float_product ? (double)((float)sp[u] * (float)sq) : sp[u] * sq;
-        D.key_g[s] = g > 90000.0 ? 90000.0 : g;  // strength_gain(); F4 turns it into the selection key
-      }
-      acc[0] += wp[u] * r2;
-      acc[1] += wp[u];
-      D.r2[s] = r2;
-      if (want_dist) D.key_s[s] = sqrt(r2);
-      if (isF && want_stats) {
-        acc[2] += p[u][0]; acc[3] += p[u][1]; acc[4] += p[u][2];
-        D.flag[mt[u]] = D.gen;
-      }
-    }
-  }
-  block_reduce_store<5, kWide / 64>(acc, P1);
-}
-
-// F3: mean radii about the centroids (cdcl .txx:1195-1213)
-__global__ __launch_bounds__(kWide) void k_f_radii(DirArgs F, int nbF, const double *P1, const double *P2,
-                                                    int nbT, const GridPoint *to_pt, int nt, double *P3,
-                                                    double *SC) {
-  // the first source and the first target of this thread travel while the prologue reduces the partial rows (for lists
-  // up to gridDim.x * kWide entries that is all of them)
-  const int first = blockIdx.x * kWide + threadIdx.x, step = gridDim.x * kWide;
-  int sl0 = -1;
-  unsigned fl0 = F.gen - 1u;
-  double p0 = 0.0, p1 = 0.0, p2 = 0.0, t0 = 0.0, t1 = 0.0, t2 = 0.0;
-  if (first < F.ps.nsrc) { sl0 = F.ps.slot[first]; load_from(F.ps, first, p0, p1, p2); }
-  if (first < nt) { fl0 = F.flag[first]; const GridPoint q = to_pt[first]; t0 = q.x; t1 = q.y; t2 = q.z; }
-  double cm[3], cf[3];
-  double tot[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // from-sums (3), distinct-to sums (3) and their count
-  if ((int)threadIdx.x < nbF)  // at most kWideBlocks rows each: one per thread
-    for (int k = 0; k < 3; ++k) tot[k] = P1[(size_t)threadIdx.x * 5 + 2 + k];
-  if ((int)threadIdx.x < nbT)
-    for (int k = 0; k < 4; ++k) tot[3 + k] = P2[(size_t)threadIdx.x * 4 + k];
-  block_sum_all<7, kWide / 64>(tot);
-  const double nd = tot[6];
-  for (int k = 0; k < 3; ++k) { cm[k] = tot[k] / (double)F.n; cf[k] = tot[3 + k] / nd; }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    for (int k = 0; k < 3; ++k) { SC[SC_CM + k] = cm[k]; SC[SC_CF + k] = cf[k]; }
-    SC[SC_ND] = nd;
-  }
-  double acc[2] = {0.0, 0.0};
-  if (sl0 >= 0) {
-    p0 -= cm[0]; p1 -= cm[1]; p2 -= cm[2];
-    acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
-  }
-  if (fl0 == F.gen) {
-    t0 -= cf[0]; t1 -= cf[1]; t2 -= cf[2];
-    acc[1] += sqrt((t0 * t0 + t1 * t1) + t2 * t2);
-  }
-  for (int s = first + step; s < F.ps.nsrc; s += step) {
-    if (F.ps.slot[s] < 0) continue;
-    load_from(F.ps, s, p0, p1, p2);
-    p0 -= cm[0]; p1 -= cm[1]; p2 -= cm[2];
-    acc[0] += sqrt((p0 * p0 + p1 * p1) + p2 * p2);
-  }
-  for (int j = first + step; j < nt; j += step) {
-    if (F.flag[j] == F.gen) {
-      const GridPoint q = to_pt[j];
-      double q0 = q.x - cf[0], q1 = q.y - cf[1], q2 = q.z - cf[2];
-      acc[1] += sqrt((q0 * q0 + q1 * q1) + q2 * q2);
-    }
-  }
-  block_reduce_store<2, kWide / 64>(acc, P3);
-}
-
-struct WeightOpts {
-  int rrl, normalize, strength_f, strength_b;
-  int mode_f, mode_b;       // LRR_ICP_SCALE_*; MUSE arrives here as an injected value
-  double inj_f, inj_b;
-};
-
-__device__ __forceinline__ NormD norm_from_scalars(const double *SC, bool flipped) {
-  NormD nm;
-  if (!flipped) {
-    for (int k = 0; k < 3; ++k) { nm.cm[k] = SC[SC_CM + k]; nm.cf[k] = SC[SC_CF + k]; }
-    nm.rm = SC[SC_RM]; nm.rf = SC[SC_RF];
-  } else {  // backward list: flipped centres and radii (rrl sym .txx:719-720)
-    for (int k = 0; k < 3; ++k) { nm.cm[k] = SC[SC_CF + k]; nm.cf[k] = SC[SC_CM + k]; }
-    nm.rm = SC[SC_RF]; nm.rf = SC[SC_RM];
-  }
-  return nm;
-}
-
-// F4: Beaton-Tukey weights, strength gain and spatial keys.  The multiplications by 1/MADscale
-// are deferred to F6, in the reference's order: w = BT/s^2 ; w *= g ; w *= 1/gs ; w *= sw ; w *= 1/ss.
-// FOLD: the first half of the order statistics rides along.  Each of the two selections of this list (strength keys,
-// spatial keys) has a narrow window around its previous result (prev * (1 -+ win)): the pass counts the keys below the
-// window (P5) and gathers the keys inside it (staged in LDS, one global reservation per block); k_selw_fold_final then
-// picks the exact rank among the gathered keys.  Used when the scales moved little over the last iterations (the host
-// decides); a window that misses the rank or overflows falls back to the full select inside the final kernel.
-struct FoldArgs { const double *prev, *win; unsigned long long *coll; int *cursor; double *P5; };
-// the streams of one batch of k_f_weights (slot -2: beyond the list)
-__device__ __forceinline__ void weights_load_batch(const DirArgs &D, bool clone, int s0, int stride, int (&sl)[kStreamBatch],
-                                                   double (&r2v)[kStreamBatch], double (&gv)[kStreamBatch], double (&ql)[kStreamBatch][3]) {
-#pragma unroll
-  for (int u = 0; u < kStreamBatch; ++u) {
-    const int s = s0 + u * stride;
-    sl[u] = -2; r2v[u] = 0.0; gv[u] = 0.0; ql[u][0] = ql[u][1] = ql[u][2] = 0.0;
-    if (s < D.ps.nsrc) {
-      sl[u] = D.ps.slot[s]; r2v[u] = D.r2[s]; gv[u] = D.key_g[s];
-      double a, b, c;
-      if (clone) load_from(D.ps, s, a, b, c);
-      else { const double *q = D.q_loc + 3 * (size_t)s; a = q[0]; b = q[1]; c = q[2]; }
-      ql[u][0] = a; ql[u][1] = b; ql[u][2] = c;
-    }
-  }
-}
-
-template <bool FOLD>
-__global__ __launch_bounds__(kWide) void k_f_weights(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
-                                                      const double *P1, const double *P3, int nb3,
-                                                      double *SC, double *P4, FoldArgs fo) {
-  __shared__ unsigned long long stage[FOLD ? 2 : 1][FOLD ? kFoldStage : 1];
-  __shared__ int nstage[2], gpos[2];
-  const bool isF = (int)blockIdx.x < nbF;
-  const DirArgs &D = isF ? F : B;
-  const int nb = isF ? nbF : nbB, lb = xcd_block(isF ? blockIdx.x : blockIdx.x - nbF, nb);
-  const int r0 = isF ? 0 : nbF, r1 = isF ? nbF : nbF + nbB;
-  const int mode = isF ? o.mode_f : o.mode_b;
-  const bool clone = !o.rrl && !isF;                 // cdcl: backward matches enter as role-reversed clones
-  // Every load that does not depend on the block sums below is issued first — the scalars earlier kernels left, the
-  // selection windows, and the first batch of this thread's sources — so that they travel while the prologue reduces
-  // the producers' partial rows: one memory round trip less on the kernel's critical path.
-  constexpr int U = kStreamBatch;
-  const int stride = nb * kWide;
-  int sl[U];
-  double r2v[U], gv[U], ql[U][3];
-  const int s_first = lb * kWide + threadIdx.x;
-  if (s_first < D.ps.nsrc) weights_load_batch(D, clone, s_first, stride, sl, r2v, gv, ql);
-  double sc_in[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0};  // cm, cf, nd as k_f_radii left them
-  if (o.normalize) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { sc_in[k] = SC[SC_CM + k]; sc_in[3 + k] = SC[SC_CF + k]; }
-    sc_in[6] = SC[SC_ND];
-  }
-  // folded selection: jobs and windows of this list (slots as in lrr_icp_estimate_symmetric: rrl {F.g, B.g, F.s, B.s}; cdcl {g, s})
-  const int jg = o.rrl ? (isF ? 0 : 1) : 0, js = o.rrl ? (isF ? 2 : 3) : 1;
-  double lo_g = INFINITY, hi_g = INFINITY, lo_s = INFINITY, hi_s = INFINITY, below[2] = {0.0, 0.0};
-  if (FOLD) {
-    const int base = o.rrl ? 0 : 4;
-    const double vg = fo.prev[base + jg], vs = fo.prev[base + js], dg = fo.win[base + jg], ds = fo.win[base + js];
-    if (vg > 0.0 && vg < INFINITY) { lo_g = vg * (1.0 - dg); hi_g = vg * (1.0 + dg); }
-    if (vs > 0.0 && vs < INFINITY) { lo_s = vs * (1.0 - ds); hi_s = vs * (1.0 + ds); }
-    if (threadIdx.x < 2) nstage[threadIdx.x] = 0;
-  }
-  double tot[4] = {0.0, 0.0, 0.0, 0.0};  // S, W of this list's residuals; radius sums of both clouds
-  // (at most kWideBlocks rows: one per thread, no loop to unroll)
-  if (mode == LRR_ICP_SCALE_RMS && r0 + (int)threadIdx.x < r1) { const int b = r0 + threadIdx.x; tot[0] = P1[(size_t)b * 5]; tot[1] = P1[(size_t)b * 5 + 1]; }
-  if (o.normalize && (int)threadIdx.x < nb3) { const int b = threadIdx.x; tot[2] = P3[(size_t)b * 2]; tot[3] = P3[(size_t)b * 2 + 1]; }
-  block_sum_all<4, kWide / 64>(tot);  // (its barriers also publish nstage)
-  const double scale = mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : (isF ? o.inj_f : o.inj_b);
-  const double rm = o.normalize ? tot[2] / (double)F.n : 1.0, rf = o.normalize ? tot[3] / sc_in[6] : 1.0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (o.normalize) { SC[SC_RM] = rm; SC[SC_RF] = rf; }
-    else for (int k = 0; k < 8; ++k) SC[k] = (k == 3 || k == 7) ? 1.0 : 0.0;
-  }
-  if (lb == 0 && threadIdx.x == 0) SC[isF ? SC_SIGF : SC_SIGB] = scale;
-  NormD nm;  // backward list: flipped centres and radii (rrl sym .txx:719-720)
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { nm.cm[k] = isF ? sc_in[k] : sc_in[3 + k]; nm.cf[k] = isF ? sc_in[3 + k] : sc_in[k]; }
-  nm.rm = isF ? rm : rf; nm.rf = isF ? rf : rm;
-  const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
-  double *wdst = clone ? D.wc : D.w;
-  const double scale2 = scale * scale;
-  double acc[1] = {0.0};
-  for (int s0 = s_first; s0 < D.ps.nsrc;) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u * stride;
-      if (sl[u] == -2) continue;
-      if (sl[u] < 0) { D.key_g[s] = INFINITY; D.key_s[s] = INFINITY; continue; }
-      double uu = r2v[u] / scale2, bt = 0.0;
-      if (uu <= 16.0) { double temp = 1 - uu * 0.0625; bt = temp * temp; }
-      double wi = bt / scale2;
-      if (clone) D.w[s] = wi;  // the backward list itself keeps its Beaton-Tukey weights (cdcl sym .txx:665)
-      double key = INFINITY;
-      if (strength && wi != 0) {
-        double g = gv[u];  // strength_gain() of the pair, left here by F1
-        wi = wi * g;
-        key = g;
-        acc[0] += 1.0;
-      }
-      D.key_g[s] = key;
-      if (FOLD) {
-        if (key < lo_g) below[0] += 1.0;
-        else if (key <= hi_g) { const int p = atomicAdd(&nstage[0], 1); if (p < kFoldStage) stage[0][p] = (unsigned long long)__double_as_longlong(key); }
-      }
-      {  // weight_spatially's 1 / (1 + 5 |q~|^2) on the normalised to-location (clones: their from-location)
-        double q0, q1, q2;
-        if (clone) { q0 = (ql[u][0] - nm.cm[0]) / nm.rm; q1 = (ql[u][1] - nm.cm[1]) / nm.rm; q2 = (ql[u][2] - nm.cm[2]) / nm.rm; }
-        else { q0 = (ql[u][0] - nm.cf[0]) / nm.rf; q1 = (ql[u][1] - nm.cf[1]) / nm.rf; q2 = (ql[u][2] - nm.cf[2]) / nm.rf; }
-        double dq = sqrt((q0 * q0 + q1 * q1) + q2 * q2);
-        const double ks = 1.0 / (1.0 + 5.0 * dq * dq);
-        D.key_s[s] = ks;
-        if (FOLD) {
-          if (ks < lo_s) below[1] += 1.0;
-          else if (ks <= hi_s) { const int p = atomicAdd(&nstage[1], 1); if (p < kFoldStage) stage[1][p] = (unsigned long long)__double_as_longlong(ks); }
-        }
-      }
-      wdst[s] = wi;
-    }
-    s0 += U * stride;
-    if (s0 < D.ps.nsrc) weights_load_batch(D, clone, s0, stride, sl, r2v, gv, ql);
-  }
-  if (!FOLD) { block_reduce_store<1, kWide / 64>(acc, P4); return; }
-  {
-    // the global reservations of the two gathered sets travel while the block reduces its three counts (one reduction
-    // for the number of strength keys, P4, and the keys below the two windows, P5)
-    __syncthreads();  // every key of the block is staged
-    if (threadIdx.x < 2) {
-      const int j = threadIdx.x == 0 ? jg : js, n = nstage[threadIdx.x];
-      // a block that staged more than it holds makes the gathered set useless: push the cursor beyond the capacity
-      gpos[threadIdx.x] = atomicAdd(&fo.cursor[j], n > kFoldStage ? kSelCap + 1 : n);
-    }
-    __shared__ double red3[kWide / 64][3];
-    const double v3[3] = {acc[0], below[0], below[1]};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double w2 = wave_sum(v3[k]);
-      if ((threadIdx.x & 63) == 0) red3[threadIdx.x >> 6][k] = w2;
-    }
-    __syncthreads();  // (also publishes gpos)
-    if (threadIdx.x < 3) {
-      double t3 = red3[0][threadIdx.x];
-#pragma unroll
-      for (int w2 = 1; w2 < kWide / 64; ++w2) t3 += red3[w2][threadIdx.x];
-      if (threadIdx.x == 0) P4[blockIdx.x] = t3;
-      else fo.P5[(size_t)blockIdx.x * 2 + (threadIdx.x - 1)] = t3;
-    }
-    for (int t = 0; t < 2; ++t) {
-      const int j = t == 0 ? jg : js, n = min(nstage[t], kFoldStage), p0 = gpos[t];
-      if (nstage[t] <= kFoldStage && p0 + n <= kSelCap)
-        for (int k = threadIdx.x; k < n; k += kWide) fo.coll[(size_t)j * kSelCap + p0 + k] = stage[t][k];
-    }
-  }
-}
-
-// second half of the folded selection: one block per job.  m (the number of keys that take part) and the rank as in
-// k_selw_collect; `below` = keys under the window (P5); when the rank lies among the gathered keys it is selected there,
-// else (window missed, overflowed, no previous result) by the full radix select over all keys of the job.  The window
-// width tunes itself: halved when it gathers more than a quarter of the capacity, doubled when it gathers next to
-// nothing, widened after a miss, cut to an eighth after an overflow (a couple of slow selections when a level with
-// millions of keys starts).
-__global__ __launch_bounds__(kSelThreads) void k_selw_fold_final(SelPack jobs, double *prev, double *win, const double *P5,
-                                                                const unsigned long long *coll, int *cursor) {
-  __shared__ unsigned long long keys[kSelCap];
-  __shared__ int lh[2048];
-  __shared__ int wave_tot[kSelThreads / 64];
-  __shared__ int sel[3];
-  __shared__ unsigned long long picked;
-  __shared__ unsigned long long small[kSelThreads];
-  __shared__ int nsmall;
-  __shared__ double red[kSelThreads / 64][2];
-  SelJob job = jobs.j[blockIdx.x];
-  double part[2] = {0.0, 0.0};  // m (counted jobs), keys below the window: whole numbers, exact in any order
-  if (job.cnt) {
-    for (int b = job.cnt_a0 + (int)threadIdx.x; b < job.cnt_a1; b += kSelThreads) part[0] += job.cnt[b];
-    for (int b = job.cnt_b0 + (int)threadIdx.x; b < job.cnt_b1; b += kSelThreads) part[0] += job.cnt[b];
-  }
-  for (int b = job.row_a0 + (int)threadIdx.x; b < job.row_a1; b += kSelThreads) part[1] += P5[(size_t)b * 2 + job.col];
-  for (int b = job.row_b0 + (int)threadIdx.x; b < job.row_b1; b += kSelThreads) part[1] += P5[(size_t)b * 2 + job.col];
-  for (int k = 0; k < 2; ++k) {
-    double v = wave_sum(part[k]);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
-  }
-  __syncthreads();
-  double tot[2] = {0.0, 0.0};
-  for (int w2 = 0; w2 < kSelThreads / 64; ++w2) { tot[0] += red[w2][0]; tot[1] += red[w2][1]; }
-  const long long m = job.cnt ? (long long)tot[0] : job.m_fixed, below = (long long)tot[1];
-  const int n = job.n0 + job.n1, c = cursor[blockIdx.x];
-  long long k = job.k;
-  if (k < 0) k = m > 1 ? (m - 1) / 2 + 1 : -1;
-  if (k >= n) k = -1;
-  const double pv = prev[job.state], pw = win[job.state];
-  __syncthreads();
-  if (threadIdx.x == 0) cursor[blockIdx.x] = 0;  // ready for the next selection
-  if (k < 0) {
-    if (threadIdx.x == 0) { job.out[0] = 0.0; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m; }
-    return;
-  }
-  const bool hit = pv > 0.0 && pv < INFINITY && c <= kSelCap && below <= k && k < below + c;
-  unsigned long long value;
-  if (hit) {
-    for (int i = threadIdx.x; i < c; i += kSelThreads) keys[i] = coll[(size_t)blockIdx.x * kSelCap + i];
-    __syncthreads();
-    // the window the weight pass gathered with: prev * (1 -+ win), as it computed it
-    const double wlo = pv * (1.0 - pw), whi = pv * (1.0 + pw);
-    value = window_select_block(keys, c, k - below, (unsigned long long)__double_as_longlong(wlo), (unsigned long long)__double_as_longlong(whi),
-                                lh, wave_tot, sel, small, &nsmall, &picked);
-  } else {
-    value = radix_select_block([&](int i) { return job_key(job, i); }, n, k, lh, wave_tot, sel);
-  }
-  if (threadIdx.x == 0) {
-    const double v = __longlong_as_double((long long)value);
-    job.out[0] = v; job.out[1] = 0.0; job.out[2] = 0.0; job.out[3] = (double)m;
-    prev[job.state] = v;
-    double w2 = pw;
-    if (c > kSelCap) w2 = pw * 0.125;               // gathered far too much (long key lists): much narrower
-    else if (!hit) w2 = fmin(pw * 4.0, 0.125);      // the rank fell outside: wider
-    else if (c > kSelCap / 4) w2 = pw * 0.5;
-    else if (c < 64) w2 = fmin(pw * 2.0, 0.125);
-    win[job.state] = w2;
-  }
-}
-
-__device__ __forceinline__ double mad_factor(const double *sel) {  // 1 / rrel_util_median_abs_dev_scale
-  double m = sel[3];
-  double gs = m > 1.0 ? 1.4826 * (1 + 5.0 / (m - 1.0)) * sel[0] : 0.0;
-  return 1.0 / gs;
-}
-
-// F6: final weights and the normal equations of both lists (backward list role-reversed).
-// The upper triangle lives in registers (90 doubles for dof 12), so few wavefronts fit a CU and
-// nothing hides a dependent load chain: each thread therefore takes its matches kAccBatch at a time
-// and issues the loads of the whole batch level by level (weights and match indices, then the
-// feature records) before any arithmetic — three memory round trips per batch instead of three
-// per match.
-constexpr int kAccBatch = 7;
-template <int DOF, bool PREMUL>
-__global__ __launch_bounds__(kBlock) void k_f_accumulate(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
-                                                         const double *SC, const double *SEL, double c0,
-                                                         double c1, double c2, int rigid_increment,
-                                                         double *P6) {
-  constexpr int NT = Tri<DOF>::N;
-  constexpr int U = kAccBatch;
-  const bool isF = (int)blockIdx.x < nbF;
-  const DirArgs &D = isF ? F : B;
-  const int nb = isF ? nbF : nbB, lb0 = isF ? blockIdx.x : blockIdx.x - nbF;
-  const int lb = (nb & 7) == 0 ? xcd_block(lb0, nb) : lb0;
-  NormD nm = norm_from_scalars(SC, !isF);
-  const bool clone = !o.rrl && !isF;
-  const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
-  // selection slots: rrl {F.g, B.g, F.s, B.s}; cdcl {merged g, merged s}
-  const double fg = strength ? mad_factor(SEL + 4 * (o.rrl ? (isF ? 0 : 1) : 0)) : 1.0;
-  const double fs = mad_factor(SEL + 4 * (o.rrl ? (isF ? 2 : 3) : 1));
-  double *wbuf = clone ? D.wc : D.w;
-  const double *prec = isF ? D.ps.to_rec : D.ps.from_rec;  // whose error projector the term uses
-  double acc[NT + DOF];
-#pragma unroll
-  for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
-  const int stride = nb * kBlock;
-  for (int s0 = lb * kBlock + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
-    int mt[U];
-    double wi[U];
-    bool on[U];
-    {
-      int sl[U];
-      double wv[U], ks[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int s = s0 + u * stride;
-        const bool in = s < D.ps.nsrc;
-        sl[u] = in ? D.ps.slot[s] : -1;
-        wv[u] = in ? wbuf[s] : 0.0;
-        ks[u] = in ? D.key_s[s] : 0.0;
-        mt[u] = in ? D.ps.m_to[s] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        on[u] = sl[u] >= 0;
-        double v = wv[u];
-        if (strength) v = v * fg;
-        v = v * ks[u];
-        v = v * fs;
-        wi[u] = v;
-        if (on[u]) wbuf[s0 + u * stride] = v;
-        if (PREMUL && v < 1e-4) on[u] = false;
-      }
-    }
-    double pl[U][3], ql[U][3], Pq[U][6];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
-      const int s = s0 + u * stride;
-      load_from(D.ps, s, pl[u][0], pl[u][1], pl[u][2]);
-      const double *qr = D.q_loc + 3 * (size_t)s;  // cached by F1: the backward list needs no gather at all
-      ql[u][0] = qr[0]; ql[u][1] = qr[1]; ql[u][2] = qr[2];
-      const double *pr = prec + (size_t)(isF ? mt[u] : s) * kRecStride;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
-      // normalised coordinates, oriented (backward list: role-reversed term)
-      double p0 = (pl[u][0] - nm.cm[0]) / nm.rm, p1 = (pl[u][1] - nm.cm[1]) / nm.rm, p2 = (pl[u][2] - nm.cm[2]) / nm.rm;
-      double q0 = (ql[u][0] - nm.cf[0]) / nm.rf, q1 = (ql[u][1] - nm.cf[1]) / nm.rf, q2 = (ql[u][2] - nm.cf[2]) / nm.rf;
-      double P[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) P[k] = Pq[u][k];
-      if (isF) accumulate_pair<DOF, PREMUL>(acc, wi[u], p0, p1, p2, q0, q1, q2, P, c0, c1, c2, rigid_increment);
-      else accumulate_pair<DOF, PREMUL>(acc, wi[u], q0, q1, q2, p0, p1, p2, P, c0, c1, c2, rigid_increment);
-    }
-  }
-  block_reduce_store<NT + DOF>(acc, P6);
-}
-
-// The 12-dof (affine) normal equations as a Kronecker product.  The affine Jacobian has one non-zero per column
-// (J[d][3d+k] = l_k, J[d][9+d] = 1), so with x = (l0, l1, l2, 1)
-//     (J^T P J)[(d,k),(e,m)] = x_k x_m P_de        and        (J^T P b)[(d,k)] = x_k (P b)_d :
-// 10 unique products x_k x_m times 6 unique projector entries = 60 sums carry the whole 78-entry triangle (entries
-// (d,k),(e,m) and (e,k),(d,m) are the same number), a third fewer accumulators and operations than the generic form —
-// what lets two waves share a SIMD.  Sum s = 6 i + j: i over {00,01,02,11,12,22,03,13,23,33} of x x^T, j over
-// {xx,xy,xz,yy,yz,zz} of P; sums 60..71: the right-hand side in parameter order.  kron_expand rebuilds the matrix.
-// Rounding: x_k x_m is formed first, where the generic form multiplies (x_k P_de) x_m — same products, last-bit
-// differences; the weight enters through P w in both forms of the reference (PREMUL: (J^T (P w)) J; else (J^T P) J w).
-template <bool PREMUL>
-__device__ __forceinline__ void accumulate_pair_kron(double *acc, double wi, double jx, double jy, double jz, double b0,
-                                                     double b1, double b2, const double *P, double c0, double c1,
-                                                     double c2, int rigid_increment) {
-  if (rigid_increment) { b0 = b0 - jx; b1 = b1 - jy; b2 = b2 - jz; }
-  double Pw[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) Pw[k] = P[k] * wi;
-  const double l0 = jx - c0, l1 = jy - c1, l2 = jz - c2;
-  const double X[9] = {l0 * l0, l0 * l1, l0 * l2, l1 * l1, l1 * l2, l2 * l2, l0, l1, l2};
-#pragma unroll
-  for (int i = 0; i < 9; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) acc[6 * i + j] += X[i] * Pw[j];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) acc[54 + j] += Pw[j];
-  const double Pb[3] = {(Pw[0] * b0 + Pw[1] * b1) + Pw[2] * b2, (Pw[1] * b0 + Pw[3] * b1) + Pw[4] * b2, (Pw[2] * b0 + Pw[4] * b1) + Pw[5] * b2};
-  const double lt[3] = {l0, l1, l2};
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) acc[60 + 3 * d + k] += lt[k] * Pb[d];
-    acc[69 + d] += Pb[d];
-  }
-}
-
-// F6 for 12 degrees of freedom: as k_f_accumulate, Kronecker sums, two blocks per compute unit
-constexpr int kKronBatch = 2;
-template <bool PREMUL>
-__global__ __launch_bounds__(kBlock, 2) void k_f_accumulate_kron(DirArgs F, DirArgs B, int nbF, int nbB, WeightOpts o,
-                                                                 const double *SC, const double *SEL, double c0, double c1,
-                                                                 double c2, int rigid_increment, double *P6) {
-  constexpr int U = kKronBatch;
-  const bool isF = (int)blockIdx.x < nbF;
-  const DirArgs &D = isF ? F : B;
-  const int nb = isF ? nbF : nbB, lb0 = isF ? blockIdx.x : blockIdx.x - nbF;
-  const int lb = (nb & 7) == 0 ? xcd_block(lb0, nb) : lb0;
-  NormD nm = norm_from_scalars(SC, !isF);
-  const bool clone = !o.rrl && !isF;
-  const bool strength = o.rrl ? (isF ? o.strength_f : o.strength_b) : o.strength_f;
-  const double fg = strength ? mad_factor(SEL + 4 * (o.rrl ? (isF ? 0 : 1) : 0)) : 1.0;
-  const double fs = mad_factor(SEL + 4 * (o.rrl ? (isF ? 2 : 3) : 1));
-  double *wbuf = clone ? D.wc : D.w;
-  const double *prec = isF ? D.ps.to_rec : D.ps.from_rec;  // whose error projector the term uses
-  double acc[kKron];
-#pragma unroll
-  for (int k = 0; k < kKron; ++k) acc[k] = 0.0;
-  const int stride = nb * kBlock;
-  for (int s0 = lb * kBlock + threadIdx.x; s0 < D.ps.nsrc; s0 += U * stride) {
-    // two memory round trips per batch: the streams (list position, weight, spatial key, match), then the locations
-    // and the projector — fetched for every listed source, before its final weight says whether the pair counts
-    int sl[U], mt[U];
-    double wv[U], ks[U], wi[U];
-    bool on[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u * stride;
-      const bool in = s < D.ps.nsrc;
-      sl[u] = in ? D.ps.slot[s] : -1;
-      wv[u] = in ? wbuf[s] : 0.0;
-      ks[u] = in ? D.key_s[s] : 0.0;
-      mt[u] = in ? D.ps.m_to[s] : 0;
-    }
-    double pl[U][3], ql[U][3], Pq[U][6];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (sl[u] < 0) continue;
-      const int s = s0 + u * stride;
-      load_from(D.ps, s, pl[u][0], pl[u][1], pl[u][2]);
-      const double *qr = D.q_loc + 3 * (size_t)s;  // cached by F1: the backward list needs no gather at all
-      ql[u][0] = qr[0]; ql[u][1] = qr[1]; ql[u][2] = qr[2];
-      const double *pr = prec + (size_t)(isF ? mt[u] : s) * kRecStride;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      on[u] = sl[u] >= 0;
-      double v = wv[u];
-      if (strength) v = v * fg;
-      v = v * ks[u];
-      v = v * fs;
-      wi[u] = v;
-      if (on[u]) wbuf[s0 + u * stride] = v;
-      if (PREMUL && v < 1e-4) on[u] = false;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
-      // normalised coordinates, oriented (backward list: role-reversed term)
-      double p0 = (pl[u][0] - nm.cm[0]) / nm.rm, p1 = (pl[u][1] - nm.cm[1]) / nm.rm, p2 = (pl[u][2] - nm.cm[2]) / nm.rm;
-      double q0 = (ql[u][0] - nm.cf[0]) / nm.rf, q1 = (ql[u][1] - nm.cf[1]) / nm.rf, q2 = (ql[u][2] - nm.cf[2]) / nm.rf;
-      const double j0 = isF ? p0 : q0, j1 = isF ? p1 : q1, j2 = isF ? p2 : q2;
-      const double b0 = isF ? q0 : p0, b1 = isF ? q1 : p1, b2 = isF ? q2 : p2;
-      accumulate_pair_kron<PREMUL>(acc, wi[u], j0, j1, j2, b0, b1, b2, Pq[u], c0, c1, c2, rigid_increment);
-    }
-  }
-  block_reduce_store<kKron>(acc, P6, (int)gridDim.x);
-}
-
-// ---------------------------------------------------------------------------------------------
-// post-convergence diagnostics of the verifier, on the matches where they live
-// ---------------------------------------------------------------------------------------------
-// sheet_angles / tube_angles (rrl .txx:281-375; cdcl .txx:273-382): weighted mean angle between
-// the mapped direction of p and the direction of q over the sheet-sheet (tube-tube) matches;
-// partial sums of w*a and w
-// unmapped (the cdcl classes, cdcl .txx:273-382): the two directions are covariance eigenvectors compared as they are,
-// except that a rigid pre-map has rotated the from-feature's covariance: its eigenvector is R d (R = xf.A)
-__global__ __launch_bounds__(kBlock) void k_angles(PairSrc ps, const ShapeRec *fshape, const ShapeRec *tshape, XfD xf,
-                                                   const double *w, int tube, double *partials, int unmapped) {
-  const double pi = 3.14159265358979323846;
-  const int want = tube ? 1 : 2, need = tube ? 2 : 1;
-  double acc[2] = {0.0, 0.0};
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
-    if (ps.slot[s] < 0) continue;
-    const ShapeRec P = fshape[s], Q = tshape[ps.m_to[s]];
-    if (P.shape != want || Q.shape != want || P.ndirs < need || Q.ndirs < need) continue;
-    const double *dp = tube ? P.td : P.sd, *dq = tube ? Q.td : Q.sd;
-    double d0, d1, d2;
-    if (unmapped) {
-      d0 = (xf.A[0] * dp[0] + xf.A[1] * dp[1]) + xf.A[2] * dp[2];
-      d1 = (xf.A[3] * dp[0] + xf.A[4] * dp[1]) + xf.A[5] * dp[2];
-      d2 = (xf.A[6] * dp[0] + xf.A[7] * dp[1]) + xf.A[8] * dp[2];
-    } else {
-      double p0, p1, p2, y0, y1, y2, z0, z1, z2;
-      load_from(ps, s, p0, p1, p2);
-      map_loc(xf, p0, p1, p2, y0, y1, y2);
-      map_loc(xf, p0 + dp[0], p1 + dp[1], p2 + dp[2], z0, z1, z2);
-      d0 = z0 - y0; d1 = z1 - y1; d2 = z2 - y2;
-      const double nrm = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
-      d0 /= nrm; d1 /= nrm; d2 /= nrm;
-    }
-    double a = acos((d0 * dq[0] + d1 * dq[1]) + d2 * dq[2]);
-    if (a > pi / 2) a = pi - a;
-    const double wi = w[s];
-    acc[0] += wi * a;
-    acc[1] += wi;
-  }
-  block_reduce_store<2>(acc, partials);
-}
-
-// compute_transfer_error_covariance (cdcl .txx:388-404): sum over the matches of J(p) C J(p)^T, J the
-// Jacobian of the transform with respect to its parameters at the from-location (dense products in
-// the order of the fixed-size matrix classes)
-struct CovarArg { double c[144]; };
-template <int DOF>
-__global__ __launch_bounds__(kBlock) void k_transfer_cov(PairSrc ps, CovarArg C, double c0, double c1, double c2,
-                                                         double *partials) {
-  double acc[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-  for (int s = blockIdx.x * kBlock + threadIdx.x; s < ps.nsrc; s += gridDim.x * kBlock) {
-    if (ps.slot[s] < 0) continue;
-    double p0, p1, p2;
-    load_from(ps, s, p0, p1, p2);
-    const double l0 = p0 - c0, l1 = p1 - c1, l2 = p2 - c2;
-    double J[3][DOF];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int k = 0; k < DOF; ++k) J[r][k] = 0.0;
-    if (DOF == 12) {  // cdcl_trans_affine.txx:141-161
-      const double l[3] = {l0, l1, l2};
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) J[r][3 * r + k] = l[k];
-        J[r][9 + r] = 1.0;
-      }
-    } else {  // cdcl_trans_rigid3d.cxx:197-225: [-[l]x , I]
-      J[0][1] = l2; J[0][2] = -l1; J[1][0] = -l2; J[1][2] = l0; J[2][0] = l1; J[2][1] = -l0;
-      J[0][3] = 1.0; J[1][4] = 1.0; J[2][5] = 1.0;
-    }
-    double M[3][DOF];  // J C
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int j = 0; j < DOF; ++j) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < DOF; ++k) v += J[r][k] * C.c[k * DOF + j];
-        M[r][j] = v;
-      }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        double v = 0.0;
-#pragma unroll
-        for (int j = 0; j < DOF; ++j) v += M[r][j] * J[e][j];
-        acc[3 * r + e] += v;
-      }
-  }
-  block_reduce_store<9>(acc, partials);
-}
-
-// ---------------------------------------------------------------------------------------------
-// fused FORWARD estimate (cdcl / rrl estimate_LS of one list: cdcl .txx:1009-1093, rrl .txx:783-859):
-// normalisation statistics of the matches, residuals in normalised coordinates under the normalised
-// transform, scale, Beaton-Tukey weights, strength gain with its MAD scale, normal equations — one
-// host round trip.  The transform is normalised on the device from the statistics (the host does
-// the same for its own bookkeeping once they arrive).
-// ---------------------------------------------------------------------------------------------
-// FW0: sums of the from-locations, stamps of the distinct matched targets (cdcl .txx:1159-1190)
-__global__ __launch_bounds__(kWide) void k_fw_stats(DirArgs F, double *P1) {
-  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // columns 2..4: the layout k_f_radii reads
-  for (int s = blockIdx.x * kWide + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kWide) {
-    if (F.ps.slot[s] < 0) continue;
-    double p0, p1, p2;
-    load_from(F.ps, s, p0, p1, p2);
-    acc[2] += p0; acc[3] += p1; acc[4] += p2;
-    F.flag[F.ps.m_to[s]] = F.gen;
-  }
-  block_reduce_store<5, kWide / 64>(acc, P1);
-}
-
-struct FwdOpts {
-  int normalize, strength, rigid;   // rigid: cdcl_trans_rigid3d keeps its centre when normalised
-  int mode;                         // LRR_ICP_SCALE_RMS or _INJECTED (MUSE arrives as injected)
-  double injected;
-};
-
-// cdcl_trans_rigid3d::normalize / cdcl_trans_affine::normalize on (A, t, c)
-// (cdcl_trans_rigid3d.cxx:260-280, cdcl_trans_affine.txx:220-253)
-__device__ __forceinline__ XfD normalized_xf(const XfD &T, const NormD &nm, int rigid) {
-  XfD N;
-  const double f = nm.rm / nm.rf;
-  for (int k = 0; k < 9; ++k) N.A[k] = f * T.A[k];
-  const double d0 = nm.cm[0] - T.c[0], d1 = nm.cm[1] - T.c[1], d2 = nm.cm[2] - T.c[2];
-  for (int r = 0; r < 3; ++r) {
-    const double Ad = (N.A[3 * r] * d0 + N.A[3 * r + 1] * d1) + N.A[3 * r + 2] * d2;
-    N.t[r] = (T.t[r] / nm.rf + Ad / nm.rm) - nm.cf[r] / nm.rf;
-    N.c[r] = rigid ? T.c[r] : 0.0;
-  }
-  return N;
-}
-
-// scalars of the forward list: (cm, rm, cf, rf) from the statistics kernels, or the identity
-__device__ __forceinline__ NormD fwd_norm(const FwdOpts &o, const DirArgs &F, const double *P3, int nb3, double *SC) {
-  __shared__ double sc_norm[8];
-  double tot[2] = {0.0, 0.0};
-  if (o.normalize)
-    for (int b = threadIdx.x; b < nb3; b += kWide) { tot[0] += P3[(size_t)b * 2]; tot[1] += P3[(size_t)b * 2 + 1]; }
-  block_sum_all<2, kWide / 64>(tot);
-  if (threadIdx.x == 0) {
-    if (o.normalize) {
-      for (int k = 0; k < 3; ++k) { sc_norm[k] = SC[SC_CM + k]; sc_norm[4 + k] = SC[SC_CF + k]; }
-      sc_norm[3] = tot[0] / (double)F.n; sc_norm[7] = tot[1] / SC[SC_ND];
-    } else {
-      for (int k = 0; k < 8; ++k) sc_norm[k] = (k == 3 || k == 7) ? 1.0 : 0.0;
-    }
-  }
-  __syncthreads();
-  return norm_from_scalars(sc_norm, false);
-}
-
-// FW1: residuals (cdcl .txx:660-735): also leaves the matched target's location and the pair's
-// strength gain per source, and the sums for the RMS scale under the previous weights
-__global__ __launch_bounds__(kWide) void k_fw_residual(DirArgs F, FwdOpts o, XfD xf, const double *P3, int nb3,
-                                                        double *SC, double *P1) {
-  const NormD nm = fwd_norm(o, F, P3, nb3, SC);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (!o.normalize) for (int k = 0; k < 3; ++k) { SC[SC_CM + k] = 0.0; SC[SC_CF + k] = 0.0; }
-    SC[SC_RM] = nm.rm; SC[SC_RF] = nm.rf;
-  }
-  const XfD T = o.normalize ? normalized_xf(xf, nm, o.rigid) : xf;
-  double acc[2] = {0.0, 0.0};
-  for (int s = xcd_block(blockIdx.x, gridDim.x) * kWide + threadIdx.x; s < F.ps.nsrc; s += gridDim.x * kWide) {
-    if (F.ps.slot[s] < 0) { F.key_s[s] = INFINITY; continue; }
-    double p0, p1, p2, y0, y1, y2;
-    load_from(F.ps, s, p0, p1, p2);
-    const double *q = F.ps.to_rec + (size_t)F.ps.m_to[s] * kRecStride;
-    const double q0 = q[0], q1 = q[1], q2 = q[2];
-    map_loc(T, (p0 - nm.cm[0]) / nm.rm, (p1 - nm.cm[1]) / nm.rm, (p2 - nm.cm[2]) / nm.rm, y0, y1, y2);
-    const double r2 = proj_residual2(y0, y1, y2, (q0 - nm.cf[0]) / nm.rf, (q1 - nm.cf[1]) / nm.rf, (q2 - nm.cf[2]) / nm.rf,
-                                     q[3], q[4], q[5], q[6], q[7], q[8]);
-    F.q_loc[3 * (size_t)s] = q0; F.q_loc[3 * (size_t)s + 1] = q1; F.q_loc[3 * (size_t)s + 2] = q2;
-    {
-      const double sp = F.ps.from_str[s], sq = q[9];
-      const double g = F.float_product ? (double)((float)sp * (float)sq) : sp * sq;
-      F.key_g[s] = g > 90000.0 ? 90000.0 : g;
-    }
-    const double wp = F.w[s];
-    acc[0] += wp * r2;
-    acc[1] += wp;
-    F.r2[s] = r2;
-    F.key_s[s] = sqrt(r2);  // MUSE sorts these (first estimate)
-  }
-  block_reduce_store<2, kWide / 64>(acc, P1);
-}
-
-// FW2: scale, Beaton-Tukey weights (cdcl .txx:736-822), strength gain and its key (cdcl .txx:826-862).
-// FOLD: the first half of the strength keys' order statistic rides along, as in k_f_weights (one job, state slot 8).
-template <bool FOLD>
-__global__ __launch_bounds__(kWide) void k_fw_weights(DirArgs F, FwdOpts o, const double *P1, int nb1, double *SC,
-                                                       double *P4, FoldArgs fo) {
-  __shared__ unsigned long long stage[FOLD ? kFoldStage : 1];
-  __shared__ int nstage, gpos;
-  // loads that do not depend on the block sums first: the selection window and this thread's first batch
-  constexpr int U = kStreamBatch;
-  const int stride = gridDim.x * kWide;
-  double lo_g = INFINITY, hi_g = INFINITY, below[2] = {0.0, 0.0};
-  if (FOLD) {
-    const double vg = fo.prev[8], dg = fo.win[8];
-    if (vg > 0.0 && vg < INFINITY) { lo_g = vg * (1.0 - dg); hi_g = vg * (1.0 + dg); }
-    if (threadIdx.x == 0) nstage = 0;
-  }
-  double tot[2] = {0.0, 0.0};
-  if (o.mode == LRR_ICP_SCALE_RMS && (int)threadIdx.x < nb1) { tot[0] = P1[(size_t)threadIdx.x * 2]; tot[1] = P1[(size_t)threadIdx.x * 2 + 1]; }
-  block_sum_all<2, kWide / 64>(tot);  // (its barriers also publish nstage)
-  const double scale = o.mode == LRR_ICP_SCALE_RMS ? sqrt(tot[0] / tot[1]) : o.injected;
-  if (blockIdx.x == 0 && threadIdx.x == 0) SC[SC_SIGF] = scale;
-  const double scale2 = scale * scale;
-  double acc[1] = {0.0};
-  for (int s0 = blockIdx.x * kWide + threadIdx.x; s0 < F.ps.nsrc; s0 += U * stride) {
-    int sl[U];
-    double r2v[U], gv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u * stride;
-      sl[u] = -2; r2v[u] = 0.0; gv[u] = 0.0;
-      if (s < F.ps.nsrc) { sl[u] = F.ps.slot[s]; r2v[u] = F.r2[s]; gv[u] = F.key_g[s]; }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u * stride;
-      if (sl[u] == -2) continue;
-      if (sl[u] < 0) { F.key_g[s] = INFINITY; continue; }
-      double uu = r2v[u] / scale2, bt = 0.0;
-      if (uu <= 16.0) { double temp = 1 - uu * 0.0625; bt = temp * temp; }
-      double wi = bt / scale2;
-      double key = INFINITY;
-      if (o.strength && wi != 0) {
-        const double g = gv[u];
-        wi = wi * g;
-        key = g;
-        acc[0] += 1.0;
-      }
-      F.key_g[s] = key;
-      if (FOLD) {
-        if (key < lo_g) below[0] += 1.0;
-        else if (key <= hi_g) { const int p = atomicAdd(&nstage, 1); if (p < kFoldStage) stage[p] = (unsigned long long)__double_as_longlong(key); }
-      }
-      F.w[s] = wi;
-    }
-  }
-  block_reduce_store<1, kWide / 64>(acc, P4);
-  if (FOLD) {
-    block_reduce_store<2, kWide / 64>(below, fo.P5);  // (its barriers also publish the staged keys)
-    if (threadIdx.x == 0) gpos = atomicAdd(&fo.cursor[0], nstage > kFoldStage ? kSelCap + 1 : nstage);
-    __syncthreads();
-    const int n = min(nstage, kFoldStage), p0 = gpos;
-    if (nstage <= kFoldStage && p0 + n <= kSelCap)
-      for (int k = threadIdx.x; k < n; k += kWide) fo.coll[p0 + k] = stage[k];
-  }
-}
-
-// FW3: final weights and the normal equations (cdcl .txx:1039-1069)
-template <int DOF>
-__global__ __launch_bounds__(kBlock) void k_fw_accumulate(DirArgs F, FwdOpts o, const double *SC, const double *SEL,
-                                                          double c0, double c1, double c2, int rigid_increment,
-                                                          double *P6) {
-  constexpr int NT = Tri<DOF>::N;
-  constexpr int U = kAccBatch;
-  const NormD nm = norm_from_scalars(SC, false);
-  const double fg = o.strength ? mad_factor(SEL) : 1.0;
-  double acc[NT + DOF];
-#pragma unroll
-  for (int k = 0; k < NT + DOF; ++k) acc[k] = 0.0;
-  const int stride = gridDim.x * kBlock;
-  const int lb = (gridDim.x & 7) == 0 ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  for (int s0 = lb * kBlock + threadIdx.x; s0 < F.ps.nsrc; s0 += U * stride) {
-    int mt[U];
-    double wi[U];
-    bool on[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u * stride;
-      const bool in = s < F.ps.nsrc;
-      on[u] = in && F.ps.slot[s] >= 0;
-      wi[u] = in ? F.w[s] : 0.0;
-      mt[u] = in ? F.ps.m_to[s] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
-      if (o.strength) { wi[u] = wi[u] * fg; F.w[s0 + u * stride] = wi[u]; }
-    }
-    double pl[U][3], ql[U][3], Pq[U][6];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
-      const int s = s0 + u * stride;
-      load_from(F.ps, s, pl[u][0], pl[u][1], pl[u][2]);
-      const double *qc = F.q_loc + 3 * (size_t)s;
-      ql[u][0] = qc[0]; ql[u][1] = qc[1]; ql[u][2] = qc[2];
-      const double *pr = F.ps.to_rec + (size_t)mt[u] * kRecStride;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (!on[u]) continue;
-      double p0 = (pl[u][0] - nm.cm[0]) / nm.rm, p1 = (pl[u][1] - nm.cm[1]) / nm.rm, p2 = (pl[u][2] - nm.cm[2]) / nm.rm;
-      double q0 = (ql[u][0] - nm.cf[0]) / nm.rf, q1 = (ql[u][1] - nm.cf[1]) / nm.rf, q2 = (ql[u][2] - nm.cf[2]) / nm.rf;
-      double P[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) P[k] = Pq[u][k];
-      accumulate_pair<DOF, false>(acc, wi[u], p0, p1, p2, q0, q1, q2, P, c0, c1, c2, rigid_increment);
-    }
-  }
-  block_reduce_store<NT + DOF>(acc, P6);
-}
-
-// FW3 for 12 degrees of freedom: Kronecker sums (accumulate_pair_kron), two blocks per compute unit
-__global__ __launch_bounds__(kBlock, 2) void k_fw_accumulate_kron(DirArgs F, FwdOpts o, const double *SC, const double *SEL,
-                                                                  double c0, double c1, double c2, int rigid_increment,
-                                                                  double *P6) {
-  constexpr int U = kKronBatch;
-  const NormD nm = norm_from_scalars(SC, false);
-  const double fg = o.strength ? mad_factor(SEL) : 1.0;
-  double acc[kKron];
-#pragma unroll
-  for (int k = 0; k < kKron; ++k) acc[k] = 0.0;
-  const int stride = gridDim.x * kBlock;
-  const int lb = (gridDim.x & 7) == 0 ? xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  for (int s0 = lb * kBlock + threadIdx.x; s0 < F.ps.nsrc; s0 += U * stride) {
-    int sl[U], mt[U];
-    double wi[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u * stride;
-      const bool in = s < F.ps.nsrc;
-      sl[u] = in ? F.ps.slot[s] : -1;
-      wi[u] = in ? F.w[s] : 0.0;
-      mt[u] = in ? F.ps.m_to[s] : 0;
-    }
-    double pl[U][3], ql[U][3], Pq[U][6];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (sl[u] < 0) continue;
-      const int s = s0 + u * stride;
-      load_from(F.ps, s, pl[u][0], pl[u][1], pl[u][2]);
-      const double *qc = F.q_loc + 3 * (size_t)s;
-      ql[u][0] = qc[0]; ql[u][1] = qc[1]; ql[u][2] = qc[2];
-      const double *pr = F.ps.to_rec + (size_t)mt[u] * kRecStride;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) Pq[u][k] = pr[3 + k];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (sl[u] < 0) continue;
-      if (o.strength) { wi[u] = wi[u] * fg; F.w[s0 + u * stride] = wi[u]; }
-      double p0 = (pl[u][0] - nm.cm[0]) / nm.rm, p1 = (pl[u][1] - nm.cm[1]) / nm.rm, p2 = (pl[u][2] - nm.cm[2]) / nm.rm;
-      double q0 = (ql[u][0] - nm.cf[0]) / nm.rf, q1 = (ql[u][1] - nm.cf[1]) / nm.rf, q2 = (ql[u][2] - nm.cf[2]) / nm.rf;
-      accumulate_pair_kron<false>(acc, wi[u], p0, p1, p2, q0, q1, q2, Pq[u], c0, c1, c2, rigid_increment);
-    }
-  }
-  block_reduce_store<kKron>(acc, P6, (int)gridDim.x);
-}
-
-// ---------------------------------------------------------------------------------------------
-// search-grid build on the device (lrr_icp_cloud_create): counting sort of the features by x-slice of
-// their cell (raster order, the search structure) and by (tile, cell) (canonical order), both with
-// the original index as the tie rule, so the arrays do not depend on the order the atomics land in
-// ---------------------------------------------------------------------------------------------
-struct GridGeom { double lox, loy, loz, inv_h; int dx, dy, dz, fine, tdx, tdy; };
-__device__ __forceinline__ void cell_of(const GridGeom &G, double x, double y, double z, int &id, int &slice) {
-  int cx = clampi((int)floor((x - G.lox) * G.inv_h), 0, G.dx - 1);
-  int cy = clampi((int)floor((y - G.loy) * G.inv_h), 0, G.dy - 1);
-  int cz = clampi((int)floor((z - G.loz) * G.inv_h), 0, G.dz - 1);
-  id = (cz * G.dy + cy) * G.dx + cx;
-  // floor(fine * a) / fine == floor(a) for a power of two: the slice lies inside the point's cell; the clamp covers the grid boundary
-  int xf = (int)floor((x - G.lox) * (G.inv_h * G.fine));
-  xf = min(max(xf, cx * G.fine), cx * G.fine + G.fine - 1);
-  slice = id * G.fine + (xf - cx * G.fine);
-}
-// position of cell `id` in the canonical cell order: tiles of kTile^3 cells, raster order inside a tile
-__device__ __forceinline__ int canon_cell(const GridGeom &G, int id) {
-  const int cx = id % G.dx, cy = (id / G.dx) % G.dy, cz = id / (G.dx * G.dy);
-  const int tile = ((cz / kTile) * G.tdy + cy / kTile) * G.tdx + cx / kTile;
-  return tile * (kTile * kTile * kTile) + ((cz % kTile) * kTile + cy % kTile) * kTile + cx % kTile;
-}
-__global__ void k_g_count(const double *loc, int n, GridGeom G, int *slice_of, int *fine_count, int *ccount) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int id, sl;
-  cell_of(G, loc[3 * (size_t)i], loc[3 * (size_t)i + 1], loc[3 * (size_t)i + 2], id, sl);
-  slice_of[i] = sl;
-  atomicAdd(&fine_count[sl], 1);           // integer counts: order-independent
-  atomicAdd(&ccount[canon_cell(G, id)], 1);
-}
-// exclusive scan of n ints in place, three launches: per-block scan of kScanItems items, scan of the block totals, add
-constexpr int kScanThreads = 1024, kScanPer = 8, kScanItems = kScanThreads * kScanPer;
-__global__ __launch_bounds__(kScanThreads) void k_scan_blocks(int *data, long long n, int *sums) {
-  __shared__ int wave_tot[kScanThreads / 64];
-  const long long base = (long long)blockIdx.x * kScanItems + (long long)threadIdx.x * kScanPer;
-  int v[kScanPer], t = 0;
-#pragma unroll
-  for (int u = 0; u < kScanPer; ++u) { v[u] = base + u < n ? data[base + u] : 0; t += v[u]; }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int incl = t;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) { int x = __shfl_up(incl, off, 64); if (lane >= off) incl += x; }
-  if (lane == 63) wave_tot[wv] = incl;
-  __syncthreads();
-  int before = 0, total = 0;
-  for (int w2 = 0; w2 < kScanThreads / 64; ++w2) { if (w2 < wv) before += wave_tot[w2]; total += wave_tot[w2]; }
-  int run = before + incl - t;
-#pragma unroll
-  for (int u = 0; u < kScanPer; ++u) { if (base + u < n) data[base + u] = run; run += v[u]; }
-  if (threadIdx.x == 0) sums[blockIdx.x] = total;
-}
-__global__ __launch_bounds__(kScanThreads) void k_scan_sums(int *sums, int nb) {
-  __shared__ int wave_tot[kScanThreads / 64];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int b0 = 0; b0 < nb; b0 += kScanThreads) {
-    const int b = b0 + threadIdx.x;
-    const int v = b < nb ? sums[b] : 0;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { int x = __shfl_up(incl, off, 64); if (lane >= off) incl += x; }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    int before = 0, total = 0;
-    for (int w2 = 0; w2 < kScanThreads / 64; ++w2) { if (w2 < wv) before += wave_tot[w2]; total += wave_tot[w2]; }
-    if (b < nb) sums[b] = carry + before + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 0) carry += total;
-    __syncthreads();
-  }
-}
-__global__ __launch_bounds__(kScanThreads) void k_scan_add(int *data, long long n, const int *sums) {
-  const int add = sums[blockIdx.x];
-  const long long base = (long long)blockIdx.x * kScanItems + (long long)threadIdx.x * kScanPer;
-#pragma unroll
-  for (int u = 0; u < kScanPer; ++u) if (base + u < n) data[base + u] += add;
-}
-__global__ void k_g_cell_start(const int *fine_start, int fine, long long ncell, int *cell_start) {
-  long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c <= ncell) cell_start[c] = fine_start[c * fine];
-}
-__global__ void k_g_scatter(const int *slice_of, int n, const int *fine_start, int *cursor, int *raster_orig) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int sl = slice_of[i];
-  raster_orig[fine_start[sl] + atomicAdd(&cursor[sl], 1)] = i;  // any order inside the slice: k_g_place ranks it
-}
-// every feature finds its rank among the features of its slice / of its cell by original index: its final
-// raster position and its canonical index
-__global__ void k_g_place(const int *slice_of, const int *raster_orig, int n, GridGeom G, const int *fine_start,
-                          const int *cstart, const double *loc, int *canon_of, int *orig_of, GridPoint *gp, float4 *gpf) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int i = raster_orig[p], sl = slice_of[i], id = sl / G.fine;
-  const int s0 = fine_start[sl], s1 = fine_start[sl + 1], c0 = fine_start[id * G.fine], c1 = fine_start[(id + 1) * G.fine];
-  int rs = 0, rc = 0;
-  for (int j = c0; j < c1; ++j) {
-    const int o = raster_orig[j];
-    rc += o < i;
-    rs += (j >= s0 && j < s1 && o < i);
-  }
-  const int canon = cstart[canon_cell(G, id)] + rc;
-  canon_of[i] = canon;
-  orig_of[canon] = i;
-  const double x = loc[3 * (size_t)i], y = loc[3 * (size_t)i + 1], z = loc[3 * (size_t)i + 2];
-  GridPoint pt;
-  pt.x = x; pt.y = y; pt.z = z; pt.canon = canon; pt.orig = i;
-  gp[s0 + rs] = pt;
-  float4 f;
-  f.x = (float)((x - G.lox) * G.inv_h); f.y = (float)((y - G.loy) * G.inv_h); f.z = (float)((z - G.loz) * G.inv_h);
-  f.w = __int_as_float(canon);
-  gpf[s0 + rs] = f;
-}
-// the per-feature arrays in canonical order
-__global__ void k_g_fill(const int *orig_of, int n, const double *loc, const double *proj, const double *strength,
-                         int float_strength, double *rec, SrcPoint *src, double *str, GridPoint *cpt) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n) return;
-  const int i = orig_of[s];
-  const double x = loc[3 * (size_t)i], y = loc[3 * (size_t)i + 1], z = loc[3 * (size_t)i + 2];
-  const double *P = proj + 9 * (size_t)i;
-  double *r = rec + (size_t)s * kRecStride;
-  r[0] = x; r[1] = y; r[2] = z;
-  r[3] = P[0]; r[4] = P[1]; r[5] = P[2]; r[6] = P[4]; r[7] = P[5]; r[8] = P[8];
-  double st = strength ? strength[i] : 0.0;
-  if (float_strength) st = (double)(float)st;
-  r[9] = st;
-  str[s] = st;
-  SrcPoint sp;
-  sp.x = x; sp.y = y; sp.z = z; sp.orig = i;
-  src[s] = sp;
-  GridPoint pt;
-  pt.x = x; pt.y = y; pt.z = z; pt.canon = s; pt.orig = i;
-  cpt[s] = pt;
-}
+#include "lrr_icp_k1.inc"
+#include "lrr_icp_passes.inc"
+#include "lrr_icp_fused.inc"
+#include "lrr_icp_grid.inc"
 
 // ---------------------------------------------------------------------------------------------
 // host helpers
