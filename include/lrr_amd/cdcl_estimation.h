@@ -1,0 +1,281 @@
+// cdcl_estimation.h — the covariance-driven EM estimator of cdcl/cdcl_estimation.{h,txx} on the device pieces of
+// include/lrr_icp.h: compute_weights (E-step), estimate_parameters and estimate_covariance
+// (M-step) and the one_iteration that strings them together, for the affine transform.
+//
+//   cdcl_obj_fun_par<3, dof> / cdcl_obj_fun_cov<3, dof>   compute(x, f, g): the two cost functions the reference hands to its
+//       optimiser (cdcl/cdcl_obj_fun_par.txx:44-142, cdcl/cdcl_obj_fun_cov.txx:42-134), evaluated over match rows that
+//       stay on the device.  With VXL at hand they plug into vnl_lbfgs as the reference's do (same compute() signature).
+//   cdcl_lbfgs            stand-in for the reference's wrapper of vnl_lbfgs (third party, absent): lbfgs_standin.h
+//   cdcl_estimation_em    compute_weights / estimate_parameters / estimate_covariance / one_iteration of
+//       cdcl_estimation<3,12> (cdcl/cdcl_estimation.txx:95-187, 210-338, 342-545)
+//
+// Not provided: the ICP base class that initialises the reference's estimator (cdcl_estimation_ICP: the caller passes an
+// initial transform with its covariance), resolution switching inside compute_weights, and the rigid small-angle
+// increment (its pre-mapped feature copies, :118-141): the affine transform only.
+#ifndef LRR_AMD_CDCL_ESTIMATION_H_
+#define LRR_AMD_CDCL_ESTIMATION_H_
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "lrr_amd/icp_engine.h"
+#include "lrr_amd/lbfgs_standin.h"
+
+namespace lrr_amd {
+
+// match rows of a moving / fixed pair, resident on the device
+class cdc_match_rows {
+ public:
+  cdc_match_rows(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, int max_matches = 100) : set_(nullptr) {
+    check(lrr_icp_cdc_set_create(moving, fixed, max_matches, &set_), "cdc_set_create");
+  }
+  ~cdc_match_rows() { if (set_) lrr_icp_cdc_set_destroy(set_); }
+  cdc_match_rows(const cdc_match_rows &) = delete;
+  cdc_match_rows &operator=(const cdc_match_rows &) = delete;
+  lrr_icp_cdc_set *handle() const { return set_; }
+
+ private:
+  lrr_icp_cdc_set *set_;
+};
+
+// (cdcl/cdcl_obj_fun_par.h:24-52) constructor: matches + transform (its centre and covariance enter J_th C_theta J_th^T);
+// compute(): value and gradient at the parameter vector x (A row-major, then t)
+template <unsigned dim, unsigned dof>
+class cdcl_obj_fun_par {
+ public:
+  cdcl_obj_fun_par(cdc_match_rows const &rows, typename cdcl_trans<dim, dof>::sptr const &trans, const lrr_icp_norm *norm)
+      : rows_(rows), trans_(trans), norm_(norm ? *norm : lrr_icp_norm()), has_norm_(norm != nullptr) {
+    static_assert(dim == 3 && dof == 12, "the affine transform in 3-D");
+    vnl_matrix_fixed<double, dof, dof> const &C = trans_->get_covariance();
+    for (unsigned i = 0; i < dof; ++i) for (unsigned j = 0; j < dof; ++j) covar_[i * dof + j] = C(i, j);
+  }
+  void compute(const vnl_vector<double> &x, double *f, vnl_vector<double> *g) {
+    trans_->set_parameterization(x);  // (:50) update transformation
+    lrr_icp_xform xf;
+    vnl_matrix_fixed<double, 3, 3> &A = trans_->get_A();
+    vnl_vector_fixed<double, 3> &t = trans_->get_translation();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) xf.A[3 * r + c] = A(r, c); xf.t[r] = t[r]; xf.c[r] = trans_->center_moving_[r]; }
+    double fv = 0.0, gv[dof];
+    check(lrr_icp_cdc_objective_par(rows_.handle(), &xf, (int)dof, covar_, has_norm_ ? &norm_ : nullptr, &fv, g ? gv : nullptr, nullptr),
+          "cdc objective (parameters)");
+    if (f) *f = fv;
+    if (g) for (unsigned i = 0; i < dof; ++i) (*g)[i] = gv[i];
+  }
+
+ private:
+  cdc_match_rows const &rows_;
+  typename cdcl_trans<dim, dof>::sptr trans_;
+  lrr_icp_norm norm_;
+  bool has_norm_;
+  double covar_[dof * dof];
+};
+
+// (cdcl/cdcl_obj_fun_cov.h) compute(): value and gradient at the dof (dof + 1) / 2 entries of the upper-triangular
+// Cholesky factor of the parameter covariance; sets the transform's covariance to U^T U (:57)
+template <unsigned dim, unsigned dof>
+class cdcl_obj_fun_cov {
+ public:
+  cdcl_obj_fun_cov(cdc_match_rows const &rows, typename cdcl_trans<dim, dof>::sptr const &trans, const lrr_icp_norm *norm)
+      : rows_(rows), trans_(trans), norm_(norm ? *norm : lrr_icp_norm()), has_norm_(norm != nullptr) {
+    static_assert(dim == 3 && dof == 12, "the affine transform in 3-D");
+  }
+  void compute(const vnl_vector<double> &x, double *f, vnl_vector<double> *g) {
+    const unsigned ncov = dof * (dof + 1) / 2;
+    vnl_matrix_fixed<double, dof, dof> U(0.0);
+    unsigned ind = 0;
+    for (unsigned d1 = 0; d1 < dof; ++d1) for (unsigned d2 = d1; d2 < dof; ++d2) U(d1, d2) = x[ind++];
+    trans_->set_covariance(U.transpose() * U);
+    lrr_icp_xform xf;
+    vnl_matrix_fixed<double, 3, 3> &A = trans_->get_A();
+    vnl_vector_fixed<double, 3> &t = trans_->get_translation();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) xf.A[3 * r + c] = A(r, c); xf.t[r] = t[r]; xf.c[r] = trans_->center_moving_[r]; }
+    double fv = 0.0, gv[ncov], xv[ncov];
+    for (unsigned i = 0; i < ncov; ++i) xv[i] = x[i];
+    check(lrr_icp_cdc_objective_cov(rows_.handle(), &xf, (int)dof, xv, has_norm_ ? &norm_ : nullptr, &fv, g ? gv : nullptr, nullptr),
+          "cdc objective (covariance)");
+    if (f) *f = fv;
+    if (g) for (unsigned i = 0; i < ncov; ++i) (*g)[i] = gv[i];
+  }
+
+ private:
+  cdc_match_rows const &rows_;
+  typename cdcl_trans<dim, dof>::sptr trans_;
+  lrr_icp_norm norm_;
+  bool has_norm_;
+};
+
+// The interface of cdcl_lbfgs the estimator uses (cdcl/cdcl_lbfgs.h; cdcl/cdcl_estimation.txx:230-248), over the stand-in
+// optimiser.  F: a class with compute(const vnl_vector<double> &, double *, vnl_vector<double> *).
+template <class F>
+class cdcl_lbfgs {
+ public:
+  explicit cdcl_lbfgs(F &f) : f_(f), max_evals_(5) { res_.f_start = res_.f_end = 0.0; res_.evals = 0; res_.code = 0; }
+  void set_max_function_evals(int n) { max_evals_ = n; }
+  void set_verbose(bool) {}
+  void set_check_derivatives(bool) {}
+  void set_trace(bool) {}
+  bool minimize(vnl_vector<double> &x) {
+    n_ = (int)x.size();
+    std::vector<double> v((size_t)n_);
+    for (int i = 0; i < n_; ++i) v[(size_t)i] = x[(unsigned)i];
+    res_ = lrr_lbfgs_minimize(n_, v.data(), &cdcl_lbfgs::thunk, this, max_evals_);
+    if (res_.code > 0) for (int i = 0; i < n_; ++i) x[(unsigned)i] = v[(size_t)i];
+    return res_.code == LRR_LBFGS_CONVERGED;
+  }
+  double get_start_error() const { return res_.f_start; }
+  double get_end_error() const { return res_.f_end; }
+  int get_failure_code() const { return res_.code; }
+  int get_num_evaluations() const { return res_.evals; }
+
+ private:
+  static void thunk(void *self, const double *x, double *f, double *g) {
+    cdcl_lbfgs *me = static_cast<cdcl_lbfgs *>(self);
+    vnl_vector<double> xv((unsigned)me->n_, 0.0), gv((unsigned)me->n_, 0.0);
+    for (int i = 0; i < me->n_; ++i) xv[(unsigned)i] = x[i];
+    me->f_.compute(xv, f, &gv);
+    for (int i = 0; i < me->n_; ++i) g[i] = gv[(unsigned)i];
+  }
+  F &f_;
+  int max_evals_, n_ = 0;
+  lrr_lbfgs_result res_;
+};
+
+// The EM loop of cdcl_estimation<3,12> around the device pieces.  moving / fixed: device clouds with covariances
+// (lrr_icp_cloud_set_covariances); trans: the affine transform with its covariance, modified in place as the reference's
+// estimator modifies the caller's transform object.
+class cdcl_estimation_em {
+ public:
+  static const unsigned dof = 12;
+  typedef cdcl_trans<3, 12>::sptr trans_sptr_type;
+  cdcl_estimation_em(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, trans_sptr_type const &trans, uint64_t seed = 1, int max_matches = 100)
+      : rows_(moving, fixed, max_matches), trans_(trans), seed_(seed), normalize_matches_(true), overflow_rows_(0) {
+    std::memset(&last_, 0, sizeof last_);
+  }
+  void normalize_matches(bool on = true) { normalize_matches_ = on; }
+  trans_sptr_type get_transform() const { return trans_; }
+  cdc_match_rows const &rows() const { return rows_; }
+  int64_t overflow_rows() const { return overflow_rows_; }
+  struct step_info { double par_start, par_end, cov_start, cov_end; int par_code, cov_code, par_evals, cov_evals; };
+  step_info const &last_step() const { return last_; }
+
+  // (cdcl/cdcl_estimation.txx:342-545, one resolution)
+  void compute_weights() {
+    lrr_icp_xform xf = xform();
+    uint32_t keys[4];
+    lrr_icp_perm_keys(&seed_, keys);
+    double C[dof * dof];
+    covariance(C);
+    check(lrr_icp_cdc_set_compute_weights(rows_.handle(), &xf, (int)dof, C, keys, &overflow_rows_), "cdc compute_weights");
+  }
+  // (:210-260)
+  bool estimate_parameters() {
+    lrr_icp_norm nm;
+    normalize(nm);
+    cdcl_obj_fun_par<3, 12> f_par(rows_, trans_, normalize_matches_ ? &nm : nullptr);
+    vnl_vector<double> x = trans_->get_parameterization(), x_old = x;
+    cdcl_lbfgs<cdcl_obj_fun_par<3, 12> > minimizer(f_par);
+    minimizer.set_max_function_evals(5);
+    bool converged = minimizer.minimize(x);
+    bool parameters_converged = (minimizer.get_start_error() - minimizer.get_end_error()) < 1e-4;
+    if ((!converged && minimizer.get_failure_code() < 0) || x.size() == 0) trans_->set_parameterization(x_old);
+    else trans_->set_parameterization(x);
+    unnormalize(nm);
+    last_.par_start = minimizer.get_start_error(); last_.par_end = minimizer.get_end_error();
+    last_.par_code = minimizer.get_failure_code(); last_.par_evals = minimizer.get_num_evaluations();
+    return parameters_converged;
+  }
+  // (:264-338)
+  bool estimate_covariance() {
+    lrr_icp_norm nm;
+    normalize(nm);
+    cdcl_obj_fun_cov<3, 12> f_cov(rows_, trans_, normalize_matches_ ? &nm : nullptr);
+    const unsigned cov_dof = dof * (dof + 1) / 2;
+    // upper triangular Cholesky factor of the covariance -> x (:283-293)
+    double C[dof * dof], U[dof * dof];
+    covariance(C);
+    if (!chol_upper(C, U)) throw std::runtime_error("cdcl_estimation_em: the parameter covariance is not positive definite");
+    vnl_vector<double> x(cov_dof, 0.0);
+    unsigned ind = 0;
+    for (unsigned d1 = 0; d1 < dof; ++d1) for (unsigned d2 = d1; d2 < dof; ++d2) x[ind++] = U[d1 * dof + d2];
+    vnl_vector<double> x_old = x;
+    cdcl_lbfgs<cdcl_obj_fun_cov<3, 12> > minimizer(f_cov);
+    minimizer.set_max_function_evals(5);
+    bool converged = minimizer.minimize(x);
+    bool covariance_converged = (minimizer.get_start_error() - minimizer.get_end_error()) < 1e-5;
+    if ((!converged && minimizer.get_failure_code() < 0) || x.size() == 0) x = x_old;
+    // the covariance from its factor (:313-323)
+    vnl_matrix_fixed<double, dof, dof> upper(0.0);
+    ind = 0;
+    for (unsigned d1 = 0; d1 < dof; ++d1) for (unsigned d2 = d1; d2 < dof; ++d2) upper(d1, d2) = x[ind++];
+    trans_->set_covariance(upper.transpose() * upper);
+    unnormalize(nm);
+    last_.cov_start = minimizer.get_start_error(); last_.cov_end = minimizer.get_end_error();
+    last_.cov_code = minimizer.get_failure_code(); last_.cov_evals = minimizer.get_num_evaluations();
+    return covariance_converged;
+  }
+  // (:95-187) for the affine transform
+  bool one_iteration(unsigned iteration) {
+    const unsigned startEM = 5;
+    this->compute_weights();
+    bool parameters_converged = false, covariance_converged = false;
+    if (iteration > startEM) {
+      parameters_converged = this->estimate_parameters();
+      this->compute_weights();
+    }
+    covariance_converged = this->estimate_covariance();
+    double fro = 0.0;
+    vnl_matrix_fixed<double, dof, dof> const &C = trans_->get_covariance();
+    for (unsigned i = 0; i < dof; ++i) for (unsigned j = 0; j < dof; ++j) fro += C(i, j) * C(i, j);
+    return parameters_converged && covariance_converged && std::sqrt(fro) < 1e-3;
+  }
+
+ private:
+  lrr_icp_xform xform() const {
+    lrr_icp_xform x;
+    vnl_matrix_fixed<double, 3, 3> &A = trans_->get_A();
+    vnl_vector_fixed<double, 3> &t = trans_->get_translation();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) x.A[3 * r + c] = A(r, c); x.t[r] = t[r]; x.c[r] = trans_->center_moving_[r]; }
+    return x;
+  }
+  void covariance(double *C) const {
+    vnl_matrix_fixed<double, dof, dof> const &M = trans_->get_covariance();
+    for (unsigned i = 0; i < dof; ++i) for (unsigned j = 0; j < dof; ++j) C[i * dof + j] = M(i, j);
+  }
+  // cdcl_normalize_matches + trans_->normalize (:218-221); the features themselves are normalised on the fly by the kernels
+  void normalize(lrr_icp_norm &nm) {
+    if (!normalize_matches_) return;
+    check(lrr_icp_cdc_normalize_stats(rows_.handle(), &nm), "cdc normalize statistics");
+    vnl_vector_fixed<double, 3> cm, cf;
+    for (int d = 0; d < 3; ++d) { cm[d] = nm.cm[d]; cf[d] = nm.cf[d]; }
+    trans_->normalize(nm.rm, nm.rf, cm, cf);
+  }
+  void unnormalize(lrr_icp_norm const &nm) {
+    if (!normalize_matches_) return;
+    vnl_vector_fixed<double, 3> cm, cf;
+    for (int d = 0; d < 3; ++d) { cm[d] = nm.cm[d]; cf[d] = nm.cf[d]; }
+    trans_->unnormalize(nm.rm, nm.rf, cm, cf);
+  }
+  static bool chol_upper(const double *C, double *U) {
+    const int n = (int)dof;
+    std::memset(U, 0, sizeof(double) * dof * dof);
+    for (int i = 0; i < n; ++i)
+      for (int j = i; j < n; ++j) {
+        double s = C[i * n + j];
+        for (int k = 0; k < i; ++k) s -= U[k * n + i] * U[k * n + j];
+        if (i == j) { if (!(s > 0.0)) return false; U[i * n + i] = std::sqrt(s); }
+        else U[i * n + j] = s / U[i * n + i];
+      }
+    return true;
+  }
+
+  cdc_match_rows rows_;
+  trans_sptr_type trans_;
+  uint64_t seed_;
+  bool normalize_matches_;
+  int64_t overflow_rows_;
+  step_info last_;
+};
+
+}  // namespace lrr_amd
+#endif

@@ -16,6 +16,7 @@
 #include "lrr_amd/rrl_estimation_ICP_matching_all.h"
 #include "lrr_amd/rrl_estimation_symmetric_ICP_matching_all.h"
 #include "lrr_amd/location_batch.h"
+#include "lrr_amd/cdcl_estimation.h"
 #include "lrr_amd/vtp_features.h"
 
 extern "C" {
@@ -457,6 +458,60 @@ int lrr_vtp_features(lrr_vtp *v, double *loc, double *proj, double *strength, ui
         for (int d = 0; d < 3; ++d) dirs9[9 * i + 3 * k + d] = f[i]->directions_[k][d];
     }
   });
+}
+
+// ---- covariance-driven EM estimator (cdcl_estimation, include/lrr_amd/cdcl_estimation.h) ------------------------------
+struct lrr_cdc_em {
+  lrr_icp_cloud *moving = nullptr, *fixed = nullptr;
+  cdcl_trans<3, 12>::sptr trans;
+  lrr_amd::cdcl_estimation_em *em = nullptr;
+  ~lrr_cdc_em() {
+    delete em;
+    if (moving) lrr_icp_cloud_destroy(moving);
+    if (fixed) lrr_icp_cloud_destroy(fixed);
+  }
+};
+static lrr_icp_cloud *cdc_cloud(const lrr_est_features *f) {
+  if (!f || !f->cov) throw std::runtime_error("cdc_em: the features need covariances");
+  lrr_icp_cloud *c = nullptr;
+  lrr_amd::check(lrr_icp_cloud_create(lrr_amd::device::ctx(), f->n, f->loc, f->proj, f->strength, 0, &c), "cloud upload");
+  if (lrr_icp_cloud_set_covariances(c, f->cov) != 0) { lrr_icp_cloud_destroy(c); throw std::runtime_error("cdc_em: covariance upload failed"); }
+  return c;
+}
+int lrr_cdc_em_create(const lrr_est_features *moving, const lrr_est_features *fixed, const double *A, const double *t, const double *c,
+                      const double *covar144, uint64_t seed, int max_matches, lrr_cdc_em **out) {
+  return guard([&] {
+    std::unique_ptr<lrr_cdc_em> h(new lrr_cdc_em);
+    h->moving = cdc_cloud(moving);
+    h->fixed = cdc_cloud(fixed);
+    h->trans = trans_factory<12>::make(A, t, c);
+    vnl_matrix_fixed<double, 12, 12> C;
+    for (unsigned r = 0; r < 12; ++r) for (unsigned k = 0; k < 12; ++k) C(r, k) = covar144[r * 12 + k];
+    h->trans->set_covariance(C);
+    h->em = new lrr_amd::cdcl_estimation_em(h->moving, h->fixed, h->trans, seed, max_matches);
+    *out = h.release();
+  });
+}
+void lrr_cdc_em_destroy(lrr_cdc_em *h) { delete h; }
+// info[8]: objective of the parameter estimate at the start / end, of the covariance estimate at the start / end, the two
+// optimiser codes, the two evaluation counts (zeros where a step did not run)
+int lrr_cdc_em_one_iteration(lrr_cdc_em *h, unsigned iteration, int *converged, double *info) {
+  return guard([&] {
+    bool cv = h->em->one_iteration(iteration);
+    if (converged) *converged = cv ? 1 : 0;
+    if (info) {
+      const lrr_amd::cdcl_estimation_em::step_info &s = h->em->last_step();
+      const bool par = iteration > 5;
+      info[0] = par ? s.par_start : 0.0; info[1] = par ? s.par_end : 0.0; info[2] = s.cov_start; info[3] = s.cov_end;
+      info[4] = par ? s.par_code : 0; info[5] = s.cov_code; info[6] = par ? s.par_evals : 0; info[7] = s.cov_evals;
+    }
+  });
+}
+int lrr_cdc_em_get_transform(lrr_cdc_em *h, double *A, double *t, double *c, double *covar144) {
+  return guard([&] { read_trans<12>(h->em->get_transform(), A, t, c, covar144); });
+}
+int lrr_cdc_em_rows(lrr_cdc_em *h, int64_t *row_count, int64_t *to_idx, double *w) {
+  return guard([&] { lrr_amd::check(lrr_icp_cdc_set_get(h->em->rows().handle(), row_count, to_idx, w), "cdc rows"); });
 }
 
 }  // extern "C"

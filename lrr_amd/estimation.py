@@ -381,6 +381,57 @@ class CdcSet:
             self.h = C.c_void_p()
 
 
+class CdcEm:
+    """cdcl_estimation's EM loop (include/lrr_amd/cdcl_estimation.h: lrr_amd::cdcl_estimation_em) for the affine
+    transform: one_iteration() = compute_weights, from iteration 6 on estimate_parameters + compute_weights,
+    estimate_covariance (cdcl/cdcl_estimation.txx:95-187)."""
+
+    def __init__(self, moving, fixed, A, t, c, covar, seed=1, max_matches=100):
+        L = est_lib()
+        self.L = L
+        self._keep = []
+        fm, ff = _features(moving, self._keep), _features(fixed, self._keep)
+        A, t, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, t, c))
+        cv = np.ascontiguousarray(covar, dtype=np.float64)
+        self.nm, self.max_matches = moving.n, int(max_matches)
+        self.h = C.c_void_p()
+        L.lrr_cdc_em_create.argtypes = [C.POINTER(_Features), C.POINTER(_Features), _dp, _dp, _dp, _dp, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]
+        L.lrr_cdc_em_destroy.argtypes = [C.c_void_p]
+        L.lrr_cdc_em_destroy.restype = None
+        L.lrr_cdc_em_one_iteration.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int), _dp]
+        L.lrr_cdc_em_get_transform.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.lrr_cdc_em_rows.argtypes = [C.c_void_p, _ip, _ip, _dp]
+        self._ck(L.lrr_cdc_em_create(C.byref(fm), C.byref(ff), _d(A), _d(t), _d(c), _d(cv), seed, self.max_matches, C.byref(self.h)))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.lrr_est_last_error().decode())
+
+    def one_iteration(self, iteration):
+        """(converged, info[8]: par f start/end, cov f start/end, optimiser codes, evaluations)"""
+        conv = C.c_int(0)
+        info = np.zeros(8)
+        self._ck(self.L.lrr_cdc_em_one_iteration(self.h, int(iteration), C.byref(conv), _d(info)))
+        return bool(conv.value), info
+
+    def get_transform(self):
+        A, t, c, cov = np.zeros((3, 3)), np.zeros(3), np.zeros(3), np.zeros((12, 12))
+        self._ck(self.L.lrr_cdc_em_get_transform(self.h, _d(A), _d(t), _d(c), _d(cov)))
+        return A, t, c, cov
+
+    def rows(self):
+        rc = np.zeros(self.nm, dtype=np.int64)
+        ti = np.zeros((self.nm, self.max_matches), dtype=np.int64)
+        w = np.zeros((self.nm, self.max_matches))
+        self._ck(self.L.lrr_cdc_em_rows(self.h, rc.ctypes.data_as(_ip), ti.ctypes.data_as(_ip), _d(w)))
+        return rc, ti, w
+
+    def close(self):
+        if self.h:
+            self.L.lrr_cdc_em_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def subset_perm(n: int, seed: int):
     """The keyed subset permutation the match kernel evaluates (host copy, for tests)."""
     L = hip_lib()

@@ -185,6 +185,40 @@ def cdc_obj_cov(moving, fixed, dof, A, t, c, x_upper, row_count, to_idx, w, norm
     return f.value, (g if want_grad else None), int(pairs)
 
 
+class CdcEmOracle:
+    """The oracle's EM loop of cdcl_estimation (affine): state in numpy arrays, one_iteration() as the reference orders it"""
+
+    def __init__(self, moving, fixed, A, t, c, covar, seed=1, max_matches=100):
+        self.mv, self.fx = moving, fixed
+        self.A = np.array(A, dtype=np.float64).reshape(3, 3).copy()
+        self.t = np.array(t, dtype=np.float64).copy()
+        self.c = np.array(c, dtype=np.float64).copy()
+        self.cov = np.array(covar, dtype=np.float64).reshape(12, 12).copy()
+        self.state = C.c_uint64(seed)
+        self.mm = int(max_matches)
+        self.rc = np.zeros(moving.n, dtype=np.int64)
+        self.ti = np.full((moving.n, self.mm), -1, dtype=np.int64)
+        self.w = np.zeros((moving.n, self.mm))
+
+    def one_iteration(self, iteration):
+        L = lib()
+        keep = []
+        fm, ff = _features(self.mv, keep), _features(self.fx, keep)
+        info = np.zeros(8)
+        i64p = C.POINTER(C.c_int64)
+        L.lrr_oracle_cdc_em_iteration.restype = C.c_int
+        L.lrr_oracle_cdc_em_iteration.argtypes = [C.POINTER(_Features), C.POINTER(_Features), _dp, _dp, _dp, _dp, C.c_uint, C.POINTER(C.c_uint64),
+                                                  C.c_int, i64p, i64p, _dp, _dp]
+        self.ti.fill(-1)
+        self.w.fill(0.0)
+        r = L.lrr_oracle_cdc_em_iteration(C.byref(fm), C.byref(ff), _d(self.A), _d(self.t), _d(self.c), _d(self.cov), int(iteration),
+                                          C.byref(self.state), self.mm, self.rc.ctypes.data_as(i64p), self.ti.ctypes.data_as(i64p), _d(self.w),
+                                          _d(info))
+        if r < 0:
+            raise RuntimeError("oracle EM iteration: covariance not positive definite")
+        return bool(r), info
+
+
 def muse_scale(res):
     r = np.ascontiguousarray(res, dtype=np.float64)
     return lib().lrr_oracle_muse_scale(_d(r), r.shape[0])

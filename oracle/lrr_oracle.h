@@ -110,6 +110,13 @@ int64_t lrr_oracle_cdc_obj_cov(const lrr_oracle_features *moving, const lrr_orac
                                const double *t, const double *c, const double *x_upper, int max_matches,
                                const int64_t *row_count, const int64_t *to_idx, const double *w, const double *norm,
                                double *f_out, double *g_out);
+/* cdcl_normalize_matches over the one-to-many rows -> {cm[3], rm, cf[3], rf} (cdcl/cdcl_estimation_ICP.txx:751-795) */
+void lrr_oracle_cdc_normalize_stats(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int max_matches,
+                                    const int64_t *row_count, const int64_t *to_idx, double *norm);
+/* one EM iteration of cdcl_estimation, affine transform, no resolution switching (cdcl/cdcl_estimation.txx:95-187, 210-338) */
+int lrr_oracle_cdc_em_iteration(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, double *A, double *t, double *c,
+                                double *covar, unsigned iteration, uint64_t *seed_state, int max_matches,
+                                int64_t *row_count, int64_t *to_idx, double *w, double *info);
 
 /* stand-alone pieces (each is also used inside the estimators) */
 void   lrr_oracle_nn(const double *fixed_loc, int64_t nf, const double *query, int64_t nq,

@@ -230,3 +230,47 @@ def test_em_steps_driven_by_lbfgs_improve_the_transform(E):
     S.close()
     cm.close()
     cf.close()
+
+
+def test_em_iterations_equal_the_oracle(E, ob):
+    """cdcl_estimation::one_iteration for the affine transform (cdcl/cdcl_estimation.txx:95-187: compute_weights, from
+    iteration 6 on estimate_parameters + compute_weights, estimate_covariance), the device path behind the drop-in class
+    lrr_amd::cdcl_estimation_em against the oracle's restatement, both driven by the same stand-in optimiser (five
+    function evaluations per estimate, as the reference caps vnl_lbfgs): match rows exact, objective values, transform and
+    covariance to tolerance, iteration by iteration through the switch at iteration 6."""
+    n = 5000
+    pair = synth.make_pair(n, n - 400, 313, kind="affine", extent=60.0)
+    mv = dataclasses.replace(pair.moving, cov=synth.covariances(pair.moving))
+    fx = dataclasses.replace(pair.fixed, cov=synth.covariances(pair.fixed))
+    T0 = synth.perturbed(pair.planted, 5, rot_deg=0.4, trans_mm=0.5)
+    B = np.random.default_rng(4).normal(size=(12, 12)) * 2e-3
+    B[9:] *= 50.0
+    Ct = B @ B.T
+    g = E.CdcEm(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, max_matches=100)
+    c = ob.CdcEmOracle(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, max_matches=100)
+    saw_parameters = False
+    for it in range(9):
+        cg, ig = g.one_iteration(it)
+        cc, ic = c.one_iteration(it)
+        assert cg == cc, it
+        rc, ti, w = g.rows()
+        assert np.array_equal(rc, c.rc), it
+        for i in np.flatnonzero(rc)[::37]:
+            k = int(rc[i])
+            o = np.argsort(ti[i, :k], kind="stable")
+            assert np.array_equal(ti[i, :k][o], c.ti[i, :k]), (it, i)
+            assert np.allclose(w[i, :k][o], c.w[i, :k], rtol=1e-7, atol=1e-300), (it, i)
+        # optimiser codes and evaluation counts equal; objective values close
+        assert np.array_equal(ig[4:], ic[4:]), (it, ig, ic)
+        assert np.allclose(ig[:4], ic[:4], rtol=1e-8, atol=1e-12), (it, ig, ic)
+        A, t, cen, cov = g.get_transform()
+        assert np.allclose(A, c.A, rtol=0, atol=1e-8 * np.abs(c.A).max()), it
+        assert np.allclose(t, c.t, rtol=0, atol=1e-7 * max(1.0, np.abs(c.t).max())), it
+        assert np.allclose(cen, c.c, rtol=1e-12, atol=1e-12), it
+        assert np.allclose(cov, c.cov, rtol=1e-5, atol=1e-7 * np.abs(c.cov).max()), it
+        if it > 5:
+            saw_parameters = True
+            assert ig[6] >= 2 and ig[1] <= ig[0]   # the parameter estimate ran and did not raise its objective
+        assert ig[7] >= 2 and ig[3] <= ig[2]
+    assert saw_parameters
+    g.close()
