@@ -175,12 +175,23 @@ def schedule_run(E, pair, T0, nn, timer):
     total = time.perf_counter() - t_all
     timer.match_profile(enable=False, reset=True)
     est.close()
+    # the same run as ONE call (the caller's loop in C++: no interpreter, no per-iteration synchronisation or event
+    # records between the iterations): the time a caller of run() sees
+    est = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                      moving_inside=pair.moving, fixed_inside=pair.fixed, seed=7, nn_method=nn)
+    timer.synchronize()
+    t0 = time.perf_counter()
+    conv2, it2, pairs2 = est.run_counted(70)
+    timer.synchronize()
+    total_run = time.perf_counter() - t0
+    est.close()
     npts = np.array([r[0] for r in rows]); wall = np.array([r[1] for r in rows]); k1 = np.array([r[2] for r in rows])
     first = np.r_[True, npts[1:] != npts[:-1]]
     coarse, finest = npts * 4 < n, npts == n
     def mean(mask, v):
         return float(v[mask].mean()) if mask.any() else None
-    return {"iterations": it, "converged": bool(conv), "total_ms": 1e3 * total, "levels": int(first.sum()),
+    return {"iterations": it, "converged": bool(conv), "total_ms": 1e3 * total, "run_call_ms": 1e3 * total_run, "run_call_iterations": it2,
+            "levels": int(first.sum()),
             "matched_pairs": int(2 * npts.sum()),
             "k1_ms_per_direction": {"coarse_levels": mean(coarse, k1), "dense_levels_first_search": mean(~coarse & first, k1),
                                     "dense_levels_later_searches": mean(~coarse & ~first & ~finest, k1),
