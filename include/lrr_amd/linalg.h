@@ -8,14 +8,22 @@
 #include <cmath>
 #include <cstring>
 
+// the same source also serves the device side of the batched location loop (lrr_icp_batch.inc: the solve of every
+// location without a host round trip): under hipcc the routines compile for both sides, and the variants ending in _ws
+// take their work arrays from the caller (LDS on the device; the plain names keep them on the stack)
+#if defined(__HIPCC__)
+#define LRR_LINALG_HD __host__ __device__
+#else
+#define LRR_LINALG_HD
+#endif
+
 namespace lrr_amd {
 namespace linalg {
 
 // inverse of a symmetric positive definite n x n matrix (n <= 12) by Cholesky factorisation:
 // A = L L^T, A^-1 = L^-T L^-1.  Returns false — and leaves `out` untouched — when a pivot shows the
 // matrix to be indefinite, singular or close to it (pivot below 1e-10 of its diagonal entry).
-inline bool chol_inverse(int n, const double *M, double *out) {
-  double L[144], Li[144];
+LRR_LINALG_HD inline bool chol_inverse_ws(int n, const double *M, double *out, double *L, double *Li) {
   for (int j = 0; j < n; ++j) {
     const double ajj = 0.5 * (M[j * n + j] + M[j * n + j]);
     double d = ajj;
@@ -47,15 +55,18 @@ inline bool chol_inverse(int n, const double *M, double *out) {
     }
   return true;
 }
+inline bool chol_inverse(int n, const double *M, double *out) {
+  double L[144], Li[144];
+  return chol_inverse_ws(n, M, out, L, Li);
+}
 
 // inverse of the symmetric n x n normal matrix (n <= 12), standing in for vnl_svd::inverse().
 // The well-conditioned positive definite case — every ICP iteration with enough matches — takes the
 // Cholesky route (2 us for n = 12); anything else goes through a cyclic-Jacobi eigen-decomposition
 // (27 us) where zero eigenvalues are left out, which is what vnl_svd::inverse() does with zero
 // singular values.
-inline void sym_inverse(int n, const double *M, double *out) {
-  if (chol_inverse(n, M, out)) return;
-  double A[144], V[144];
+LRR_LINALG_HD inline void sym_inverse_ws(int n, const double *M, double *out, double *A, double *V) {
+  if (chol_inverse_ws(n, M, out, A, V)) return;
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) {
       A[i * n + j] = 0.5 * (M[i * n + j] + M[j * n + i]);
@@ -102,11 +113,15 @@ inline void sym_inverse(int n, const double *M, double *out) {
       out[i * n + j] = s;
     }
 }
+inline void sym_inverse(int n, const double *M, double *out) {
+  double A[144], V[144];
+  sym_inverse_ws(n, M, out, A, V);
+}
 
 // one-sided Jacobi SVD of a 3x3 (row-major): M = U diag(s) V^T
-inline void svd3(const double *M, double *U, double *s, double *V) {
+LRR_LINALG_HD inline void svd3(const double *M, double *U, double *s, double *V) {
   double W[9];
-  std::memcpy(W, M, sizeof W);
+  for (int i = 0; i < 9; ++i) W[i] = M[i];
   for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 60; ++sweep) {
     bool rotated = false;
@@ -141,7 +156,7 @@ inline void svd3(const double *M, double *U, double *s, double *V) {
   }
 }
 
-inline void inverse3(const double *M, double *out) {
+LRR_LINALG_HD inline void inverse3(const double *M, double *out) {
   double U[9], s[3], V[9];
   svd3(M, U, s, V);
   for (int i = 0; i < 3; ++i)

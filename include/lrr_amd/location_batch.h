@@ -205,6 +205,7 @@ class rrl_location_batch {
   // uploads the two full volumes once (m_FeaturesMovingAll[0], m_FeaturesFixedAll[0]); they stay resident
   rrl_location_batch(vcl_vector<feature_sptr_type> const &moving_all, vcl_vector<feature_sptr_type> const &fixed_all)
       : batch_(nullptr), max_iterations_(70), min_features_(1000), diagnostics_(true), check_valid_(true),
+        device_loop_(std::getenv("LRR_BATCH_HOST_LOOP") == nullptr),
         voxel_spacing_(1.0), sample_interval_(5.0) {
     moving_.upload(moving_all);
     fixed_.upload(fixed_all);
@@ -218,6 +219,7 @@ class rrl_location_batch {
   void set_min_features(unsigned n) { min_features_ = n; }       // 1000 (:1632)
   void set_diagnostics(bool on) { diagnostics_ = on; }
   void set_check_valid_transform(bool on) { check_valid_ = on; } // `if (!validTransform(...)) break;` (:2482)
+  void set_device_loop(bool on) { device_loop_ = on; }           // false: the host half of every iteration on the host
   void set_sampling(double voxel_spacing, double interval) { voxel_spacing_ = voxel_spacing; sample_interval_ = interval; }
   lrr_icp_batch *handle() const { return batch_; }
 
@@ -266,8 +268,61 @@ class rrl_location_batch {
     opts.normalize = 1; opts.strength_f = 1; opts.strength_b = 1; opts.swapped = 0;
     std::vector<lrr_icp_sym_out> est(B);
     std::vector<double> sums(8 * B);
-    // the caller's loop, all locations in lockstep: one_iteration of every running location
-    // (rrl sym .txx:341-438)
+    if (device_loop_ && running > 0) {
+      // the caller's loop of every location on the device (lrr_icp_batch_iterate): the host half of estimate_LS and the
+      // convergence test run as kernels; what comes back is the schedule's outcome and the normal equations of the
+      // last estimate, from which the final transform and its covariance are rebuilt exactly as in the loop below
+      std::vector<lrr_icp_batch_start> start(B);
+      std::vector<lrr_icp_batch_final> fin(B);
+      for (size_t b = 0; b < B; ++b) {
+        std::memset(&start[b], 0, sizeof start[b]);
+        if (!st[b].running) continue;
+        start[b].run = 1;
+        start[b].xf_fwd = xform_of(st[b].F);
+        start[b].xf_bwd = xform_of(st[b].B);
+        start[b].rng_fwd = st[b].rng[0];
+        start[b].rng_bwd = st[b].rng[1];
+      }
+      tm.lap("host");
+      check(lrr_icp_batch_iterate(batch_, start.data(), max_iterations_, check_valid_ ? 1 : 0, fin.data()), "batch iterate");
+      tm.lap("iterate");
+      workers_.parallel_for(B, [&](size_t b) {
+        state &s = st[b];
+        if (!s.running) return;
+        const lrr_icp_batch_final &f = fin[b];
+        location_result &r = results[b];
+        s.running = false;
+        s.iteration = (unsigned)f.iterations;
+        // the lists hold the subsets of the last search; the schedule may have grown number_points_ after it
+        s.number_points[0] = (unsigned)f.searched_fwd; s.number_points[1] = (unsigned)f.searched_bwd;
+        s.rng[0] = f.rng_fwd; s.rng[1] = f.rng_bwd;
+        s.error_after = f.weighted_error;
+        s.rms = f.rms;
+        if (f.iterations > 0) {
+          s.scale_estimated[0] = s.scale_estimated[1] = true;
+          lrr_icp_sym_out &e = est[b];
+          std::memset(&e, 0, sizeof e);
+          e.norm = f.norm;
+          std::memcpy(e.AtA, f.AtA, sizeof e.AtA);
+          std::memcpy(e.Atb, f.Atb, sizeof e.Atb);
+          affine_forward_update(s.F, e);
+          s.B = s.F->inverse();
+        }
+        r.matched_pairs = f.matched_pairs;
+        r.initial_RMS = f.initial_rms;
+        r.valid_transform = f.valid_transform != 0;
+        r.converged = f.converged != 0;
+        r.oscillated = f.oscillated != 0;
+        r.iterations = (unsigned)f.iterations;
+        r.weighted_error = f.weighted_error;
+        r.RMS_error = f.rms;
+        r.forward = s.F->clone();
+      });
+      running = 0;
+      tm.lap("rebuild");
+    }
+    // the same loop with its host half on the host (set_device_loop(false) / LRR_BATCH_HOST_LOOP): all locations in
+    // lockstep, one_iteration of every running location (rrl sym .txx:341-438)
     while (running > 0) {
       for (size_t b = 0; b < B; ++b) {
         state &s = st[b];
@@ -455,7 +510,7 @@ class rrl_location_batch {
   lrr_icp_batch *batch_;
   host_workers workers_;
   unsigned max_iterations_, min_features_;
-  bool diagnostics_, check_valid_;
+  bool diagnostics_, check_valid_, device_loop_;
   double voxel_spacing_, sample_interval_;
 };
 

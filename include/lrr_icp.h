@@ -289,6 +289,30 @@ int  lrr_icp_batch_estimate(lrr_icp_batch *batch, const lrr_icp_batch_loc *loc, 
 int  lrr_icp_batch_errors(lrr_icp_batch *batch, const lrr_icp_batch_loc *loc, double *sums);
 /* sheet / tube angles of both lists: sums[b][dir] = {sheet sum w a, sheet sum w, tube sum w a, tube sum w} */
 int  lrr_icp_batch_angles(lrr_icp_batch *batch, const lrr_icp_batch_loc *loc, double *sums);
+/* The caller's loop for every location of the batch in one call (rrl/itkLocationRegistration.cxx:2418-2482: one_iteration
+ * until converged, max_iterations or an invalid transform), dof 12 / rrl flavour / affine transforms.  The first iteration
+ * runs through the calls above (MUSE); from its solve on, the host half of estimate_LS (solve, un-normalise, inverse:
+ * rrl sym .txx:880-912) and the convergence test with its schedule (rrl sym .txx:383-437) run as kernels over the
+ * per-location tables, so no result travels to the host between iterations.  fin[b] holds the schedule's outcome and the
+ * normal equations and normalisation of the last estimate: the caller rebuilds the final transform and its covariance
+ * from them exactly as after lrr_icp_batch_estimate. */
+typedef struct {
+  int32_t run;                       /* 0: the location is left alone (too few features) */
+  lrr_icp_xform xf_fwd, xf_bwd;      /* transforms at the start */
+  uint64_t rng_fwd, rng_bwd;         /* states of the subset-permutation generators (lrr_icp_perm_keys) */
+} lrr_icp_batch_start;
+typedef struct {
+  int32_t converged, oscillated, valid_transform, iterations;
+  int64_t matched_pairs;
+  int64_t n_fwd, n_bwd;              /* number_points_ of the two lists after the last schedule step ... */
+  int64_t searched_fwd, searched_bwd;/* ... and at the last search */
+  double initial_rms, rms, weighted_error;
+  double AtA[144], Atb[12];          /* normal equations of the last estimate (iterations > 0) */
+  lrr_icp_norm norm;                 /* and its normalisation */
+  uint64_t rng_fwd, rng_bwd;         /* generator states after the last search */
+} lrr_icp_batch_final;
+int  lrr_icp_batch_iterate(lrr_icp_batch *batch, const lrr_icp_batch_start *start, unsigned max_iterations, int check_valid,
+                           lrr_icp_batch_final *fin);
 int64_t lrr_icp_batch_num_matches(const lrr_icp_batch *batch, int64_t b, int dir);
 /* matches_ of location b: from = index in the ROI list, to = index in the full volume */
 int  lrr_icp_batch_get_matches(lrr_icp_batch *batch, int64_t b, int dir, int64_t *from_idx, int64_t *to_idx, double *w);

@@ -36,7 +36,7 @@ ICP_SYMBOLS = [
     "lrr_icp_nearest", "lrr_icp_cloud_set_covariances", "lrr_icp_cdc_compute_weights",
     "lrr_icp_cdc_set_create", "lrr_icp_cdc_set_destroy", "lrr_icp_cdc_set_compute_weights", "lrr_icp_cdc_set_get", "lrr_icp_cdc_objective_par", "lrr_icp_cdc_objective_cov", "lrr_icp_cdc_normalize_stats",
     "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
-    "lrr_icp_batch_match", "lrr_icp_batch_estimate", "lrr_icp_batch_errors", "lrr_icp_batch_angles",
+    "lrr_icp_batch_match", "lrr_icp_batch_estimate", "lrr_icp_batch_errors", "lrr_icp_batch_angles", "lrr_icp_batch_iterate",
     "lrr_icp_batch_num_matches", "lrr_icp_batch_get_matches",
 ]
 

@@ -184,6 +184,41 @@ def test_batch_is_deterministic(E):
     bt.close()
 
 
+def test_device_loop_equals_host_loop(E, monkeypatch):
+    """lrr_icp_batch_iterate (solve, inverse, convergence test and schedule as kernels) against the same loop with its
+    host half on the host.  With the host's SVD-based 3x3 inverse on the device too (LRR_BATCH_SVD_INVERSE) the device
+    routines are the host's (linalg.h, same operations in the same order) and every result row is bit-equal, with and
+    without the validTransform test; with the adjugate inverse (the default) the backward transform of a search differs
+    in the last bits: same iteration counts, results equal to 1e-9"""
+    pair, rois, inits, mbox, fbox, seeds = _setup(40000, 5, 20252, 50.0)
+    A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
+    A0[3] *= 1.6  # a start far enough off to exercise the oscillation counters
+    C = E.LocationBatch.COL
+
+    def run(check_valid):
+        bt = E.LocationBatch(pair.moving, pair.fixed)
+        rows = bt.run(A0, t0, c0, mbox, fbox, seeds, diagnostics=True, check_valid=check_valid)
+        bt.close()
+        return rows
+
+    for check_valid in (False, True):
+        fast = run(check_valid)
+        monkeypatch.setenv("LRR_BATCH_SVD_INVERSE", "1")
+        dev = run(check_valid)
+        monkeypatch.delenv("LRR_BATCH_SVD_INVERSE")
+        monkeypatch.setenv("LRR_BATCH_HOST_LOOP", "1")
+        host = run(check_valid)
+        monkeypatch.delenv("LRR_BATCH_HOST_LOOP")
+        assert (host[:, C["iterations"]] > 3).all()
+        assert np.array_equal(dev, host, equal_nan=True)
+        assert np.array_equal(fast[:, C["iterations"]], host[:, C["iterations"]])
+        assert np.array_equal(fast[:, C["converged"]], host[:, C["converged"]])
+        assert np.array_equal(fast[:, C["matched_pairs"]], host[:, C["matched_pairs"]])
+        for name in ("A", "t", "weighted_error", "rms"):
+            a, h = fast[:, C[name]], host[:, C[name]]
+            assert np.abs(a - h).max() <= 1e-9 * max(1.0, np.abs(h).max()), name
+
+
 def _rank_worker(rank, world, port, out_dir):
     """one rank of a 2-rank job on ONE GPU (gloo rendezvous and gather on the CPU; the ranks share cuda:0)"""
     import os
