@@ -1400,6 +1400,13 @@ int64_t lrr_icp_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]) {
 }
 
 // what one K1 submission needs after its arguments have been checked
+// Subsets the thread-per-SOURCE kernels serve (every source inverts the keyed permutation for itself; both directions in
+// one launch): a quarter of the cloud or more, and — above what the coarse pair path takes — an eighth: a source without
+// a previous match is bounded by a point of its own cell (ball_search), so a grown subset needs no search from scratch,
+// and the thread-per-slot path it would take otherwise forks and joins two streams (32000 of 200k: 72 -> 45 us per direction).
+constexpr int64_t kCoarseMax = 16384;
+inline bool dense_level(int64_t n_points, int64_t N) { return n_points * 4 >= N || (n_points > kCoarseMax && n_points * 8 >= N); }
+
 struct MatchPrep {
   Keys kk;
   int half = 1;
@@ -1475,7 +1482,7 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   P.g = P.voronoi ? view_of_voronoi(d->to) : view_of(d->to);
   P.q.src = d->from->src; P.q.raw = nullptr; P.q.want_orig = 0; P.q.pidx = nullptr; P.q.bloc = nullptr; P.q.loc_of = nullptr; P.q.dir = 0;
   P.x = to_dev(xf);
-  P.dense = !order && n_points * 4 >= N && !P.voronoi;  // fine levels: every source feature is looked at
+  P.dense = !order && dense_level(n_points, N) && !P.voronoi;  // fine levels: every source feature is looked at
   if ((rc = fresh_counts(ctx, L, st, &P.counts))) return rc;
   // a level's later iterations: every active source carries its previous match -> ball search
   // ... and so does the first search after a dense level has grown: the sources of the old subset carry a match (any
@@ -1607,7 +1614,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
   // Later iterations of a level (both directions in the ball-search state): every phase handles both
   // directions in ONE launch on the main stream (blockIdx.y = direction) — no fork/join at all.
   const bool both_steady = method != LRR_ICP_NN_BRUTE && method != LRR_ICP_NN_VORONOI && !order_f && !order_b && n_f > 0 && n_b > 0 &&
-                           n_f * 4 >= f->from->n && n_b * 4 >= b->from->n && f->searches > 0 && b->searches > 0;
+                           dense_level(n_f, f->from->n) && dense_level(n_b, b->from->n) && f->searches > 0 && b->searches > 0;
   if (both_steady) {
     MatchPrep Pf, Pb;
     hipStream_t st = ctx->stream;
@@ -1676,7 +1683,6 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
   // Coarse levels (both subsets sparse and small, keyed permutations): one stream, three launches for both directions
   // — list positions + work lists, wave-per-query search (around the previous match where there is one), brute force
   // for what is left.
-  constexpr int64_t kCoarseMax = 16384;
   if ((method == LRR_ICP_NN_GRID || method == LRR_ICP_NN_AUTO) && !order_f && !order_b && keys_f && keys_b && n_f > 0 && n_b > 0 &&
       n_f * 4 < f->from->n && n_b * 4 < b->from->n && n_f <= kCoarseMax && n_b <= kCoarseMax && std::getenv("LRR_ICP_NO_COARSE_PAIR") == nullptr) {
     MatchPrep Pf, Pb;

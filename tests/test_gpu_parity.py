@@ -180,8 +180,13 @@ def test_forward_run_matches_oracle_config1(E, ob, kind_name, dof):
     pair = synth.make_pair(5000, 5000, 20241, kind="rigid" if dof == 6 else "affine")
     ident = synth.Transform(np.eye(3), np.zeros(3), np.zeros(3))
     g, c = _both(E, ob, getattr(E, kind_name), dof, pair, ident, 11, False)
+    timer = E.DeviceTimer()
+    timer.k1_path_counts(reset=True)
     rg, rc = g.run(30), c.run(30)
     assert rg == rc, "converged flag / iteration count"
+    # a forward class's coarse level (1000 of 5000 points) goes through the thread-per-slot kernel (k_match_direct): the ball
+    # search bounded by an earlier match of the slot's source or by a point of its own cell
+    assert timer.k1_path_counts()["direct"] > 0, timer.k1_path_counts()
     assert np.array_equal(g.matches(0)[1], c.matches(0)[1])
     Ag, tg, _, _ = g.get_transform()
     Ac, tc, _, _ = c.get_transform()
@@ -547,12 +552,13 @@ def test_full_size_200k_schedule_against_oracle(E, ob, kind_name):
     assert at_finest >= 8 and g.number_points(0) == n and c.number_points(0) == n
     assert abs(g.weighted_error(0) - c.weighted_error(0)) <= 1e-9 * max(1.0, c.weighted_error(0))
     # every state of the grid matcher served searches of this run (and every one of them was compared above): the
-    # coarse pair path, the ring search of the 32k level, ball searches of settled and of freshly grown levels, the
+    # coarse pair path, ball searches of settled and of freshly grown levels (from the 32k level on), the
     # certificate with its separate list kernels (the tile kernel serves a first-ever dense search: the tests that
-    # start at the full level)
+    # start at the full level; the thread-per-slot kernel a forward class's coarse levels:
+    # test_forward_run_matches_oracle_config1)
     # (the certificate kernel that searches its own failures: see test_symmetric_full_schedule_matches_oracle)
     paths = timer.k1_path_counts()
-    for name in ("coarse_pair", "direct", "ball", "ball_growth", "cert"):
+    for name in ("coarse_pair", "ball", "ball_growth", "cert"):
         assert paths[name] > 0, paths  # (cert_inline needs lists <= 512: test_symmetric_full_schedule_matches_oracle)
     g.close()
 
