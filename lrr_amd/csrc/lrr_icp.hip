@@ -58,7 +58,6 @@ constexpr int kMaxRed = 96;          // max doubles reduced per pass (78 + 12 fo
 constexpr int kRecStride = 10;       // feature record: x y z pxx pxy pxz pyy pyz pzz strength
 constexpr int kTile = 8;             // canonical order: tiles of kTile^3 grid cells
 constexpr int kScanUnroll = 8;       // candidate loads in flight per lane in the global-memory grid search
-constexpr int kEasyBudget = 48;      // candidate points a lane may scan in the thread-per-query global search
 constexpr int kRingMax = 8;          // rings walked by the wave-per-query phase before the brute-force fallback
 constexpr int kTileBudget = 48;      // candidates a lane may scan from LDS before handing its query over
 constexpr int kTileCap = 2048;       // target points a block may stage in LDS (64 KB) ...
