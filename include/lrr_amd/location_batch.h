@@ -127,13 +127,14 @@ inline double sampled_transfer_max_trace(cdcl_trans<3, 12>::sptr const &T, vnl_v
 // independent across locations) spread over a few sleeping worker threads: parallel_for(n, f) runs f(i) for every i
 // exactly once, in chunks handed out through an atomic counter, the caller working along.  Workers block on a
 // condition variable between calls (no spinning: the device runtime's own threads share the cores).
-// LRR_BATCH_THREADS sets the number of workers (default: up to 6, fewer on small machines; 0 = caller only).
+// LRR_BATCH_THREADS sets the number of workers (default: 9 on machines with 16 or more hardware threads, else up to 6, fewer
+// on small machines; 0 = caller only).
 class host_workers {
  public:
   host_workers() : stop_(false), generation_(0), n_(0), chunk_(1), next_(0), pending_(0) {
-    unsigned want = 6;
     const unsigned hw = std::thread::hardware_concurrency();
-    if (hw && hw / 2 < want + 1) want = hw / 2 > 0 ? hw / 2 - 1 : 0;
+    unsigned want = hw >= 16 ? 9 : 6;  // (the device runtime's threads keep the rest)
+    if (hw && hw / 2 < want + 1 && hw < 16) want = hw / 2 > 0 ? hw / 2 - 1 : 0;
     if (const char *e = std::getenv("LRR_BATCH_THREADS")) want = (unsigned)std::max(0, std::atoi(e));
     for (unsigned t = 0; t < want; ++t) threads_.emplace_back([this] { work(); });
   }
@@ -252,9 +253,7 @@ class rrl_location_batch {
       std::memset(&loc[b], 0, sizeof loc[b]);
       if (!s.running) continue;
       ++running;
-      // SetupEstimation: set_features + set_transform (:1635-1637; rrl sym .txx:268-315)
-      s.F = queries[b].transform->clone();
-      s.B = s.F->inverse();
+      // SetupEstimation: set_features + set_transform (:1635-1637; rrl sym .txx:268-315); the transforms follow below
       s.N[0] = (unsigned)nm[b]; s.N[1] = (unsigned)nf[b];
       for (int d = 0; d < 2; ++d) { s.number_points[d] = std::min(1000u, s.N[d]); s.scale_estimated[d] = false; }
       s.rng[0] = queries[b].seed;
@@ -263,6 +262,12 @@ class rrl_location_batch {
       s.error_after = 0.0;  // weighted_error() of a list without matches
       s.iteration = 0;
     }
+
+    workers_.parallel_for(B, [&](size_t b) {  // (the inverse is a 3 x 3 SVD: microseconds each, independent)
+      if (!st[b].running) return;
+      st[b].F = queries[b].transform->clone();
+      st[b].B = st[b].F->inverse();
+    });
 
     lrr_icp_batch_opts opts;
     opts.normalize = 1; opts.strength_f = 1; opts.strength_b = 1; opts.swapped = 0;
@@ -379,8 +384,7 @@ class rrl_location_batch {
       }
     }
     tm.lap("host");
-    if (diagnostics_) decision_measurements(queries, st, loc, results, est, sums);
-    tm.lap("diagnostics");
+    if (diagnostics_) decision_measurements(queries, st, loc, results, est, sums, tm);
     tm.report(B);
     for (size_t b = 0; b < B; ++b)
       if (results[b].enough_features && st[b].B) results[b].backward = st[b].B;
@@ -452,7 +456,7 @@ class rrl_location_batch {
   // ComputeDecisionMeasurements (:1816-1871) of every location that ran: forward angles and error, then
   // estimate_LS_backward(false) (sets the backward covariance, re-weights both lists), then the backward ones
   void decision_measurements(std::vector<location_query> const &queries, std::vector<state> &st, std::vector<lrr_icp_batch_loc> &loc,
-                             std::vector<location_result> &results, std::vector<lrr_icp_sym_out> &est, std::vector<double> &sums) {
+                             std::vector<location_result> &results, std::vector<lrr_icp_sym_out> &est, std::vector<double> &sums, phase_timer &tm) {
     const size_t B = st.size();
     bool any = false;
     for (size_t b = 0; b < B; ++b) {
@@ -462,6 +466,7 @@ class rrl_location_batch {
     if (!any) return;
     const double deg = 180.0 / 3.14159265358979323846;
     check(lrr_icp_batch_angles(batch_, loc.data(), sums.data()), "batch angles");
+    tm.lap("angles");
     for (size_t b = 0; b < B; ++b)
       if (loc[b].active) {
         const double *a = &sums[8 * b];
@@ -474,14 +479,17 @@ class rrl_location_batch {
     for (size_t b = 0; b < B; ++b)
       if (loc[b].active) { loc[b].scale_mode_f = loc[b].scale_mode_b = LRR_ICP_SCALE_RMS; }
     check(lrr_icp_batch_estimate(batch_, loc.data(), &opts, est.data()), "batch backward estimate");
+    tm.lap("backward estimate");
     workers_.parallel_for(B, [&](size_t b) {
       if (!loc[b].active) return;
       symmetric_apply_solution<dof>(st[b].B, st[b].F, est[b], true, false);
       fill_loc(loc[b], st[b]);
     });
+    tm.lap("apply");
     check(lrr_icp_batch_angles(batch_, loc.data(), sums.data()), "batch angles");
     std::vector<double> esums(6 * B);
     check(lrr_icp_batch_errors(batch_, loc.data(), esums.data()), "batch error metrics");
+    tm.lap("angles + errors");
     workers_.parallel_for(B, [&](size_t b) {
       if (!loc[b].active) return;
       location_result &r = results[b];
@@ -504,6 +512,7 @@ class rrl_location_batch {
       r.measurements[6] = std::min(sa, sab);
       r.measurements[7] = std::min(ta, tab);
     });
+    tm.lap("measurements");
   }
 
   device_cloud<FeatureT> moving_, fixed_;
