@@ -224,6 +224,36 @@ def test_device_loop_equals_host_loop(E, monkeypatch):
             assert np.abs(a - h).max() <= 1e-9 * max(1.0, np.abs(h).max()), name
 
 
+def test_device_loop_many_locations(E, monkeypatch):
+    """300 locations in one batch (more than one round of the per-location kernels; every fifth ROI holds fewer than
+    1000 features and never runs, the rest converge at different iterations, so the chain of launches runs with a
+    shrinking set of locations): device loop with the host's inverse == host loop, row for row"""
+    pair, rois, inits, mbox, fbox, seeds = _setup(60000, 300, 20253, 35.0)
+    A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
+    C = E.LocationBatch.COL
+    for bx in (mbox, fbox):  # every fifth location: a box of 8 mm, too few features to run
+        mid = 0.5 * (bx[::5, :3] + bx[::5, 3:])
+        bx[::5, :3], bx[::5, 3:] = mid - 4.0, mid + 4.0
+
+    def run():
+        bt = E.LocationBatch(pair.moving, pair.fixed)
+        rows = bt.run(A0, t0, c0, mbox, fbox, seeds, diagnostics=False)
+        bt.close()
+        return rows
+
+    monkeypatch.setenv("LRR_BATCH_SVD_INVERSE", "1")
+    dev = run()
+    monkeypatch.delenv("LRR_BATCH_SVD_INVERSE")
+    monkeypatch.setenv("LRR_BATCH_HOST_LOOP", "1")
+    host = run()
+    monkeypatch.delenv("LRR_BATCH_HOST_LOOP")
+    ran = host[:, C["enough_features"]] > 0
+    assert 20 < ran.sum() and (~ran).sum() > 0, ran.sum()
+    its = host[ran, C["iterations"]]
+    assert its.min() >= 1 and np.unique(its).size >= 4  # locations stop at different iterations
+    assert np.array_equal(dev, host, equal_nan=True)
+
+
 def _rank_worker(rank, world, port, out_dir):
     """one rank of a 2-rank job on ONE GPU (gloo rendezvous and gather on the CPU; the ranks share cuda:0)"""
     import os
