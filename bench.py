@@ -133,7 +133,8 @@ def code_stamp():
     (.git does not travel to the GPU box)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("lrr_icp.hip", "lrr_icp_k1.inc", "lrr_icp_passes.inc", "lrr_icp_fused.inc", "lrr_icp_grid.inc", "lrr_icp_batch.inc", "lrr_icp_cdc.inc"):
+    for f in ("lrr_icp.hip", "lrr_icp_k1.inc", "lrr_icp_solve.inc", "lrr_icp_passes.inc", "lrr_icp_fused.inc", "lrr_icp_grid.inc", "lrr_icp_batch.inc",
+              "lrr_icp_cdc.inc"):
         with open(os.path.join(ROOT, "lrr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

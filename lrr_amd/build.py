@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 INC = os.path.join(ROOT, "include")
 HIP_SRC = os.path.join(HERE, "csrc", "lrr_icp.hip")
-HIP_INCS = [os.path.join(HERE, "csrc", f) for f in ("lrr_icp_k1.inc", "lrr_icp_passes.inc", "lrr_icp_fused.inc", "lrr_icp_grid.inc",
+HIP_INCS = [os.path.join(HERE, "csrc", f) for f in ("lrr_icp_k1.inc", "lrr_icp_solve.inc", "lrr_icp_passes.inc", "lrr_icp_fused.inc", "lrr_icp_grid.inc",
                                                   "lrr_icp_batch.inc", "lrr_icp_cdc.inc")]  # sections of the one translation unit
 HIP_SO = os.path.join(HERE, "liblrr_icp_hip.so")
 EST_SRC = os.path.join(HERE, "csrc", "lrr_est_capi.cpp")

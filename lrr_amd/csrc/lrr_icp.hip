@@ -537,6 +537,7 @@ __device__ __forceinline__ bool ring_settled(double lb, double tol, double bd) {
 }
 
 #include "lrr_icp_k1.inc"
+#include "lrr_icp_solve.inc"
 #include "lrr_icp_passes.inc"
 #include "lrr_icp_fused.inc"
 #include "lrr_icp_grid.inc"
