@@ -191,10 +191,11 @@ def test_batch_is_deterministic(E):
 
 def test_device_loop_equals_host_loop(E, monkeypatch):
     """lrr_icp_batch_iterate (solve, inverse, convergence test and schedule as kernels) against the same loop with its
-    host half on the host.  With the host's SVD-based 3x3 inverse on the device too (LRR_BATCH_SVD_INVERSE) the device
-    routines are the host's (linalg.h, same operations in the same order) and every result row is bit-equal, with and
-    without the validTransform test; with the adjugate inverse (the default) the backward transform of a search differs
-    in the last bits: same iteration counts, results equal to 1e-9"""
+    host half on the host.  With the host's SVD-based 3x3 inverse on the device too (LRR_BATCH_SVD_INVERSE) and the first
+    estimate's MUSE through the step-wise path (LRR_BATCH_HOST_MUSE) the device routines are the host's (linalg.h, same
+    operations in the same order) and every result row is bit-equal, with and without the validTransform test; by default
+    (adjugate inverse; MUSE from a sort and a prefix sum on the device) the backward transform of a search and the first
+    scale differ in the last bits: same iteration counts, results equal to 1e-9"""
     pair, rois, inits, mbox, fbox, seeds = _setup(40000, 5, 20252, 50.0)
     A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
     A0[3] *= 1.6  # a start far enough off to exercise the oscillation counters
@@ -209,8 +210,10 @@ def test_device_loop_equals_host_loop(E, monkeypatch):
     for check_valid in (False, True):
         fast = run(check_valid)
         monkeypatch.setenv("LRR_BATCH_SVD_INVERSE", "1")
+        monkeypatch.setenv("LRR_BATCH_HOST_MUSE", "1")  # (the first estimate's MUSE through the step-wise path, as in the host loop)
         dev = run(check_valid)
         monkeypatch.delenv("LRR_BATCH_SVD_INVERSE")
+        monkeypatch.delenv("LRR_BATCH_HOST_MUSE")
         monkeypatch.setenv("LRR_BATCH_HOST_LOOP", "1")
         host = run(check_valid)
         monkeypatch.delenv("LRR_BATCH_HOST_LOOP")
@@ -242,8 +245,10 @@ def test_device_loop_many_locations(E, monkeypatch):
         return rows
 
     monkeypatch.setenv("LRR_BATCH_SVD_INVERSE", "1")
+    monkeypatch.setenv("LRR_BATCH_HOST_MUSE", "1")
     dev = run()
     monkeypatch.delenv("LRR_BATCH_SVD_INVERSE")
+    monkeypatch.delenv("LRR_BATCH_HOST_MUSE")
     monkeypatch.setenv("LRR_BATCH_HOST_LOOP", "1")
     host = run()
     monkeypatch.delenv("LRR_BATCH_HOST_LOOP")
