@@ -39,14 +39,16 @@ def _setup(n, nloc, seed, half):
     return pair, rois, inits, mbox, fbox, seeds
 
 
-@pytest.mark.parametrize("stream", [False, True])
-def test_device_roi_selection_equals_numpy(E, monkeypatch, stream):
+@pytest.mark.parametrize("form", ["grid", "grid_global_bits", "stream"])
+def test_device_roi_selection_equals_numpy(E, monkeypatch, form):
     """FeaturesInROIs on the device: every location's two ROI lists equal numpy's box test, in the
     volume's original order; boxes that hold nothing, everything, and features exactly on a face.  Both forms of
     the selection: through the volume's search grid (default) and by streaming the volume (LRR_BATCH_ROI_STREAM);
     the whole result rows (one iteration on the selected lists) are the same"""
-    if stream:
+    if form == "stream":
         monkeypatch.setenv("LRR_BATCH_ROI_STREAM", "1")
+    if form == "grid_global_bits":  # (the bit maps in global scratch memory: the form volumes too large for LDS take)
+        monkeypatch.setenv("LRR_BATCH_ROI_GLOBAL_BITS", "1")
     pair, rois, inits, mbox, fbox, seeds = _setup(30000, 5, 20250, 40.0)
     # extra boxes: empty, whole volume, a face through a feature (inclusive on both ends)
     p = pair.moving.loc[123]

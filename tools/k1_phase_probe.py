@@ -27,3 +27,4 @@ print(json.dumps({n: v[i] for i, n in enumerate(names)}, indent=1))
 print("per active lane: loads+perm %.0f  search %.0f (bound %.0f rows %.0f cand %.0f) cycles; rows %.1f candidates %.1f" % (
     v[1] / v[10], v[2] / v[10], v[4] / v[10], v[5] / v[10], v[6] / v[10], v[7] / v[10], v[8] / v[10]))
 print("per inactive lane: %.0f cycles" % (v[0] / max(v[9], 1)))
+print("ROI fill, per workgroup: zero %.0f  mark %.0f  prefix %.0f  emit %.0f cycles (%d workgroups)" % (v[11] / max(v[15], 1), v[12] / max(v[15], 1), v[13] / max(v[15], 1), v[14] / max(v[15], 1), int(v[15])))
