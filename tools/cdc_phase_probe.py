@@ -23,7 +23,7 @@ cm.set_covariances(mv.cov)
 cf.set_covariances(fx.cov)
 S = E.CdcSet(cm, cf, max_matches=100)
 S.compute_weights(12, T.A, T.t, T.c, Ct, seed=1)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 lib.lrr_icp_debug_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.lrr_icp_debug_prof(out, 1)
 S.compute_weights(12, T.A, T.t, T.c, Ct, seed=2)

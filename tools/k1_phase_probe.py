@@ -15,7 +15,7 @@ rois = synth.query_rois(pair, 256, 20245, half=25.0)
 inits = [synth.perturbed(pair.planted, 100 + i) for i in range(len(rois))]
 batch = E.LocationBatch(pair.moving, pair.fixed)
 locations.register_locations(pair, rois[:4], inits, 0, 1, batch=batch)
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 lib.lrr_icp_debug_prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 lib.lrr_icp_debug_prof(out, 1)
 locations.register_locations(pair, rois, inits, 0, 1, batch=batch)
@@ -27,4 +27,5 @@ print(json.dumps({n: v[i] for i, n in enumerate(names)}, indent=1))
 print("per active lane: loads+perm %.0f  search %.0f (bound %.0f rows %.0f cand %.0f) cycles; rows %.1f candidates %.1f" % (
     v[1] / v[10], v[2] / v[10], v[4] / v[10], v[5] / v[10], v[6] / v[10], v[7] / v[10], v[8] / v[10]))
 print("per inactive lane: %.0f cycles" % (v[0] / max(v[9], 1)))
-print("ROI fill, per workgroup: zero %.0f  mark %.0f  prefix %.0f  emit %.0f cycles (%d workgroups)" % (v[11] / max(v[15], 1), v[12] / max(v[15], 1), v[13] / max(v[15], 1), v[14] / max(v[15], 1), int(v[15])))
+print("residual pass, per wavefront: loop %.0f  block sum %.0f cycles (%d wavefronts)" % (v[21] / max(v[23], 1), v[22] / max(v[23], 1), int(v[23])))
+print("ROI fill, per workgroup: zero %.0f  mark %.0f  prefix %.0f  emit %.0f cycles (%d workgroups)" % (v[16] / max(v[20], 1), v[17] / max(v[20], 1), v[18] / max(v[20], 1), v[19] / max(v[20], 1), int(v[20])))
