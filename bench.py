@@ -226,7 +226,10 @@ def bench_locations(args, rank, local_rank, world):
                                                               device_index=local_rank, estimators=ests)
     else:
         batch = E.LocationBatch(pair.moving, pair.fixed)  # the two volumes resident before timing
-        locations.register_locations(pair, rois[:4], inits, 0, 1, batch=batch)  # warm-up: libraries, kernels, buffers
+        # warm-up: libraries and kernels, then the rank's own block once so that every buffer has its final size (the first
+        # full run otherwise pays the allocations: 13 against 10 ms)
+        locations.register_locations(pair, rois[:4], inits, 0, 1, batch=batch)
+        locations.register_locations(pair, rois, inits, rank, world, gather_device=dev, batch=batch)
         run = lambda: locations.register_locations(pair, rois, inits, rank, world, gather_device=dev, batch=batch)
     for _ in range(reps):
         if world > 1:
