@@ -5,6 +5,7 @@
 // cdcl_feature_* objects from flat arrays, instantiates the four classes at <3,6> and <3,12>
 // and forwards the reference's method names one to one.  No arithmetic of the hot path lives
 // here.
+#include <chrono>
 #include <cstring>
 #include <exception>
 #include <memory>
@@ -387,6 +388,8 @@ int lrr_est_batch_run(lrr_est_batch *bt, int64_t B, const double *A0, const doub
                       const double *fixed_box, const uint64_t *seeds, unsigned max_iterations, int diagnostics, int check_valid,
                       double *rows) {
   return guard([&] {
+    const bool timing = std::getenv("LRR_BATCH_TIMING") != nullptr;
+    const auto w0 = std::chrono::steady_clock::now();
     std::vector<lrr_amd::location_query> q((size_t)B);
     for (int64_t b = 0; b < B; ++b) {
       q[(size_t)b].transform = trans_factory<12>::make(A0 + 9 * b, t0 + 3 * b, c0 + 3 * b);
@@ -400,7 +403,9 @@ int lrr_est_batch_run(lrr_est_batch *bt, int64_t B, const double *A0, const doub
     BT(bt)->set_diagnostics(diagnostics != 0);
     BT(bt)->set_check_valid_transform(check_valid != 0);
     std::vector<lrr_amd::location_result> res;
+    const auto w1 = std::chrono::steady_clock::now();
     BT(bt)->run(q, res);
+    const auto w2 = std::chrono::steady_clock::now();
     for (int64_t b = 0; b < B; ++b) {
       double *r = rows + (size_t)b * LRR_EST_BATCH_ROW;
       const lrr_amd::location_result &R = res[(size_t)b];
@@ -413,6 +418,11 @@ int lrr_est_batch_run(lrr_est_batch *bt, int64_t B, const double *A0, const doub
       for (int k = 0; k < 8; ++k) r[32 + k] = R.measurements[k];
       if (R.forward) read_trans<12>(R.forward, r + 2, r + 11, r + 14, r + 55);
       if (R.backward) read_trans<12>(R.backward, r + 40, r + 49, r + 52, r + 199);
+    }
+    if (timing) {
+      const auto w3 = std::chrono::steady_clock::now();
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      std::fprintf(stderr, "[lrr batch wrapper] queries %.2f ms run %.2f ms rows %.2f ms\n", ms(w0, w1), ms(w1, w2), ms(w2, w3));
     }
   });
 }
