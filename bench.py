@@ -416,7 +416,7 @@ def main():
     times = []
     # K1's launch duration is taken live with HIP events, on the stream that runs it, around every k1_sample-th K1
     # submission of the timed region (each timed submission costs two event records on the critical path)
-    k1_sample = int(os.environ.get("LRR_BENCH_K1_SAMPLE", "8"))
+    k1_sample = int(os.environ.get("LRR_BENCH_K1_SAMPLE", "32"))  # (every 8th submission costs 2.6 % of `value`, every one 5-8 %)
     timer.match_profile(enable=k1_sample, reset=True)
     timer.cert_stats(reset=True)
     for _ in range(reps):
