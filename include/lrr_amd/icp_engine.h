@@ -656,6 +656,7 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     iterations_run_ = 0;
     state_version_ = 1;
     err_version_ = 0;
+    err_queued_version_ = 0;
     for (unsigned i = 0; i < dof * dof; ++i) last_AtA_[i] = 0.0;
     for (unsigned i = 0; i < dof; ++i) last_Atb_[i] = 0.0;
   }
@@ -685,10 +686,24 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
       s2 = err_sums_[0]; swr = err_sums_[1]; sw = err_sums_[2];
       return;
     }
-    check(lrr_icp_errors(dir_, &xf, &s2, &swr, &sw), "error metrics");
+    if (err_queued_version_ == state_version_ && std::memcmp(&xf, &err_queued_xf_, sizeof xf) == 0) {
+      check(lrr_icp_errors_collect(dir_, &s2, &swr, &sw), "error metrics");  // queued by prefetch_errors()
+    } else {
+      check(lrr_icp_errors(dir_, &xf, &s2, &swr, &sw), "error metrics");
+    }
+    err_queued_version_ = 0;
     err_version_ = state_version_;
     err_xf_ = xf;
     err_sums_[0] = s2; err_sums_[1] = swr; err_sums_[2] = sw;
+  }
+  // queues the error pass for the current transform and state without waiting for it: errors() collects it if nothing
+  // has changed by then (the symmetric estimate queues it before it inverts the new forward transform on the host)
+  void prefetch_errors() {
+    lrr_icp_xform xf = xform_of(trans_);
+    if (err_version_ == state_version_ && std::memcmp(&xf, &err_xf_, sizeof xf) == 0) return;
+    check(lrr_icp_errors_launch(dir_, &xf), "error metrics");
+    err_queued_version_ = state_version_;
+    err_queued_xf_ = xf;
   }
   void touch() { ++state_version_; matches_dirty_ = true; }
   void accumulate(trans_sptr_type const &jac_trans, int flags, double *AtA, double *Atb) {
@@ -762,8 +777,8 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
   std::vector<int64_t> explicit_order_;
   unsigned iterations_run_;
   double last_AtA_[dof * dof], last_Atb_[dof];
-  uint64_t state_version_, err_version_;
-  lrr_icp_xform err_xf_;
+  uint64_t state_version_, err_version_, err_queued_version_;
+  lrr_icp_xform err_xf_, err_queued_xf_;
   double err_sums_[3];
 };
 
@@ -896,6 +911,8 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     for (unsigned i = 0; i < dof; ++i) F.last_Atb_[i] = r.Atb[i];
     symmetric_apply_solution<dof>(F.trans_, B.trans_, r, normalize_matches_, estimate_parameters, estimate_parameters);
     if (rigid) F.end_rigid_increment(forward_global);
+    // the iteration asks for the forward list's weighted error next: its pass runs while the host inverts the transform
+    if (estimate_parameters && !rigid) F.prefetch_errors();
     if (estimate_parameters) B.trans_ = F.trans_->inverse();
   }
   // rrl: swap forward_/backward_, estimate_LS, swap back (rrl sym .txx:921-934).
