@@ -119,12 +119,14 @@ class cdcl_lbfgs {
     n_ = (int)x.size();
     std::vector<double> v((size_t)n_);
     for (int i = 0; i < n_; ++i) v[(size_t)i] = x[(unsigned)i];
-    res_ = lrr_lbfgs_minimize(n_, v.data(), &cdcl_lbfgs::thunk, this, max_evals_);
+    // (cdcl/cdcl_lbfgs.h:28-36: report_iter() ends the minimisation once the objective has changed by 5 % of its start value)
+    res_ = lrr_lbfgs_minimize_stop(n_, v.data(), &cdcl_lbfgs::thunk, this, max_evals_, LRR_CDCL_LBFGS_STOP_FRACTION);
     if (res_.code > 0) for (int i = 0; i < n_; ++i) x[(unsigned)i] = v[(size_t)i];
     return res_.code == LRR_LBFGS_CONVERGED;
   }
   double get_start_error() const { return res_.f_start; }
   double get_end_error() const { return res_.f_end; }
+  double obj_fun_change() const { return std::fabs(res_.f_start - res_.f_end); }  // (cdcl/cdcl_lbfgs.h:25)
   int get_failure_code() const { return res_.code; }
   int get_num_evaluations() const { return res_.evals; }
 
@@ -194,7 +196,12 @@ class cdcl_estimation_em {
     // upper triangular Cholesky factor of the covariance -> x (:283-293)
     double C[dof * dof], U[dof * dof];
     covariance(C);
-    if (!chol_upper(C, U)) throw std::runtime_error("cdcl_estimation_em: the parameter covariance is not positive definite");
+    if (!chol_upper(C, U)) {
+      // (the reference's vnl_cholesky runs in quiet mode and carries on with whatever it produced; here the estimate fails —
+      // after the transform has been put back into un-normalised coordinates, so the caller's object stays usable)
+      unnormalize(nm);
+      throw std::runtime_error("cdcl_estimation_em: the parameter covariance is not positive definite");
+    }
     vnl_vector<double> x(cov_dof, 0.0);
     unsigned ind = 0;
     for (unsigned d1 = 0; d1 < dof; ++d1) for (unsigned d2 = d1; d2 < dof; ++d2) x[ind++] = U[d1 * dof + d2];

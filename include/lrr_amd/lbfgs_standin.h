@@ -3,7 +3,8 @@
  * absent here, "parity unpinned").  It is NOT a restatement of that routine: same family (two-loop recursion over the
  * last m = 5 curvature pairs, initial step 1 / |g|, Armijo backtracking), same contract as the caller uses it
  * (cdcl/cdcl_estimation.txx:230-248, 298-311): a cap on function evaluations, the function value at the start and at the
- * end, and a return code that is negative only when no descent step was found at all.
+ * end, a return code that is negative only when no descent step was found at all, and (lrr_lbfgs_minimize_stop) the 5 %
+ * stopping rule that is the one thing cdcl_lbfgs adds to vnl_lbfgs.
  *
  * Shared by the drop-in classes (include/lrr_amd/cdcl_estimation.h) and by the CPU checker under oracle/ (which includes this
  * header; nothing here depends on it): both
@@ -23,7 +24,9 @@ extern "C" {
 /* value and gradient at x (n entries); g is never NULL */
 typedef void (*lrr_lbfgs_fg)(void *user, const double *x, double *f, double *g);
 
-enum { LRR_LBFGS_CONVERGED = 1, LRR_LBFGS_TOO_MANY_EVALS = 5, LRR_LBFGS_NO_DESCENT = -1 };
+/* USER_STOP: the stopping rule of cdcl_lbfgs::report_iter (vnl_nonlinear_minimizer::FAILED_USER_REQUEST = 9: positive, so the
+ * estimator keeps the point reached, cdcl/cdcl_estimation.txx:242-248) */
+enum { LRR_LBFGS_CONVERGED = 1, LRR_LBFGS_TOO_MANY_EVALS = 5, LRR_LBFGS_USER_STOP = 9, LRR_LBFGS_NO_DESCENT = -1 };
 
 typedef struct {
   double f_start, f_end; /* get_start_error(), get_end_error() */
@@ -31,8 +34,11 @@ typedef struct {
   int code;              /* > 0: x holds the best point found; < 0: failure, x is left as it was */
 } lrr_lbfgs_result;
 
-/* minimises f over x[0..n) in place; max_evals >= 1 function evaluations (the reference: 5) */
-static inline lrr_lbfgs_result lrr_lbfgs_minimize(int n, double *x, lrr_lbfgs_fg fg, void *user, int max_evals) {
+/* minimises f over x[0..n) in place; max_evals >= 1 function evaluations (the reference: 5).
+ * stop_fraction > 0: the one behaviour cdcl_lbfgs adds to vnl_lbfgs (cdcl/cdcl_lbfgs.h:28-36, report_iter): after every
+ * iteration (accepted iterate) the minimisation ends once |f_start - f| > stop_fraction |f_start| — 0.05 in the reference:
+ * "stop when the objective function has been sufficiently decreased".  0 = plain minimiser. */
+static inline lrr_lbfgs_result lrr_lbfgs_minimize_stop(int n, double *x, lrr_lbfgs_fg fg, void *user, int max_evals, double stop_fraction) {
   enum { M = 5 };
   lrr_lbfgs_result R;
   const double c1 = 1e-4, gtol = 1e-12, ftol = 1e-14;
@@ -107,6 +113,7 @@ static inline lrr_lbfgs_result lrr_lbfgs_minimize(int n, double *x, lrr_lbfgs_fg
     memcpy(g, gt, sizeof(double) * (size_t)n);
     f = ft;
     moved = 1;
+    if (stop_fraction > 0.0 && fabs(R.f_start - f) > stop_fraction * fabs(R.f_start)) { R.code = LRR_LBFGS_USER_STOP; break; }
     if (df <= ftol * fabs(f)) { R.code = LRR_LBFGS_CONVERGED; break; }
   }
   R.f_end = f;
@@ -114,6 +121,12 @@ static inline lrr_lbfgs_result lrr_lbfgs_minimize(int n, double *x, lrr_lbfgs_fg
   free(g);
   return R;
 }
+
+static inline lrr_lbfgs_result lrr_lbfgs_minimize(int n, double *x, lrr_lbfgs_fg fg, void *user, int max_evals) {
+  return lrr_lbfgs_minimize_stop(n, x, fg, user, max_evals, 0.0);
+}
+/* the fraction cdcl_lbfgs::report_iter stops at */
+#define LRR_CDCL_LBFGS_STOP_FRACTION 0.05
 
 #ifdef __cplusplus
 }

@@ -223,6 +223,9 @@ class rrl_location_batch {
   void set_device_loop(bool on) { device_loop_ = on; }           // false: the host half of every iteration on the host
   void set_sampling(double voxel_spacing, double interval) { voxel_spacing_ = voxel_spacing; sample_interval_ = interval; }
   lrr_icp_batch *handle() const { return batch_; }
+  // wall-clock milliseconds of the phases of the last run() (roi, host, iterate, rebuild, angles, ...): what bench.py prices
+  // the device-bound part of a batch with
+  std::vector<std::pair<std::string, double> > const &last_phases() const { return last_phases_; }
 
   // registers every query; results[i] belongs to queries[i]
   void run(std::vector<location_query> const &queries, std::vector<location_result> &results) {
@@ -230,6 +233,7 @@ class rrl_location_batch {
     results.assign(B, location_result());
     if (B == 0) return;
     phase_timer tm(std::getenv("LRR_BATCH_TIMING") != nullptr);
+    last_phases_.clear();
     std::vector<double> mbox(6 * B), fbox(6 * B);
     for (size_t b = 0; b < B; ++b)
       for (int d = 0; d < 3; ++d) {
@@ -369,7 +373,9 @@ class rrl_location_batch {
         if (s.iteration == 0) results[b].initial_RMS = s.rms;
         ++s.iteration;
         bool stop = converged || s.iteration >= max_iterations_;
-        if (!stop && check_valid_ && !valid_transform(s.F)) { results[b].valid_transform = false; stop = true; }
+        // `++iteration; if (!validTransform(...)) break;` (:2482): tested after every iteration, whether or not the loop
+        // condition ends it too
+        if (check_valid_ && !valid_transform(s.F)) { results[b].valid_transform = false; stop = true; }
         if (stop) {
           s.running = false;
           --running;
@@ -386,6 +392,7 @@ class rrl_location_batch {
     tm.lap("host");
     if (diagnostics_) decision_measurements(queries, st, loc, results, est, sums, tm);
     tm.report(B);
+    last_phases_ = tm.acc;
     for (size_t b = 0; b < B; ++b)
       if (results[b].enough_features && st[b].B) results[b].backward = st[b].B;
   }
@@ -398,7 +405,6 @@ class rrl_location_batch {
     std::vector<std::pair<std::string, double> > acc;
     explicit phase_timer(bool enable) : on(enable), t(std::chrono::steady_clock::now()) {}
     void lap(const char *name) {
-      if (!on) return;
       auto now = std::chrono::steady_clock::now();
       double ms = std::chrono::duration<double, std::milli>(now - t).count();
       t = now;
@@ -521,6 +527,7 @@ class rrl_location_batch {
   unsigned max_iterations_, min_features_;
   bool diagnostics_, check_valid_, device_loop_;
   double voxel_spacing_, sample_interval_;
+  std::vector<std::pair<std::string, double> > last_phases_;
 };
 
 }  // namespace lrr_amd

@@ -131,33 +131,40 @@ struct file_info {
   size_t appended_begin = 0, appended_end = 0;  // the bytes after '_' of <AppendedData>
 };
 
-// the bytes of one binary data block (inline base64 text or a region of the appended section)
-inline std::vector<unsigned char> block_bytes(const std::string &text, size_t pos, bool raw, const file_info &fi) {
+// the bytes of one binary data block (inline base64 text or a region of the appended section).  `limit`: the most bytes
+// the caller can use (expected values x type size): every size word read from the file is checked against it and against
+// what is left of the file BEFORE anything is sized or addressed with it (checks in subtraction form: no sum can wrap).
+inline std::vector<unsigned char> block_bytes(const std::string &text, size_t pos, bool raw, const file_info &fi, uint64_t limit) {
   std::vector<unsigned char> out, tmp;
   const size_t h = fi.hsize;
+  if (pos > text.size()) throw std::runtime_error("vtp: block offset beyond the file");
+  const size_t left = text.size() - pos;  // bytes (or base64 characters) from pos to the end of the file
   if (!fi.compressed) {
     if (raw) {
-      if (pos + h > text.size()) throw std::runtime_error("vtp: truncated raw block");
+      if (left < h) throw std::runtime_error("vtp: truncated raw block");
       const uint64_t nbytes = header_int((const unsigned char *)text.data() + pos, h);
-      if (pos + h + nbytes > text.size()) throw std::runtime_error("vtp: truncated raw block");
-      out.assign(text.begin() + pos + h, text.begin() + pos + h + nbytes);
+      if (nbytes > left - h) throw std::runtime_error("vtp: truncated raw block");
+      if (nbytes > limit) throw std::runtime_error("vtp: a block is larger than its array");
+      out.assign(text.begin() + pos + h, text.begin() + pos + h + (size_t)nbytes);
       return out;
     }
     // base64: VTK encodes the length word as a unit of its own; other writers encode length + data together
     size_t p2 = b64_decode(text, pos, h, tmp);
     if (tmp.size() < h) throw std::runtime_error("vtp: truncated base64 header");
     const uint64_t nbytes = header_int(tmp.data(), h);
+    if (nbytes > limit) throw std::runtime_error("vtp: a block is larger than its array");
+    if (nbytes / 3 > left / 4 + 1) throw std::runtime_error("vtp: truncated base64 block");  // 4 characters carry 3 bytes
     // was the header a unit of its own (ended by padding) or the start of a joint unit?
     bool separate = p2 > 0 && text[p2 - 1] == '=';
     if (separate) {
-      b64_decode(text, p2, nbytes, out);
+      b64_decode(text, p2, (size_t)nbytes, out);
     } else {
-      b64_decode(text, pos, h + nbytes, tmp);
+      b64_decode(text, pos, h + (size_t)nbytes, tmp);
       if (tmp.size() < h) throw std::runtime_error("vtp: truncated base64 block");
       out.assign(tmp.begin() + h, tmp.end());
     }
     if (out.size() < nbytes) throw std::runtime_error("vtp: truncated base64 block");
-    out.resize(nbytes);
+    out.resize((size_t)nbytes);
     return out;
   }
   // compressed: [nblocks][block size][last block size][compressed size of each block], then the blocks
@@ -165,40 +172,52 @@ inline std::vector<unsigned char> block_bytes(const std::string &text, size_t po
   size_t data_pos;
   uint64_t nblocks, bsize, lsize;
   if (raw) {
-    if (pos + 3 * h > text.size()) throw std::runtime_error("vtp: truncated compressed header");
+    if (left < 3 * h) throw std::runtime_error("vtp: truncated compressed header");
     nblocks = header_int((const unsigned char *)text.data() + pos, h);
-    if (pos + (3 + nblocks) * h > text.size()) throw std::runtime_error("vtp: truncated compressed header");
-    head.assign(text.begin() + pos, text.begin() + pos + (3 + nblocks) * h);
-    data_pos = pos + (3 + nblocks) * h;
+    if (nblocks > (left - 3 * h) / h) throw std::runtime_error("vtp: truncated compressed header");
+    const size_t hbytes = (3 + (size_t)nblocks) * h;
+    head.assign(text.begin() + pos, text.begin() + pos + hbytes);
+    data_pos = pos + hbytes;
   } else {
     b64_decode(text, pos, 3 * h, tmp);
     if (tmp.size() < 3 * h) throw std::runtime_error("vtp: truncated compressed header");
     nblocks = header_int(tmp.data(), h);
-    data_pos = b64_decode(text, pos, (3 + nblocks) * h, head);
-    if (head.size() < (3 + nblocks) * h) throw std::runtime_error("vtp: truncated compressed header");
+    if (nblocks > left / h) throw std::runtime_error("vtp: truncated compressed header");  // (every size word takes more than h characters)
+    const size_t hbytes = (3 + (size_t)nblocks) * h;
+    data_pos = b64_decode(text, pos, hbytes, head);
+    if (head.size() < hbytes) throw std::runtime_error("vtp: truncated compressed header");
   }
   bsize = header_int(head.data() + h, h);
   lsize = header_int(head.data() + 2 * h, h);
+  // (bsize is the writer's nominal block size — 32 KB by default, whatever the array's size; what a block may inflate to is
+  // checked block by block below)
+  if (data_pos > text.size()) throw std::runtime_error("vtp: truncated compressed data");
+  const uint64_t data_left = text.size() - data_pos;
   uint64_t ctotal = 0;
-  for (uint64_t b = 0; b < nblocks; ++b) ctotal += header_int(head.data() + (3 + b) * h, h);
+  for (uint64_t b = 0; b < nblocks; ++b) {
+    const uint64_t csize = header_int(head.data() + (3 + b) * h, h);
+    if (csize > data_left - ctotal) throw std::runtime_error("vtp: truncated compressed data");  // (ctotal <= data_left: no wrap)
+    ctotal += csize;
+  }
   std::vector<unsigned char> comp;
   if (raw) {
-    if (data_pos + ctotal > text.size()) throw std::runtime_error("vtp: truncated compressed data");
-    comp.assign(text.begin() + data_pos, text.begin() + data_pos + ctotal);
+    comp.assign(text.begin() + data_pos, text.begin() + data_pos + (size_t)ctotal);
   } else {
-    b64_decode(text, data_pos, ctotal, comp);
+    b64_decode(text, data_pos, (size_t)ctotal, comp);
     if (comp.size() < ctotal) throw std::runtime_error("vtp: truncated compressed data");
   }
   size_t cpos = 0;
   for (uint64_t b = 0; b < nblocks; ++b) {
     const uint64_t csize = header_int(head.data() + (3 + b) * h, h);
     const uint64_t usize = (b + 1 == nblocks && lsize != 0) ? lsize : bsize;
+    if (csize > comp.size() - cpos) throw std::runtime_error("vtp: truncated compressed data");
+    if (usize > limit - out.size()) throw std::runtime_error("vtp: the blocks inflate to more than their array");  // (out.size() <= limit)
     const size_t old = out.size();
-    out.resize(old + usize);
+    out.resize(old + (size_t)usize);
     uLongf got = (uLongf)usize;
     if (uncompress(out.data() + old, &got, comp.data() + cpos, (uLong)csize) != Z_OK || got != usize)
       throw std::runtime_error("vtp: zlib block does not inflate to its declared size");
-    cpos += csize;
+    cpos += (size_t)csize;
   }
   return out;
 }
@@ -212,7 +231,7 @@ inline std::vector<double> array_values(const std::string &text, const std::stri
   std::vector<double> v;
   if (format == "ascii") {
     const char *p = text.data() + body_begin, *end = text.data() + body_end;
-    v.reserve(expect);
+    v.reserve(std::min(expect, (body_end - body_begin) / 2 + 1));  // (a value takes at least two characters)
     while (p < end) {
       while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p;
       if (p >= end) break;
@@ -224,18 +243,23 @@ inline std::vector<double> array_values(const std::string &text, const std::stri
     }
   } else {
     std::vector<unsigned char> bytes;
+    const size_t ts = type_size(type);
+    // (zlib deflates at most ~1030 : 1, everything else stores a value in at least one byte)
+    if (expect / 1100 > text.size()) throw std::runtime_error("vtp: a DataArray declares more values than the file can hold");
+    const uint64_t limit = (uint64_t)expect * ts;
     if (format == "binary") {
-      bytes = block_bytes(text, body_begin, false, fi);
+      bytes = block_bytes(text, body_begin, false, fi, limit);
     } else if (format == "appended") {
       const std::string off = attr(tag, "offset");
       if (off.empty()) throw std::runtime_error("vtp: appended DataArray without offset");
-      const size_t pos = fi.appended_begin + (size_t)std::strtoull(off.c_str(), nullptr, 10);
-      if (pos >= fi.appended_end) throw std::runtime_error("vtp: appended offset beyond the data section");
-      bytes = block_bytes(text, pos, fi.appended_raw, fi);
+      const unsigned long long offv = std::strtoull(off.c_str(), nullptr, 10);
+      if (fi.appended_end < fi.appended_begin || offv >= fi.appended_end - fi.appended_begin)
+        throw std::runtime_error("vtp: appended offset beyond the data section");
+      const size_t pos = fi.appended_begin + (size_t)offv;
+      bytes = block_bytes(text, pos, fi.appended_raw, fi, limit);
     } else {
       throw std::runtime_error("vtp: unknown DataArray format " + format);
     }
-    const size_t ts = type_size(type);
     v.resize(bytes.size() / ts);
     for (size_t i = 0; i < v.size(); ++i) v[i] = value_at(bytes.data() + i * ts, type);
   }
@@ -260,7 +284,9 @@ inline void read_vtp(const std::string &path, vtp_arrays &out) {
   file_info fi;
   size_t p = text.find("<VTKFile");
   if (p == std::string::npos) throw std::runtime_error("vtp: not a VTK XML file: " + path);
-  const std::string head = text.substr(p, text.find('>', p) - p);
+  const size_t head_end = text.find('>', p);
+  if (head_end == std::string::npos) throw std::runtime_error("vtp: unterminated <VTKFile> tag");
+  const std::string head = text.substr(p, head_end - p);
   if (attr(head, "type") != "PolyData") throw std::runtime_error("vtp: VTKFile type is not PolyData");
   const std::string bo = attr(head, "byte_order");
   if (!bo.empty() && bo != "LittleEndian") throw std::runtime_error("vtp: only LittleEndian files are supported");
@@ -271,6 +297,7 @@ inline void read_vtp(const std::string &path, vtp_arrays &out) {
   const size_t ap = text.find("<AppendedData");
   if (ap != std::string::npos) {
     const size_t tag_end = text.find('>', ap);
+    if (tag_end == std::string::npos) throw std::runtime_error("vtp: unterminated <AppendedData> tag");
     const std::string atag = text.substr(ap, tag_end - ap);
     fi.appended_raw = attr(atag, "encoding") == "raw";
     size_t us = text.find('_', tag_end);
@@ -282,11 +309,14 @@ inline void read_vtp(const std::string &path, vtp_arrays &out) {
   }
   const size_t piece = text.find("<Piece", p);
   if (piece == std::string::npos || piece > xml_end) throw std::runtime_error("vtp: no <Piece>");
-  const std::string ptag = text.substr(piece, text.find('>', piece) - piece);
+  const size_t ptag_end = text.find('>', piece);
+  if (ptag_end == std::string::npos || ptag_end > xml_end) throw std::runtime_error("vtp: unterminated <Piece> tag");
+  const std::string ptag = text.substr(piece, ptag_end - piece);
   const std::string np = attr(ptag, "NumberOfPoints");
   if (np.empty()) throw std::runtime_error("vtp: <Piece> without NumberOfPoints");
   out = vtp_arrays();
   out.n = (size_t)std::strtoull(np.c_str(), nullptr, 10);
+  if (out.n / 1100 > text.size()) throw std::runtime_error("vtp: NumberOfPoints exceeds what the file can hold");
   const size_t piece_end = std::min(text.find("</Piece>", piece), xml_end);
   const size_t pts_a = text.find("<Points", piece), pts_b = text.find("</Points>", piece);
   const size_t pd_a = text.find("<PointData", piece), pd_b = text.find("</PointData>", piece);

@@ -66,6 +66,10 @@ int  lrr_icp_timer_stop(lrr_icp_ctx *ctx, double *elapsed_ms);
 /* accumulated device time of the matching kernels since the last reset (HIP events around
  * every K1 launch when profiling is enabled) */
 int  lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_t *launches, int reset);
+/* the elapsed time of every timed K1 submission since the last reset, in submission order (a submission serves one
+ * direction, or both directions of a symmetric estimator in the same launches): *count = how many there are, the first
+ * min(cap, *count) are copied to ms.  bench.py's median / spread of the K1 kernel time. */
+int  lrr_icp_match_profile_samples(lrr_icp_ctx *ctx, double *ms, int64_t cap, int64_t *count);
 /* how many searches (directions) each state of the grid matcher has served on this context since the last reset:
  * certificate kernel that searches its own failures / certificate + list + wave-per-query kernels / ball search of a
  * settled level / ball search right after a level grew / tile kernel (first dense search) / coarse pair path

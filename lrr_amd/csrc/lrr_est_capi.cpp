@@ -108,6 +108,15 @@ void read_trans(typename cdcl_trans<3, dof>::sptr const &T, double *A, double *t
   if (covar) for (unsigned r = 0; r < dof; ++r) for (unsigned k = 0; k < dof; ++k) covar[r * dof + k] = T->get_covariance()(r, k);
 }
 
+// validTransform (rrl/itkLocationRegistration.cxx:2914-2926): singular values of A within [0.1, 10]
+template <unsigned dof>
+bool singular_values_in_range(typename cdcl_trans<3, dof>::sptr const &T) {
+  double U[9], sv[3], V[9];
+  lrr_amd::linalg::svd3(T->get_A().data_block(), U, sv, V);
+  for (int d = 0; d < 3; ++d) if (sv[d] > 10.0 || sv[d] < 0.1) return false;
+  return true;
+}
+
 struct est_base {
   int dof = 0;
   virtual ~est_base() {}
@@ -122,7 +131,7 @@ struct est_base {
   virtual void set_subset_seed(uint64_t seed) = 0;
   virtual void find_closest_euclidean() = 0;
   virtual bool one_iteration(unsigned it) = 0;
-  virtual bool run(unsigned max_it, unsigned *done, int64_t *pairs) = 0;
+  virtual bool run(unsigned max_it, unsigned *done, int64_t *pairs, bool check_valid = false, int *valid = nullptr) = 0;
   virtual void estimate_LS(bool) = 0;
   virtual void estimate_LS_backward(bool) = 0;
   virtual void get_transform(int dir, double *A, double *t, double *c, double *covar) = 0;
@@ -169,12 +178,18 @@ struct fwd_impl : est_base {
   void set_subset_seed(uint64_t seed) override { e->set_subset_seed(seed); }
   void find_closest_euclidean() override { e->find_closest_euclidean(); }
   bool one_iteration(unsigned it) override { return e->one_iteration(0, 0, it); }
-  bool run(unsigned max_it, unsigned *done, int64_t *pairs) override {
+  bool run(unsigned max_it, unsigned *done, int64_t *pairs, bool check_valid, int *valid) override {
     // run() of the reference hard-codes 30 iterations (cdcl .txx:419)
     bool conv = false;
     unsigned it = 0;
+    if (valid) *valid = 1;
     e->initialize();
-    while (!conv && it < max_it) { conv = e->one_iteration(0, 0, it); ++it; if (pairs) *pairs += e->number_points(); }
+    while (!conv && it < max_it) {
+      conv = e->one_iteration(0, 0, it);
+      ++it;
+      if (pairs) *pairs += e->number_points();
+      if (check_valid && !singular_values_in_range<DOF>(e->get_transform())) { if (valid) *valid = 0; break; }
+    }
     if (done) *done = it;
     return conv;
   }
@@ -222,14 +237,17 @@ struct sym_impl : est_base {
   void set_subset_seed(uint64_t seed) override { e->set_subset_seed(seed); }
   void find_closest_euclidean() override { e->find_closest_euclidean(); }
   bool one_iteration(unsigned it) override { return e->one_iteration(0, 0, it); }
-  bool run(unsigned max_it, unsigned *done, int64_t *pairs) override {
-    // the caller's loop (rrl/itkLocationRegistration.cxx:2418): the class's own run() is a stub
+  bool run(unsigned max_it, unsigned *done, int64_t *pairs, bool check_valid, int *valid) override {
+    // the caller's loop (rrl/itkLocationRegistration.cxx:2418-2482): the class's own run() is a stub
     bool conv = false;
     unsigned it = 0;
+    if (valid) *valid = 1;
     while (!conv && it < max_it) {
       if (pairs) *pairs += e->forward().number_points() + e->backward().number_points();
       conv = e->one_iteration(0, 0, it);
       ++it;
+      // `if( !validTransform( estimation->get_transform() ) ) break;` (:2482)
+      if (check_valid && !singular_values_in_range<DOF>(e->get_transform())) { if (valid) *valid = 0; break; }
     }
     if (done) *done = it;
     return conv;
@@ -340,6 +358,10 @@ int lrr_est_iterate(lrr_est *e, unsigned first, unsigned count, int *converged) 
 int lrr_est_run(lrr_est *e, unsigned max_it, unsigned *done, int *converged) { return guard([&] { bool c = E(e)->run(max_it, done, nullptr); if (converged) *converged = c ? 1 : 0; }); }
 // same loop, also counting the matched pairs formed (sum over iterations of the active subset sizes)
 int lrr_est_run_counted(lrr_est *e, unsigned max_it, unsigned *done, int *converged, int64_t *pairs) { return guard([&] { if (pairs) *pairs = 0; bool c = E(e)->run(max_it, done, pairs); if (converged) *converged = c ? 1 : 0; }); }
+// the caller's loop with its validTransform break (rrl/itkLocationRegistration.cxx:2418-2482): *valid = 0 when it ended the loop
+int lrr_est_run_caller(lrr_est *e, unsigned max_it, int check_valid, unsigned *done, int *converged, int64_t *pairs, int *valid) {
+  return guard([&] { if (pairs) *pairs = 0; bool c = E(e)->run(max_it, done, pairs, check_valid != 0, valid); if (converged) *converged = c ? 1 : 0; });
+}
 int lrr_est_set_subset_seed(lrr_est *e, uint64_t seed) { return guard([&] { E(e)->set_subset_seed(seed); }); }
 int lrr_est_estimate_LS(lrr_est *e, int p) { return guard([&] { E(e)->estimate_LS(p != 0); }); }
 int lrr_est_estimate_LS_backward(lrr_est *e, int p) { return guard([&] { E(e)->estimate_LS_backward(p != 0); }); }
@@ -427,6 +449,17 @@ int lrr_est_batch_run(lrr_est_batch *bt, int64_t B, const double *A0, const doub
   });
 }
 
+
+// phases of the last lrr_est_batch_run as "name=ms;name=ms;..." (wall clock inside rrl_location_batch::run); returns the
+// length written (0: nothing ran yet)
+int lrr_est_batch_last_timing(lrr_est_batch *bt, char *out, int cap) {
+  if (!bt || !out || cap <= 0) return 0;
+  std::string s;
+  for (auto const &p : BT(bt)->last_phases()) { char b[96]; std::snprintf(b, sizeof b, "%s=%.6f;", p.first.c_str(), p.second); s += b; }
+  if ((int)s.size() >= cap) s.resize((size_t)cap - 1);
+  std::memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
 
 // ---- feature files (include/lrr_amd/vtp_features.h) -----------------------------------------------------
 typedef struct lrr_vtp lrr_vtp;

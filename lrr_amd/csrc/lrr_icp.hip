@@ -155,6 +155,8 @@ struct lrr_icp_ctx {
   int err_nb = 0;
   int *d_done = nullptr;
   unsigned long long *d_cert_stats = nullptr;  // {queries, searched} of the certificate kernel
+  int *d_fault = nullptr;  // set by the residual passes when a match index is outside the to-cloud (a K1 phase left a source
+                           // unserved): the estimate then fails with an error instead of gathering from a wild address
   // K1 scratch: one set per submission lane.  Lane 0 runs on `stream`; lane 1 has its own stream so
   // that the two directions of a symmetric estimator search concurrently (lrr_icp_match_pair).
   K1Lane lane[2];
@@ -168,6 +170,7 @@ struct lrr_icp_ctx {
   int pe_used = 0;
   double match_ms = 0.0;
   int64_t match_launches = 0;
+  std::vector<float> match_samples;  // elapsed ms of every timed K1 submission since the last reset (lrr_icp_match_profile_samples)
 };
 
 struct lrr_icp_cloud {
@@ -454,6 +457,25 @@ __device__ __forceinline__ void block_sum_all(double (&v)[K]) {
   __syncthreads();
 }
 
+// ---- tagged results in mapped host memory ------------------------------------------------------------------
+// A result crosses to the host as a 16-byte chunk {value, check}: check = chunk_check(tag, bits of value), tag = the
+// submission's number.  The host takes a value only when the check word it reads belongs to the tag it waits for AND
+// to the value bits it reads (chunk_take): the two 8-byte halves of a chunk may arrive in any order or at different
+// times (no assumption that the 16-byte store lands indivisibly, no fence on the device) — a half that is still the
+// previous submission's, or a slot that was never written, fails the test and the host polls on.  Naturally aligned
+// 8-byte words are the unit of both the device's store and the host's load.
+__host__ __device__ inline unsigned long long chunk_check(unsigned long long tag, unsigned long long vbits) {
+  unsigned long long x = (vbits ^ (tag * 0x9E3779B97F4A7C15ull)) * 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 31;
+  x = (x + tag) * 0x94D049BB133111EBull;
+  x ^= x >> 29;
+  return x | 1ull;  // never 0: a cleared slot holds no result
+}
+__device__ __forceinline__ double2 tagged_chunk(double value, double tag) {
+  const unsigned long long c = chunk_check((unsigned long long)tag, (unsigned long long)__double_as_longlong(value));
+  return make_double2(value, __longlong_as_double((long long)c));
+}
+
 // one wavefront per output value: lane l sums blocks l, l+64, ... in order, then the fixed
 // shuffle tree — deterministic for a given (nblocks, K)
 // The results also go straight into mapped host memory (host[head + k]; block 0 first forwards the
@@ -467,21 +489,22 @@ __global__ __launch_bounds__(64) void k_reduce_partials(const double *partials, 
                                                         const double *fwd, int head, double *host, int *done,
                                                         volatile unsigned long long *host_seq, unsigned long long seq,
                                                         const int *cnt_a = nullptr, const int *cnt_b = nullptr, int ld = 0,
-                                                        double tag = 0.0) {
+                                                        double tag = 0.0, const int *fault = nullptr) {
   int k = blockIdx.x;
   double s = 0.0;
   if (ld > 0) for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)k * ld + b];  // column-major rows (block_reduce_store)
   else for (int b = threadIdx.x; b < nblocks; b += 64) s += partials[(size_t)b * K + k];
   s = wave_sum(s);
   if (tag != 0.0) {
-    // tagged results: value i travels as the 16-byte chunk {value, tag} at host[2 i], written by ONE store; the host takes
-    // a value once its tag is there (wait_chunks) — no fence, no counter, no last block
+    // tagged results: value i travels as the 16-byte chunk {value, check word} at host[2 i]; the host takes a value once
+    // the check word of THIS tag and THIS value is there (wait_chunks / chunk_take) — no fence, no counter, no last block
     double2 *hc = reinterpret_cast<double2 *>(host);
-    if (threadIdx.x == 0) { out[k] = s; hc[head + k] = make_double2(s, tag); }
+    if (threadIdx.x == 0) { out[k] = s; hc[head + k] = tagged_chunk(s, tag); }
     if (k == 0) {
-      for (int t = threadIdx.x; t < head; t += 64) hc[t] = make_double2(fwd[t], tag);
-      if (threadIdx.x == 0) hc[head + K] = make_double2(cnt_a ? (double)*cnt_a : -1.0, tag);
-      if (threadIdx.x == 1) hc[head + K + 1] = make_double2(cnt_b ? (double)*cnt_b : -1.0, tag);
+      for (int t = threadIdx.x; t < head; t += 64) hc[t] = tagged_chunk(fwd[t], tag);
+      if (threadIdx.x == 0) hc[head + K] = tagged_chunk(cnt_a ? (double)*cnt_a : -1.0, tag);
+      if (threadIdx.x == 1) hc[head + K + 1] = tagged_chunk(cnt_b ? (double)*cnt_b : -1.0, tag);
+      if (threadIdx.x == 2) hc[head + K + 2] = tagged_chunk(fault ? (double)*fault : 0.0, tag);  // (checked_match)
     }
     return;
   }
@@ -514,6 +537,17 @@ __device__ __forceinline__ double slab_gap(double v, double lo, double hi, doubl
 struct Best { double d; int orig, canon; };
 __device__ __forceinline__ void consider(Best &b, double d, int orig, int canon) {
   if (d < b.d || (d == b.d && orig < b.orig)) { b.d = d; b.orig = orig; b.canon = canon; }
+}
+
+// A match index as the passes after K1 gather with it: inside the to-cloud, or 0 with the context's fault word set (and stored as 0; the
+// estimate that follows reports "match index out of range" instead of reading from a wild address).  K1 writes a valid
+// index for every active source — this is the guard behind that invariant (round 2 lost a GPU box to a work-in-progress
+// search that left -1 in m_to: to_rec[-1 * 10] lies below the cloud's slab).
+__device__ __forceinline__ int checked_match(int mt, int nt, int *fault, const int *stored) {
+  if ((unsigned)mt < (unsigned)nt) return mt;
+  if (fault) atomicOr(fault, 1);
+  *const_cast<int *>(stored) = 0;  // the passes behind this one gather with the stored index too
+  return 0;
 }
 
 // stopping bound of the ring search: distance from the query to the nearest INTERIOR face of the
@@ -646,16 +680,25 @@ int wait_results(lrr_icp_ctx *ctx, unsigned long long seq) {
   return LRR_ICP_OK;
 }
 
-// waits until `count` tagged chunks {value, tag} (k_reduce_partials) have arrived in mapped host memory and copies
-// their values to ctx->fused_vals (the chunks stay as they are: a tag slot only ever holds tags, so a stale one never
-// equals the current tag); 50 ms without them: stream synchronisation (reports a failed kernel), then failure
+// one tagged chunk (tagged_chunk): true and *value once the check word in the chunk belongs to `tag` and to the value
+// bits beside it; a torn or stale chunk (either half not yet this submission's) reads as "not there yet"
+inline bool chunk_take(const volatile double *chunk, double tag, double *value) {
+  const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(chunk);
+  const unsigned long long check = w[1], vbits = w[0];
+  if (check != chunk_check((unsigned long long)tag, vbits)) return false;
+  std::memcpy(value, &vbits, sizeof vbits);
+  return true;
+}
+// waits until `count` tagged chunks (k_reduce_partials) have arrived in mapped host memory and copies their values to
+// ctx->fused_vals; 50 ms without them: stream synchronisation (reports a failed kernel), then failure
 int wait_chunks(lrr_icp_ctx *ctx, const double *chunks, int count, double tag) {
   const volatile double *c = chunks;
   const auto t0 = std::chrono::steady_clock::now();
   bool synced = false;
+  ctx->fused_vals.resize((size_t)count);
   for (int i = 0; i < count; ++i) {
     unsigned spin = 0;
-    while (c[2 * i + 1] != tag) {
+    while (!chunk_take(c + 2 * i, tag, &ctx->fused_vals[(size_t)i])) {
       if ((++spin & 1023u) != 0 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) continue;
       if (synced) return fail(ctx, LRR_ICP_ERR_HIP, "results did not arrive");
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -663,8 +706,6 @@ int wait_chunks(lrr_icp_ctx *ctx, const double *chunks, int count, double tag) {
     }
   }
   std::atomic_thread_fence(std::memory_order_acquire);
-  ctx->fused_vals.resize((size_t)count);
-  for (int i = 0; i < count; ++i) ctx->fused_vals[(size_t)i] = c[2 * i];
   return LRR_ICP_OK;
 }
 inline double seq_tag(unsigned long long seq) { return (double)(seq & 0xfffffffffffffull); }  // exact in a double, never 0 (seq >= 1)
@@ -899,9 +940,16 @@ int resolve_profile(lrr_icp_ctx *ctx) {
     float ms = 0.f;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->pe[i], ctx->pe[i + 1]));
     ctx->match_ms += ms;
+    if (ctx->match_samples.size() < (size_t)1 << 20) ctx->match_samples.push_back(ms);
   }
   ctx->pe_used = 0;
   return LRR_ICP_OK;
+}
+
+// a residual pass met a match index outside the to-cloud (checked_match): clears the word, fails the call
+int match_fault(lrr_icp_ctx *ctx, const char *who) {
+  (void)hipMemsetAsync(ctx->d_fault, 0, sizeof(int), ctx->stream);
+  return fail(ctx, LRR_ICP_ERR_STATE, std::string(who) + ": a match index is outside the to-cloud (a K1 phase left an active source without a match)");
 }
 
 // certificate statistics of a search whose kernel had no wave-per-query kernel behind it to add them on the device
@@ -920,6 +968,7 @@ DirArgs dir_args(lrr_icp_dir *d) {
   a.w = d->w; a.wc = d->wc; a.r2 = d->r2; a.key_s = d->key_s; a.key_g = d->key_g; a.q_loc = d->q_loc;
   a.flag = d->flag; a.gen = d->flag_gen;
   a.float_product = d->from->float_strength;
+  a.nt = (int)d->to->n; a.fault = d->ctx->d_fault;
   return a;
 }
 
@@ -968,6 +1017,8 @@ int lrr_icp_create(int device, lrr_icp_ctx **out) {
   if ((e = hipHostGetDevicePointer((void **)&ctx->h_seq_dev, ctx->h_seq, 0)) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_done, sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMemset(ctx->d_done, 0, sizeof(int))) != hipSuccess) return bail(e);
+  if ((e = hipMalloc(&ctx->d_fault, sizeof(int))) != hipSuccess) return bail(e);
+  if ((e = hipMemset(ctx->d_fault, 0, sizeof(int))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_cert_stats, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e);
   if ((e = hipMemset(ctx->d_cert_stats, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail(e);
   if ((e = hipMalloc(&ctx->d_selstate, sizeof(SelState) * kMaxSelJobs)) != hipSuccess) return bail(e);
@@ -1014,6 +1065,7 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->d_muse) (void)hipFree(ctx->d_muse);
   if (ctx->d_done) (void)hipFree(ctx->d_done);
   if (ctx->d_cert_stats) (void)hipFree(ctx->d_cert_stats);
+  if (ctx->d_fault) (void)hipFree(ctx->d_fault);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1048,7 +1100,7 @@ int lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_
   if (rc) return rc;
   if (total_ms) *total_ms = ctx->match_ms;
   if (launches) *launches = ctx->match_launches;
-  if (reset) { ctx->match_ms = 0.0; ctx->match_launches = 0; }
+  if (reset) { ctx->match_ms = 0.0; ctx->match_launches = 0; ctx->match_samples.clear(); }
   if (enable && ctx->pe.empty()) {
     ctx->pe.resize(kProfEvents);
     for (auto &ev : ctx->pe) HIPCHK(ctx, hipEventCreate(&ev));
@@ -1056,6 +1108,16 @@ int lrr_icp_match_profile(lrr_icp_ctx *ctx, int enable, double *total_ms, int64_
   ctx->prof = enable != 0;
   ctx->prof_every = enable > 1 ? (unsigned)enable : 1u;  // enable = N > 1: every N-th submission is timed (two event records cost a few us)
   ctx->prof_tick = 0;
+  return LRR_ICP_OK;
+}
+
+// the individual timed K1 submissions behind lrr_icp_match_profile's total (each = the launch(es) serving its directions)
+int lrr_icp_match_profile_samples(lrr_icp_ctx *ctx, double *ms, int64_t cap, int64_t *count) {
+  if (!ctx || !count || cap < 0 || (cap > 0 && !ms)) return LRR_ICP_ERR_ARG;
+  int rc = resolve_profile(ctx);
+  if (rc) return rc;
+  *count = (int64_t)ctx->match_samples.size();
+  for (int64_t i = 0; i < cap && i < *count; ++i) ms[i] = (double)ctx->match_samples[(size_t)i];
   return LRR_ICP_OK;
 }
 
@@ -2059,14 +2121,14 @@ static int errors_drain(lrr_icp_ctx *ctx) {
   for (int b = 0; b < ctx->err_nb; ++b) {
     for (int k = 0; k < 3; ++k) {
       unsigned spin = 0;
-      while (rows[8 * b + 2 * k + 1] != tag) {
+      double v = 0.0;
+      while (!chunk_take(rows + 8 * b + 2 * k, tag, &v)) {
         if ((++spin & 1023u) != 0 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(50)) continue;
         if (synced) return fail(ctx, LRR_ICP_ERR_HIP, "error sums did not arrive");
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         synced = true;
       }
-      std::atomic_thread_fence(std::memory_order_acquire);
-      r[k] += rows[8 * b + 2 * k];
+      r[k] += v;
     }
   }
   for (int k = 0; k < 3; ++k) d->err_stash[k] = r[k];
@@ -2213,10 +2275,11 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   HIPCHK(ctx, hipGetLastError());
   const unsigned long long seq = ++ctx->seq;
   hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbAF + nbAB, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq,
-                     F->cert_list_count, B->cert_list_count, kron ? nbAF + nbAB : 0, seq_tag(seq));
+                     F->cert_list_count, B->cert_list_count, kron ? nbAF + nbAB : 0, seq_tag(seq), (const int *)ctx->d_fault);
   HIPCHK(ctx, hipGetLastError());
-  { int rc = wait_chunks(ctx, ctx->h_fused, (int)FIN_OFF + K + 2, seq_tag(seq)); if (rc) return rc; }
+  { int rc = wait_chunks(ctx, ctx->h_fused, (int)FIN_OFF + K + 3, seq_tag(seq)); if (rc) return rc; }
   const double *h = ctx->fused_vals.data();
+  if (h[FIN_OFF + K + 2] != 0.0) return match_fault(ctx, "estimate_symmetric");
   if (F->cert_list_count) F->last_list_count = (int)h[FIN_OFF + K];
   if (B->cert_list_count) B->last_list_count = (int)h[FIN_OFF + K + 1];
   note_inline_cert(ctx, F);
@@ -2420,9 +2483,10 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   HIPCHK(ctx, hipGetLastError());
   const unsigned long long seq = ++ctx->seq;
   hipLaunchKernelGGL(k_reduce_partials, dim3(K), dim3(64), 0, st, P6, nbA, K, FIN, (const double *)OUT, (int)FIN_OFF, ctx->h_fused_dev, ctx->d_done, ctx->h_seq_dev, seq,
-                     F->cert_list_count, (const int *)nullptr, kron ? nbA : 0, seq_tag(seq));
+                     F->cert_list_count, (const int *)nullptr, kron ? nbA : 0, seq_tag(seq), (const int *)ctx->d_fault);
   HIPCHK(ctx, hipGetLastError());
-  { int rc = wait_chunks(ctx, ctx->h_fused, (int)FIN_OFF + K + 2, seq_tag(seq)); if (rc) return rc; }
+  { int rc = wait_chunks(ctx, ctx->h_fused, (int)FIN_OFF + K + 3, seq_tag(seq)); if (rc) return rc; }
+  if (ctx->fused_vals[(size_t)FIN_OFF + K + 2] != 0.0) return match_fault(ctx, "estimate_forward");
   const double *h = ctx->fused_vals.data();
   if (F->cert_list_count) F->last_list_count = (int)h[FIN_OFF + K];
   note_inline_cert(ctx, F);

@@ -25,7 +25,7 @@ _ip = C.POINTER(C.c_int64)
 # every symbol include/lrr_icp.h declares
 ICP_SYMBOLS = [
     "lrr_icp_create", "lrr_icp_destroy", "lrr_icp_last_error", "lrr_icp_synchronize",
-    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile", "lrr_icp_event_overhead", "lrr_icp_cert_stats", "lrr_icp_k1_path_counts",
+    "lrr_icp_timer_start", "lrr_icp_timer_stop", "lrr_icp_match_profile", "lrr_icp_match_profile_samples", "lrr_icp_event_overhead", "lrr_icp_cert_stats", "lrr_icp_k1_path_counts",
     "lrr_icp_cloud_create", "lrr_icp_cloud_destroy", "lrr_icp_cloud_size", "lrr_icp_cloud_build_voronoi",
     "lrr_icp_dir_create", "lrr_icp_dir_destroy", "lrr_icp_dir_set_from", "lrr_icp_dir_num_matches",
     "lrr_icp_perm_keys", "lrr_icp_subset_perm", "lrr_icp_match", "lrr_icp_match_pair", "lrr_icp_premap",
@@ -201,6 +201,15 @@ class DeviceTimer:
         if self.L.lrr_icp_match_profile(self.ctx, int(enable), C.byref(ms), C.byref(n), int(reset)) != 0:
             raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
         return ms.value, n.value
+
+    def match_samples(self, cap=1 << 16):
+        """elapsed ms of every timed K1 submission since the last reset of match_profile"""
+        buf = np.zeros(cap)
+        n = C.c_int64(0)
+        self.L.lrr_icp_match_profile_samples.argtypes = [C.c_void_p, _dp, C.c_int64, _ip]
+        if self.L.lrr_icp_match_profile_samples(self.ctx, _d(buf), cap, C.byref(n)) != 0:
+            raise RuntimeError(self.L.lrr_icp_last_error(self.ctx).decode())
+        return buf[:min(cap, n.value)].copy()
 
     K1_PATHS = ("cert_inline", "cert", "ball", "ball_growth", "tile", "coarse_pair", "direct")
 
@@ -523,10 +532,15 @@ class Estimator:
         self._ck(est_lib().lrr_est_run(self._h, max_iterations, C.byref(n), C.byref(conv)))
         return bool(conv.value), int(n.value)
 
-    def run_counted(self, max_iterations=70):
-        """run() + the number of matched pairs formed over its iterations"""
-        n, conv, pairs = C.c_uint(0), C.c_int(0), C.c_int64(0)
-        self._ck(est_lib().lrr_est_run_counted(self._h, max_iterations, C.byref(n), C.byref(conv), C.byref(pairs)))
+    def run_counted(self, max_iterations=70, check_valid=False):
+        """run() + the number of matched pairs formed over its iterations; check_valid: the caller's
+        `if (!validTransform(...)) break;` after every iteration (rrl/itkLocationRegistration.cxx:2482) — whether it
+        ended the loop is kept in self.last_valid"""
+        n, conv, pairs, valid = C.c_uint(0), C.c_int(0), C.c_int64(0), C.c_int(1)
+        L = est_lib()
+        L.lrr_est_run_caller.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_int), _ip, C.POINTER(C.c_int)]
+        self._ck(L.lrr_est_run_caller(self._h, max_iterations, int(check_valid), C.byref(n), C.byref(conv), C.byref(pairs), C.byref(valid)))
+        self.last_valid = bool(valid.value)
         return bool(conv.value), int(n.value), int(pairs.value)
 
     def set_subset_seed(self, seed):
@@ -621,7 +635,7 @@ class LocationBatch:
 
     __del__ = close
 
-    def run(self, A0, t0, c0, moving_box, fixed_box, seeds, max_iterations=70, diagnostics=True, check_valid=False):
+    def run(self, A0, t0, c0, moving_box, fixed_box, seeds, max_iterations=70, diagnostics=True, check_valid=True):
         """A0 (B,3,3), t0 (B,3), c0 (B,3): initial transforms; *_box (B,6): x0, x1 of the ROIs; seeds (B,).
         Returns one row of `width` doubles per location (COL)."""
         A0 = np.ascontiguousarray(A0, dtype=np.float64).reshape(-1, 9)
@@ -637,6 +651,19 @@ class LocationBatch:
                                        int(check_valid), _d(rows)) != 0:
             raise RuntimeError(est_lib().lrr_est_last_error().decode())
         return rows
+
+    def last_timing(self):
+        """wall-clock ms of the phases of the last run() inside the C++ class: {'roi': .., 'iterate': .., ...}"""
+        buf = C.create_string_buffer(2048)
+        L = est_lib()
+        L.lrr_est_batch_last_timing.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.lrr_est_batch_last_timing(self._h, buf, 2048)
+        out = {}
+        for item in buf.value.decode().split(";"):
+            if "=" in item:
+                k, v = item.split("=")
+                out[k] = out.get(k, 0.0) + float(v)
+        return out
 
     def matches(self, b, direction=0):
         """matches_ of location b after run(): from = index in the ROI list, to = index in the full volume"""

@@ -37,7 +37,8 @@ def roi_boxes(rois, half=25.0):
 
 
 def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world: int = 1, seed: int = 7,
-                       gather_device=None, half: float = 25.0, batch=None, diagnostics=True, max_batch: int = 1024):
+                       gather_device=None, half: float = 25.0, batch=None, diagnostics=True, max_batch: int = 1024,
+                       check_valid: bool = True):
     """Batched form.  rois: synth.query_rois output (only the centres are used: the ROI lists are selected
     on the device); inits: the initial transform of every location; batch: an estimation.LocationBatch
     that already holds the two volumes (kept by the caller across calls), else one is built and closed.
@@ -56,7 +57,9 @@ def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world
         # the subset permutations of a location depend only on (seed, location): results do not depend on
         # which rank or batch handles it
         seeds = np.array([location_seed(seed, int(i)) for i in idx], dtype=np.uint64)
-        r = batch.run(A0, t0, c0, mbox[idx], fbox[idx], seeds, max_iterations=MAX_ITERATIONS, diagnostics=diagnostics)
+        # check_valid: the caller's `if (!validTransform(...)) break;` (rrl/itkLocationRegistration.cxx:2482)
+        r = batch.run(A0, t0, c0, mbox[idx], fbox[idx], seeds, max_iterations=MAX_ITERATIONS, diagnostics=diagnostics,
+                      check_valid=check_valid)
         r[:, 19] = idx
         rows.append(r)
     if own:
@@ -68,7 +71,7 @@ def register_locations(pair: synth.VolumePair, rois, inits, rank: int = 0, world
     return multi_gpu.gather_results(local, len(rois), device=gather_device), pairs
 
 
-def _run_block(pair, rois, inits, indices, seed, est=None, diagnostics=True):
+def _run_block(pair, rois, inits, indices, seed, est=None, diagnostics=True, check_valid=True):
     """One estimator object re-used over `indices` (a host thread = one device context).  `est`: an
     estimator that already holds the two volumes (uploaded by an earlier block); returns it for the
     next one."""
@@ -86,7 +89,7 @@ def _run_block(pair, rois, inits, indices, seed, est=None, diagnostics=True):
         # the subset permutations of a location depend only on (seed, location): results do not
         # depend on which rank / thread / estimator object handles it
         est.set_subset_seed(location_seed(seed, i))
-        converged, it, p = est.run_counted(MAX_ITERATIONS)  # the caller's loop, in C++ (no GIL held)
+        converged, it, p = est.run_counted(MAX_ITERATIONS, check_valid=check_valid)  # the caller's loop, in C++ (no GIL held)
         pairs += p
         A, t, c, _ = est.get_transform()
         row = multi_gpu.pack_result(i, converged, it, A, t, c, est.weighted_error(), est.RMS_error())

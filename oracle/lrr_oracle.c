@@ -1272,7 +1272,7 @@ int lrr_oracle_cdc_em_iteration(const lrr_oracle_features *moving, const lrr_ora
     for (int i = 0; i < 9; ++i) x[i] = T.A[i];
     for (int i = 0; i < 3; ++i) x[9 + i] = T.t[i];
     memcpy(x_old, x, sizeof x);
-    lrr_lbfgs_result r = lrr_lbfgs_minimize(12, x, em_fg_par, &E, 5);
+    lrr_lbfgs_result r = lrr_lbfgs_minimize_stop(12, x, em_fg_par, &E, 5, LRR_CDCL_LBFGS_STOP_FRACTION);  /* cdcl/cdcl_lbfgs.h:28-36 */
     parameters_converged = (r.f_start - r.f_end) < 1e-4;
     if (r.code < 0) memcpy(x, x_old, sizeof x);
     for (int i = 0; i < 9; ++i) T.A[i] = x[i];
@@ -1289,7 +1289,7 @@ int lrr_oracle_cdc_em_iteration(const lrr_oracle_features *moving, const lrr_ora
     if (!chol_upper(dof, T.covar, U)) return -1;
     { int ind = 0; for (int d1 = 0; d1 < dof; ++d1) for (int d2 = d1; d2 < dof; ++d2) x[ind++] = U[d1 * dof + d2]; }
     memcpy(x_old, x, sizeof x);
-    lrr_lbfgs_result r = lrr_lbfgs_minimize(ncov, x, em_fg_cov, &E, 5);
+    lrr_lbfgs_result r = lrr_lbfgs_minimize_stop(ncov, x, em_fg_cov, &E, 5, LRR_CDCL_LBFGS_STOP_FRACTION);
     covariance_converged = (r.f_start - r.f_end) < 1e-5;
     if (r.code < 0) memcpy(x, x_old, sizeof x);
     memset(U, 0, sizeof U);

@@ -89,7 +89,7 @@ def test_batch_equals_one_at_a_time_and_oracle(E, ob):
         m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[b]
         g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in,
                         seed=int(seeds[b]))
-        conv, its, npairs = g.run_counted(locations.MAX_ITERATIONS)
+        conv, its, npairs = g.run_counted(locations.MAX_ITERATIONS, check_valid=True)
         assert bool(rows[b, C["converged"]]) == conv and int(rows[b, C["iterations"]]) == its, b
         assert int(rows[b, C["matched_pairs"]]) == npairs
         A, t, c, cov = g.get_transform()
@@ -139,7 +139,7 @@ def test_batch_decision_measurements(E, ob):
         for factory in (E.Estimator, ob.OracleEstimator):
             kind = E.RRL_SYMMETRIC if factory is E.Estimator else ob.RRL_SYMMETRIC
             g = factory(kind, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in, seed=int(seeds[b]))
-            g.run(locations.MAX_ITERATIONS) if factory is ob.OracleEstimator else g.run_counted(locations.MAX_ITERATIONS)
+            g.run(locations.MAX_ITERATIONS) if factory is ob.OracleEstimator else g.run_counted(locations.MAX_ITERATIONS, check_valid=True)
             sa, ta, we = g.sheet_angles(0), g.tube_angles(0), g.weighted_error(0)
             g.estimate_LS_backward(False)
             sab, tab, web = g.sheet_angles(1), g.tube_angles(1), g.weighted_error(1)

@@ -101,3 +101,79 @@ def test_empty_file(tmp_path):
         p = tmp_path / "empty.vtp"
         vtp.write_vtp(p, e, fmt=fmt)
         assert vtp.read_features(p).n == 0
+
+
+@pytest.fixture(scope="module")
+def vtp_probe(tmp_path_factory):
+    """tests/cpp/vtp_probe.cpp built with AddressSanitizer + UBSan (host build: g++, no GPU code)"""
+    import subprocess
+    out = tmp_path_factory.mktemp("probe") / "vtp_probe"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "vtp_probe.cpp"), "-lz", "-o", str(out)])
+    return str(out)
+
+
+def _probe(exe, path):
+    import subprocess
+    r = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1:max_allocation_size_mb=4096"))
+    assert r.returncode == 0, f"sanitizer report or crash on {path}:\n{r.stderr[-2000:]}"
+    return r.stdout.strip()
+
+
+def _patch_word(data: bytes, pos: int, value: int, size: int) -> bytes:
+    return data[:pos] + int(value).to_bytes(size, "little") + data[pos + size:]
+
+
+@pytest.mark.parametrize("header_type", ["UInt32", "UInt64"])
+@pytest.mark.parametrize("compress", [False, True])
+def test_corrupt_size_words_end_in_an_error(tmp_path, vtp_probe, header_type, compress):
+    """ADVICE (round 2): every size word of a binary block is attacker-controlled.  Raw appended blocks with their size words
+    replaced by huge values (sums that would wrap 64 bits), by values just past the end of the file, and truncated files:
+    the reader must throw its runtime_error — run under ASan/UBSan so that an out-of-bounds read would be seen"""
+    pair = synth.make_pair(600, 10, 91, kind="affine")
+    arrays = vtp.disk_arrays(pair.fixed)
+    p = tmp_path / "f.vtp"
+    vtp.write_vtp(p, arrays, fmt="appended-raw", compress=compress, header_type=header_type)
+    data = p.read_bytes()
+    assert _probe(vtp_probe, p) == "ok 600"
+    h = 8 if header_type == "UInt64" else 4
+    start = data.index(b"<AppendedData")
+    us = data.index(b"_", data.index(b">", start)) + 1
+    big = [2**(8 * h) - 1, 2**(8 * h) - h, 2**(8 * h - 1), len(data), len(data) - us, 2**31]
+    words = 1 if not compress else 5  # nbytes | nblocks, block size, last size, first compressed sizes
+    for w in range(words):
+        for v in big:
+            q = tmp_path / f"c_{w}_{v}.vtp"
+            q.write_bytes(_patch_word(data, us + w * h, v, h))
+            got = _probe(vtp_probe, q)
+            # (word 1 of a compressed block is the writer's nominal block size: unused when the array is one short block)
+            assert got.startswith("error vtp:") or (compress and w == 1 and got == "ok 600"), (w, v, got)
+    for cut in (us + 1, us + h, us + 3 * h + 1, len(data) - 300, len(data) // 2):
+        q = tmp_path / f"t_{cut}.vtp"
+        q.write_bytes(data[:cut])
+        assert _probe(vtp_probe, q).startswith("error vtp:"), cut
+
+
+def test_corrupt_markup_and_base64_end_in_an_error(tmp_path, vtp_probe):
+    pair = synth.make_pair(300, 10, 92, kind="affine")
+    arrays = vtp.disk_arrays(pair.fixed)
+    p = tmp_path / "f.vtp"
+    for fmt in ("binary", "appended-base64"):
+        for compress in (False, True):
+            vtp.write_vtp(p, arrays, fmt=fmt, compress=compress)
+            data = p.read_bytes()
+            assert _probe(vtp_probe, p) == "ok 300"
+            for cut in (40, len(data) // 3, len(data) // 2, len(data) - 200):
+                q = tmp_path / "cut.vtp"
+                q.write_bytes(data[:cut])
+                assert _probe(vtp_probe, q).startswith("error vtp:"), (fmt, compress, cut)
+    # tags without their closing '>'
+    for text in ('<VTKFile type="PolyData"', '<VTKFile type="PolyData"><PolyData><Piece NumberOfPoints="3"',
+                 '<VTKFile type="PolyData"><AppendedData encoding="raw"',
+                 '<VTKFile type="PolyData"><PolyData><Piece NumberOfPoints="99999999999999999999"><Points><DataArray type="Float32" '
+                 'NumberOfComponents="3" format="ascii">1 2 3</DataArray></Points></Piece></PolyData></VTKFile>'):
+        q = tmp_path / "m.vtp"
+        q.write_text(text)
+        assert _probe(vtp_probe, q).startswith("error vtp:"), text
