@@ -5,10 +5,17 @@ matched-feature-pairs/s (+ ms/iteration) on 200k x 200k synthetic 3-D features.
 A "step" is ONE iteration of rrl_estimation_symmetric_ICP_matching_all<3,12>::one_iteration at
 the finest level (every point of both ROIs matched: 200k forward + 200k backward pairs), i.e.
 config[2] of BASELINE.json, which fits one GPU.  Inputs are resident in HBM before the timed
-region (uploaded by the estimator constructor).  N > 1 (one process per GPU, launched by
-torch.distributed.run): every rank runs an independent problem of the same size (weak scaling:
-the path shards over independent query problems), then ONE all_gather of the
-final transforms over RCCL.
+region (uploaded by the estimator constructor).  N > 1: one process per GPU — started by
+torch.distributed.run, or by this script itself when it is called as `python bench.py --gpus N`
+without a rendezvous in the environment (the parent makes no GPU call and only starts the ranks):
+every rank runs an independent problem of the same size (weak scaling: the path shards over
+independent query problems), then ONE all_gather of the final transforms over RCCL.
+
+The same line carries, as sub-records: the three regimes of the 200k x 200k workload (`value` = the
+converged steady state; `moving_transform` = set_transform(perturbed) at the finest level -> iterate to
+convergence; `schedule` = the faithful 1000 -> N run), config 5 (`locations`: 256 query locations sharded
+over the ranks, with its own roofline and CPU baseline), the production matcher's lookup semantics on
+the GPU (`voronoi`), and the CPU oracle beside them (`cpu_baseline`).
 
 Prints one JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
@@ -53,7 +60,30 @@ def parse():
     ap.add_argument("--locations-mode", choices=["batch", "sequential"], default="batch",
                     help="batch: all locations of a rank advance in lockstep, one submission per phase; sequential: one estimator object at a time (the reference caller's form)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed region; the median is reported")
+    ap.add_argument("--no-locations", action="store_true", help="skip the config-5 sub-record of the default workload")
+    ap.add_argument("--no-moving", action="store_true", help="skip the moving-transform regime")
+    ap.add_argument("--no-voronoi", action="store_true", help="skip the GPU run with the Voronoi-lookup semantics")
+    ap.add_argument("--cpu-locations", type=int, default=64, help="query locations the CPU oracle registers for the locations baseline")
+    ap.add_argument("--code-stamp", action="store_true", help="print the stamp of the kernel sources and exit (tools/*.sh record it)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a rendezvous in the environment: this process has made no GPU call (torch is not
+    even imported yet) and starts the N ranks as children through torch.distributed.run, one per GPU, rendezvous on
+    127.0.0.1; rank 0's JSON line goes to the inherited stdout.  Never an exec: the parent waits and returns the
+    children's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def _oracle_iterations(pair, T0, n, iters, nn_backend, out, k):
@@ -202,10 +232,43 @@ def schedule_run(E, pair, T0, nn, timer):
             "per_iteration": [{"n_points": int(a), "ms": round(float(b), 4), "k1_ms_per_direction": round(float(c), 5)} for a, b, c in rows]}
 
 
-def bench_locations(args, rank, local_rank, world):
-    """config 5: `--locations` query locations x one 200k volume pair, static blocks per rank
-    (32 per GPU at 256/8), one all_gather of the result rows.  Strong scaling: total work fixed.
-    A step = one query location registered to convergence plus the caller's decision measurements."""
+def cpu_locations(pair, rois, inits, rows_gpu, count, seed=7):
+    """config 5 on the CPU oracle, 1 thread: the first `count` query locations registered one after the other as the
+    reference's caller does (set_features + set_transform, one_iteration until converged / 70 / an invalid transform).
+    Pairs per location are the GPU rows' (the oracle forms the same ones: tests/test_gpu_batch.py)."""
+    from lrr_amd import estimation as E
+    from lrr_amd import locations
+    from oracle import binding as ob
+    C = E.LocationBatch.COL
+    count = max(1, min(count, len(rois)))
+    same, o, dt = 0, None, 0.0
+    for i in range(count):
+        _, _, mi, fi = rois[i]
+        T0 = inits[i]
+        m_in, f_in = pair.moving.subset(mi), pair.fixed.subset(fi)  # (FeaturesInROIs; numpy, outside the timed part on both sides)
+        if o is None:  # the search structures of the two volumes are built once, as the reference reads its Voronoi maps once
+            o = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in,
+                                   seed=1, nn_backend=ob.NN_KDTREE)
+        t0 = time.perf_counter()
+        o.set_features(m_in, f_in)          # SetupEstimation (:1635-1637)
+        o.set_transform(T0.A, T0.t, T0.c)
+        o.set_subset_seed(locations.location_seed(seed, i))
+        conv, its = o.run(locations.MAX_ITERATIONS)
+        dt += time.perf_counter() - t0
+        same += int(bool(rows_gpu[i, C["converged"]]) == conv and int(rows_gpu[i, C["iterations"]]) == its)
+    o.close()
+    pairs = float(rows_gpu[:count, C["matched_pairs"]].sum())
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": 1, "kind": "port", "locations_per_s": count / dt,
+            "sample": f"the first {count} of the {len(rois)} query locations, registered one after the other by the C oracle (kd-tree NN) "
+                      f"to convergence: set_features + set_transform + the caller's loop ({dt:.2f} s; the kd-trees of the two volumes are built once, "
+                      "outside the timed part; no decision measurements)",
+            "same_flags_and_iterations_as_gpu": f"{same}/{count}"}
+
+
+def locations_measure(args, rank, local_rank, world, cpu=True):
+    """config 5: `--locations` query locations x one 200k volume pair, static blocks per rank (32 per GPU at 256/8), one
+    all_gather of the result rows.  Strong scaling: total work fixed.  A step = one query location registered to
+    convergence plus the caller's decision measurements.  Returns the record on rank 0 (None elsewhere)."""
     import torch
     import torch.distributed as dist
 
@@ -217,7 +280,7 @@ def bench_locations(args, rank, local_rank, world):
     dev = (torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")) if world > 1 else None
     sequential = args.locations_mode == "sequential"
     reps = max(1, args.reps)
-    times, pairs, rows = [], 0, None
+    times, pairs, rows, phases = [], 0, None, []
     if sequential:
         ests = []  # the estimators (and the two uploaded volumes) live across the calls: inputs resident before timing
         locations.register_locations_sequential(pair, rois[: max(1, args.workers)], inits, 0, 1, workers=args.workers,
@@ -241,6 +304,8 @@ def bench_locations(args, rank, local_rank, world):
         if world > 1:
             dist.barrier()
         times.append(time.perf_counter() - t0)
+        if not sequential:
+            phases.append(batch.last_timing())
     if sequential:
         for e in ests:
             if e is not None:
@@ -248,25 +313,56 @@ def bench_locations(args, rank, local_rank, world):
     else:
         batch.close()
     dt = float(np.median(times))
-    tt = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=dev if dev is not None else "cuda")
+    ph = phases[int(np.argsort(times)[len(times) // 2])] if phases else {}
+    # [median wall, this rank's pairs, this rank's device-bound phases (ROI selection + the iterations)]
+    tt = torch.tensor([dt, float(pairs), float(ph.get("iterate", 0.0)), float(ph.get("roi", 0.0))], dtype=torch.float64,
+                      device=dev if dev is not None else "cuda")
     if world > 1:
         dist.all_reduce(tt[0:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(tt[1:2], op=dist.ReduceOp.SUM)
+        dist.all_reduce(tt[2:4], op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return None
+    dt, pairs, it_ms, roi_ms = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
+    C = E.LocationBatch.COL
+    rec = {
+        "metric": "ICP matched-feature-pairs/sec", "value": pairs / dt, "unit": "pairs/s", "n_gpus": world,
+        "steps": len(rois), "warmup": 1, "ms_per_step": 1e3 * dt / max(len(rois), 1), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{len(rois)} query locations (50 mm ROIs) x {args.n}-feature volume pair, "
+                               "symmetric ICP to convergence per location (<= 70 iterations, validTransform break) + decision measurements",
+                   "mode": args.locations_mode,
+                   "parallelism": (f"{world} rank(s), static blocks of locations, one batch per rank, one all_gather" if not sequential else
+                                   f"{world} rank(s) x {args.workers} host thread(s), static blocks of locations, one all_gather")},
+        "locations_per_s": len(rois) / dt, "ms_total": 1e3 * dt, "converged": int(rows[:, 0].sum()),
+        "mean_iterations": float(rows[:, 1].mean()), "max_iterations": int(rows[:, 1].max()),
+        "matched_pairs": int(pairs), "repetitions": reps, "seconds_all": times, "row_bytes": int(rows.shape[1] * 8),
+        "phases_ms": ph, "roofline": None, "cpu_baseline": None}
+    if not sequential and it_ms > 0.0:
+        # every matched pair of every iteration goes once through K1 (k_b_match + the wave-per-query phase) and the five
+        # passes of the estimate (k_b_residual, k_b_stats, k_b_weights, k_b_select, k_b_accumulate) + k_b_errors:
+        # SURVEY 8(d)'s 180 algorithmic bytes per pair, over the time the device works on the iterations (the slowest
+        # rank's lrr_icp_batch_iterate: the host queues ahead of the device there)
+        ach = pairs / world * ITER_BYTES_PER_PAIR / (it_ms * 1e-3) / 1e9
+        rec["roofline"] = {"bound": "hbm", "kernel": "one lockstep iteration of all locations of a rank = k_b_match + k_match_hard2 + k_match_overflow2 "
+                                                     "+ k_b_residual, k_b_stats, k_b_weights, k_b_select, k_b_accumulate + k_run_solve, k_b_errors, k_run_decide "
+                                                     "(lrr_icp_batch_iterate); latency-bound: a location is a few thousand pairs",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel_ms": it_ms, "algorithmic_bytes_per_launch": pairs / world * ITER_BYTES_PER_PAIR,
+                           "note": "achieved = (matched pairs of the slowest rank's block x 180 B) / its iterate phase; ROI selection "
+                                   f"{roi_ms:.3f} ms and the decision measurements are outside it"}
+    if cpu and world == 1 and not args.no_cpu_baseline and not sequential:
+        rec["cpu_baseline"] = cpu_locations(pair, rois, inits, rows, args.cpu_locations)
+        rec["speedup_vs_cpu_1thread"] = rec["value"] / rec["cpu_baseline"]["value"]
+    return rec
+
+
+def bench_locations(args, rank, local_rank, world):
+    import torch.distributed as dist
+    rec = locations_measure(args, rank, local_rank, world)
     if rank == 0:
-        dt, pairs = float(tt[0]), float(tt[1])
-        print(json.dumps({
-            "metric": "ICP matched-feature-pairs/sec", "value": pairs / dt, "unit": "pairs/s", "n_gpus": world,
-            "steps": len(rois), "warmup": 1, "ms_per_step": 1e3 * dt / max(len(rois), 1), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{len(rois)} query locations (50 mm ROIs) x {args.n}-feature volume pair, "
-                                   "symmetric ICP to convergence per location (<= 70 iterations) + decision measurements",
-                       "mode": args.locations_mode,
-                       "parallelism": (f"{world} rank(s), static blocks of locations, one batch per rank, one all_gather" if not sequential else
-                                       f"{world} rank(s) x {args.workers} host thread(s), static blocks of locations, one all_gather")},
-            "locations_per_s": len(rois) / dt, "converged": int(rows[:, 0].sum()),
-            "mean_iterations": float(rows[:, 1].mean()), "max_iterations": int(rows[:, 1].max()),
-            "repetitions": reps, "seconds_all": times, "row_bytes": int(rows.shape[1] * 8),
-            "roofline": None, "cpu_baseline": None}))
+        rec["code_sha"] = code_stamp()
+        print(json.dumps(rec))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -356,8 +452,112 @@ def bench_cdc(args):
     cf.close()
 
 
+def sample_stats(ms, per):
+    """median / spread of HIP-event samples (ms per submission) as time per `per`-th of a submission"""
+    v = np.sort(np.asarray(ms, dtype=np.float64)) / per
+    if v.size == 0:
+        return None
+    q = lambda f: float(v[min(v.size - 1, int(f * v.size))])
+    return {"n": int(v.size), "median_ms": float(np.median(v)), "mean_ms": float(v.mean()), "p10_ms": q(0.10), "p90_ms": q(0.90),
+            "min_ms": float(v[0]), "max_ms": float(v[-1])}
+
+
+def moving_transform(est, E, pair, timer, reps):
+    """The regime a caller of set_transform() sees at the finest level: the transform is set to planted (+) a fresh
+    perturbation (0.5 deg, 0.5 mm: what T0 is), every point of both ROIs is active (set_number_points), and the caller's
+    loop runs until the class reports convergence.  The first iteration takes its scale from MUSE and searches without a
+    certificate; the certificate comes in as the transform settles.  Wall time of the whole loop (one C++ call, no
+    synchronisation inside) over `reps` repetitions + one more repetition with HIP events on every K1 submission."""
+    from lrr_amd import synth
+    n = pair.moving.n
+    rows = []
+    k1 = None
+    for r in range(reps + 2):  # 0: warm-up (untimed); last: K1 events on every submission (its wall time is not used)
+        Tp = synth.perturbed(pair.planted, 500 + r)
+        est.set_transform(Tp.A, Tp.t, Tp.c)
+        est.set_number_points(10**9)
+        events = r == reps + 1
+        if events:
+            timer.match_profile(enable=1, reset=True)
+            timer.cert_stats(reset=True)
+            timer.k1_path_counts(reset=True)
+        timer.synchronize()
+        t0 = time.perf_counter()
+        conv, its, pairs = est.run_counted(70)
+        timer.synchronize()
+        dt = time.perf_counter() - t0
+        if events:
+            ms = timer.match_samples()
+            seen, searched = timer.cert_stats()
+            k1 = {"per_direction": sample_stats(ms, 2), "per_iteration_ms_per_direction": [round(float(x) / 2, 5) for x in ms],
+                  "certificate": {"queries": seen, "searched": searched, "skipped_frac": (1.0 - searched / seen) if seen else None},
+                  "searches_skipped_frac_of_all": (1.0 - (searched + (2 * n * its - seen)) / (2.0 * n * its)) if its else None,
+                  "paths": timer.k1_path_counts(reset=True)}
+            timer.match_profile(enable=False, reset=True)
+        elif r > 0:
+            rows.append((dt, its, pairs, conv))
+    dts = np.array([x[0] for x in rows])
+    mid = int(np.argsort(dts)[len(dts) // 2])
+    dt, its, pairs, conv = rows[mid]
+    k1_bytes = n * K1_BYTES_PER_PAIR_FIXED + 24.0 * n
+    out = {"what": "set_transform(planted (+) perturbation) at the finest level, then one_iteration until converged (<= 70)",
+           "repetitions": reps, "iterations": [int(x[1]) for x in rows], "converged": [bool(x[3]) for x in rows],
+           "ms_total_all": [1e3 * float(x[0]) for x in rows], "ms_total": 1e3 * dt, "matched_pairs": int(pairs),
+           "value": pairs / dt, "unit": "pairs/s", "ms_per_iteration": 1e3 * dt / max(its, 1), "k1": k1}
+    if k1 and k1["per_direction"]:
+        ach = k1_bytes / (k1["per_direction"]["mean_ms"] * 1e-3) / 1e9
+        out["k1_roofline"] = {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "kernel_ms": k1["per_direction"]["mean_ms"], "algorithmic_bytes_per_launch": k1_bytes,
+                              "note": "mean over ALL K1 submissions of the loop (ball search while the transform moves, certificate once it settles)"}
+    return out
+
+
+def voronoi_gpu(E, pair, T0, timer, steps, reps):
+    """The production matcher's semantics on the GPU (LRR_ICP_NN_VORONOI: the quantised lookup in the 1 mm Voronoi volume,
+    rrl/rrl_estimation_ICP_matching_all.txx:530-543): same workload, finest-level iterations after the faithful schedule."""
+    est = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=pair.moving, fixed_inside=pair.fixed,
+                      seed=7, nn_method=E.NN_VORONOI)
+    it = 0
+    timer.synchronize()
+    t0 = time.perf_counter()
+    while not est.finest_level() and it < 70:
+        est.one_iteration(it)
+        it += 1
+    timer.synchronize()
+    sched_ms = 1e3 * (time.perf_counter() - t0)
+    for _ in range(3):
+        est.one_iteration(it)
+        it += 1
+    n_pairs = est.number_points(0) + est.number_points(1)
+    times = []
+    for _ in range(reps):
+        timer.synchronize()
+        t0 = time.perf_counter()
+        est.iterate(it, steps)
+        it += steps
+        timer.synchronize()
+        times.append(time.perf_counter() - t0)
+    timer.match_profile(enable=1, reset=True)
+    est.iterate(it, 16)
+    ms = timer.match_samples()
+    timer.match_profile(enable=False, reset=True)
+    werr = est.weighted_error()
+    est.close()
+    dt = float(np.median(times))
+    return {"what": "the same workload with the rrl classes' own matcher semantics (nearest occupied voxel of the 1 mm Voronoi volume; "
+                    "different match sets than the exact search of `value`)",
+            "value": steps * n_pairs / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "repetitions": reps,
+            "schedule_iterations": it - 3 - steps * reps - 16, "schedule_ms_incl_first_voronoi_build": sched_ms,
+            "k1_per_direction": sample_stats(ms, 2), "final_weighted_error": werr}
+
+
 def main():
     args = parse()
+    if args.code_stamp:
+        print(code_stamp())
+        return 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -415,8 +615,11 @@ def main():
     reps = max(1, args.reps)
     times = []
     # K1's launch duration is taken live with HIP events, on the stream that runs it, around every k1_sample-th K1
-    # submission of the timed region (each timed submission costs two event records on the critical path)
-    k1_sample = int(os.environ.get("LRR_BENCH_K1_SAMPLE", "32"))  # (every 8th submission costs 2.6 % of `value`, every one 5-8 %)
+    # submission of the timed region (each timed submission costs two event records on the critical path: every
+    # submission 5-8 % of `value`, every 8th 2.6 %).  The timed region yields steps x reps / k1_sample samples; a sampling
+    # pass of its own after it (every submission timed, same steady state) brings the total to >= 64 whatever --steps is.
+    want_samples = 64
+    k1_sample = int(os.environ.get("LRR_BENCH_K1_SAMPLE", "0")) or max(4, min(32, (args.steps * reps) // 24))
     timer.match_profile(enable=k1_sample, reset=True)
     timer.cert_stats(reset=True)
     for _ in range(reps):
@@ -427,8 +630,17 @@ def main():
         barrier()
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
-    match_ms, match_launches = timer.match_profile(enable=False, reset=False)
+    samples_timed = timer.match_samples()
     cert_seen, cert_searched = timer.cert_stats()
+    extra = max(0, want_samples - samples_timed.size)
+    samples_extra = np.zeros(0)
+    if extra:
+        timer.match_profile(enable=1, reset=True)
+        est.iterate(it, extra)
+        it += extra
+        samples_extra = timer.match_samples()
+    timer.match_profile(enable=False, reset=True)
+    samples = np.concatenate([samples_timed, samples_extra])
     event_pair_ms = timer.event_overhead(64)  # an empty event pair on the same stream: the markers' share of a timed submission
 
     A, t, c, _ = est.get_transform()
@@ -442,14 +654,16 @@ def main():
     else:
         rows = row[None]
 
+    out = None
     if rank == 0:
         total_pairs = args.steps * n_pairs_step * world
         value = total_pairs / dt
-        # a timed submission = one HIP-event pair for the launch(es) serving BOTH directions; launches counts directions.
-        # The steady state's single kernel carries its two events itself (hipExtLaunchKernelGGL: the kernel's own start
-        # and end timestamps, what rocprofv3 reports under profiles/); submissions of several kernels are bracketed by
-        # two recorded events, whose marker packets add ~2 us (an empty pair alone reads event_pair_ms).
-        k1_ms = match_ms / max(match_launches, 1)
+        # a timed submission = one HIP-event pair for the launch(es) serving BOTH directions.  The steady state's single
+        # kernel carries its two events itself (hipExtLaunchKernelGGL: the kernel's own start and end timestamps, what
+        # rocprofv3 reports under profiles/); submissions of several kernels are bracketed by two recorded events, whose
+        # marker packets add ~2 us (an empty pair alone reads event_pair_ms).
+        st = sample_stats(samples, 2)
+        k1_ms = st["median_ms"] if st else 0.0
         n_dir = n_pairs_step // 2
         k1_bytes = n_dir * K1_BYTES_PER_PAIR_FIXED + 24.0 * n  # per launch: n_dir queries vs one n-point cloud
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
@@ -472,22 +686,25 @@ def main():
             "config": {"workload": f"{n}x{n} synthetic 3-D features, symmetric ICP "
                                    "(rrl_estimation_symmetric_ICP_matching_all<3,12>), finest-level iteration, "
                                    f"{n_pairs_step} matched pairs per step per GPU",
+                       "regime": "steady: the estimate has converged when the timed steps start (the transform no longer moves and K1's "
+                                 "certificate skips nearly every search); see regimes / moving_transform / schedule for the other two",
                        "nn": args.nn, "schedule_iterations_before_timing": schedule_iters,
                        "parallelism": f"{world} independent problem(s), one per GPU; one all_gather of the final transforms"},
             "repetitions": reps, "seconds_all": times, "code_sha": code_stamp(),
             "roofline": {"bound": "hbm",
-                         "kernel": ("K1 find_closest_euclidean at the finest level = k_match_cert_inline2 (certificate pass whose wavefronts "
-                                    "also search the few sources that fail it; k_match_cert2 + k_match_list2 + k_match_hard2 while the lists are "
-                                    "long): one launch serves the forward and the backward search (lrr_icp_match_pair); kernel_ms = HIP-event "
-                                    "time of that launch (events attached to the launch itself) / 2 = one direction"
-                                    if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
+                         "kernel": ("K1 find_closest_euclidean at the finest level, steady state = k_match_cert_inline2 (certificate pass whose wavefronts "
+                                    "also search the few sources that fail it): one launch serves the forward and the backward search "
+                                    "(lrr_icp_match_pair); kernel_ms = MEDIAN HIP-event time of that launch (events attached to the launch itself) / 2 "
+                                    "= one direction" if args.nn == "grid" else "K1 find_closest_euclidean = k_match_brute + k_brute_merge"),
                          "event_pair_ms": event_pair_ms, "timed_every": k1_sample,
+                         "samples": {"per_direction": st, "in_timed_region": int(samples_timed.size), "in_sampling_pass": int(samples_extra.size),
+                                     "timed_region_only": sample_stats(samples_timed, 2)},
                          "valu_frac": valu_frac,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_GBs": (traffic / (k1_ms * 1e-3) / 1e9) if (traffic and k1_ms > 0) else None,
                          "traffic_frac": (traffic / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k1_ms > 0) else None,
-                         "kernel_ms": k1_ms, "launches": match_launches,
+                         "kernel_ms": k1_ms, "launches": int(samples.size),
                          "certificate": {"queries": cert_seen, "searched": cert_searched,
                                          "skipped_frac": (1.0 - cert_searched / cert_seen) if cert_seen else None},
                          "algorithmic_bytes_per_launch": k1_bytes,
@@ -496,18 +713,47 @@ def main():
             "upload_s": upload_s,
             "final_weighted_error": float(rows[0, 17]),
         }
-        if world == 1 and not args.no_schedule:
+    # the other two regimes of the same workload, the production matcher's semantics, the CPU beside them (one GPU only)
+    if world == 1:
+        if not args.no_moving and args.nn == "grid":
+            out["moving_transform"] = moving_transform(est, E, pair, timer, 5)
+        if not args.no_schedule:
             out["schedule"] = schedule_run(E, pair, T0, nn, timer)
+            sc = out["schedule"]
+            sc["value"] = sc["matched_pairs"] / (sc["run_call_ms"] * 1e-3)
+            sc["unit"] = "pairs/s"
+        out["regimes"] = {
+            "unit": "pairs/s",
+            "steady_converged": value,
+            "moving_transform_finest_level": out.get("moving_transform", {}).get("value"),
+            "whole_schedule_run_call": out.get("schedule", {}).get("value"),
+            "note": "steady = `value` (every timed step is past convergence); moving = set_transform(perturbed) at the finest level, "
+                    "iterated to convergence; whole schedule = the faithful 1000 -> N run() a caller of the class makes"}
+        if not args.no_voronoi and args.nn == "grid":
+            out["voronoi"] = voronoi_gpu(E, pair, T0, timer, min(args.steps, 50), 3)
+    est.close()
+    # config 5 beside it: every rank takes its block of the query locations (the driver's --gpus N run then measures it too)
+    if not args.no_locations and args.nn == "grid":
+        rec = locations_measure(args, rank, local_rank, world)
+        if rank == 0:
+            for k in ("metric", "higher_is_better", "vs_baseline", "dtype", "data", "warmup"):
+                rec.pop(k, None)
+            out["locations"] = rec
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pair, T0, n, args.cpu_iters)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"]["compared_with"] = ("`value` is the steady regime; the CPU path's cost does not depend on the regime — the "
+                                                    "ratios against the other two regimes are speedup_vs_cpu_1thread_by_regime")
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_1thread_by_regime"] = {k: (v / out["cpu_baseline"]["value"] if v else None)
+                                                        for k, v in out["regimes"].items() if k not in ("unit", "note")}
         print(json.dumps(out))
-    est.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

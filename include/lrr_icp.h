@@ -365,6 +365,11 @@ int  lrr_icp_cdc_normalize_stats(lrr_icp_cdc_set *set, lrr_icp_norm *out);
 int  lrr_icp_cdc_objective_cov(lrr_icp_cdc_set *set, const lrr_icp_xform *x, int dof, const double *x_upper,
                                const lrr_icp_norm *norm, double *f, double *g, int64_t *pairs);
 
+/* test hook (no reference counterpart): overwrites the stored match of from-feature from_idx (original index) with `value`
+ * as it is — also a value outside the to-cloud, which K1 never writes: the residual passes of the estimate that follows
+ * must answer with LRR_ICP_ERR_STATE ("match index out of range") instead of gathering from a wild address */
+int  lrr_icp_debug_set_match(lrr_icp_dir *dir, int64_t from_idx, int64_t value);
+
 /* stand-alone exact nearest neighbour of host query points (tests, diagnostics) */
 int  lrr_icp_nearest(lrr_icp_cloud *cloud, const double *query, int64_t nq, int method, int64_t *idx);
 

@@ -148,6 +148,7 @@ struct est_base {
   virtual int64_t number_points(int dir) = 0;
   virtual double last_scale(int dir) = 0;
   virtual void normal_equations(double *AtA, double *Atb) = 0;
+  virtual lrr_icp_dir *device_dir(int dir) = 0;
 };
 
 template <class Dir>
@@ -212,6 +213,7 @@ struct fwd_impl : est_base {
   int64_t number_points(int) override { return e->number_points(); }
   double last_scale(int) override { return e->last_scale(); }
   void normal_equations(double *AtA, double *Atb) override { e->last_normal_equations(AtA, Atb); }
+  lrr_icp_dir *device_dir(int) override { return e->device_dir(); }
 };
 
 template <unsigned DOF, class F, class Est>
@@ -276,6 +278,7 @@ struct sym_impl : est_base {
   int64_t number_points(int dir) override { return d(dir).number_points(); }
   double last_scale(int dir) override { return d(dir).last_scale(); }
   void normal_equations(double *AtA, double *Atb) override { e->forward().last_normal_equations(AtA, Atb); }
+  lrr_icp_dir *device_dir(int dir) override { return d(dir).device_dir(); }
 };
 
 template <class Fn>
@@ -378,6 +381,8 @@ int64_t lrr_est_num_matches(lrr_est *e, int dir) { int64_t n = 0; guard([&] { n 
 int lrr_est_get_matches(lrr_est *e, int dir, int64_t *f, int64_t *t, double *w) { return guard([&] { E(e)->get_matches(dir, f, t, w); }); }
 int64_t lrr_est_get_number_points(lrr_est *e, int dir) { int64_t n = 0; guard([&] { n = E(e)->number_points(dir); }); return n; }
 int lrr_est_last_scale(lrr_est *e, int dir, double *out) { return guard([&] { *out = E(e)->last_scale(dir); }); }
+// the device state of one direction (C-ABI handle: tests reach the lrr_icp_* diagnostics with it)
+lrr_icp_dir *lrr_est_device_dir(lrr_est *e, int dir) { return E(e)->device_dir(dir); }
 int lrr_est_last_normal_equations(lrr_est *e, double *AtA, double *Atb) { return guard([&] { E(e)->normal_equations(AtA, Atb); }); }
 
 

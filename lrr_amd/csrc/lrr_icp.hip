@@ -2305,6 +2305,19 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   return LRR_ICP_OK;
 }
 
+// test hook: the stored match of from-feature `from_idx` becomes `value` as it is (also outside the to-cloud)
+int lrr_icp_debug_set_match(lrr_icp_dir *d, int64_t from_idx, int64_t value) {
+  if (!d || from_idx < 0 || from_idx >= d->from->n) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int s = 0;
+  HIPCHK(ctx, hipMemcpy(&s, d->from->canon_of + from_idx, sizeof(int), hipMemcpyDeviceToHost));
+  const int v = (int)value;
+  HIPCHK(ctx, hipMemcpy(d->m_to + s, &v, sizeof(int), hipMemcpyHostToDevice));
+  return LRR_ICP_OK;
+}
+
 int lrr_icp_cloud_set_shapes(lrr_icp_cloud *c, const uint8_t *shape, const uint8_t *ndirs, const double *dirs6) {
   if (!c || (c->n > 0 && (!shape || !ndirs || !dirs6))) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = c->ctx;

@@ -33,7 +33,7 @@ ICP_SYMBOLS = [
     "lrr_icp_normalize_stats", "lrr_icp_normalize_stats_merged", "lrr_icp_clone_weights", "lrr_icp_weight_by_strength",
     "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_errors_launch", "lrr_icp_errors_collect", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_cloud_set_shape_vectors", "lrr_icp_angles", "lrr_icp_angles_unmapped", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
-    "lrr_icp_nearest", "lrr_icp_cloud_set_covariances", "lrr_icp_cdc_compute_weights",
+    "lrr_icp_nearest", "lrr_icp_debug_set_match", "lrr_icp_cloud_set_covariances", "lrr_icp_cdc_compute_weights",
     "lrr_icp_cdc_set_create", "lrr_icp_cdc_set_destroy", "lrr_icp_cdc_set_compute_weights", "lrr_icp_cdc_set_get", "lrr_icp_cdc_objective_par", "lrr_icp_cdc_objective_cov", "lrr_icp_cdc_normalize_stats",
     "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
     "lrr_icp_batch_match", "lrr_icp_batch_estimate", "lrr_icp_batch_errors", "lrr_icp_batch_angles", "lrr_icp_batch_iterate",
@@ -601,6 +601,15 @@ class Estimator:
 
     def number_points(self, direction=0):
         return est_lib().lrr_est_get_number_points(self._h, direction)
+
+    def debug_set_match(self, direction, from_idx, value):
+        """test hook (lrr_icp_debug_set_match): the stored match of from-feature from_idx becomes `value` as it is"""
+        L, H = est_lib(), hip_lib()
+        L.lrr_est_device_dir.restype = C.c_void_p
+        L.lrr_est_device_dir.argtypes = [C.c_void_p, C.c_int]
+        H.lrr_icp_debug_set_match.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+        if H.lrr_icp_debug_set_match(L.lrr_est_device_dir(self._h, direction), int(from_idx), int(value)) != 0:
+            raise RuntimeError("lrr_icp_debug_set_match failed")
 
     def normal_equations(self):
         AtA, Atb = np.empty((self.dof, self.dof)), np.empty(self.dof)

@@ -300,6 +300,12 @@ class OracleEstimator:
     def set_number_points(self, n):
         lib().lrr_oracle_set_number_points(self._h, int(n))
 
+    def set_subset_seed(self, seed):
+        L = lib()
+        L.lrr_oracle_set_subset_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.lrr_oracle_set_subset_seed.restype = None
+        L.lrr_oracle_set_subset_seed(self._h, int(seed))
+
     def inject_initial_scale(self, fwd, bwd=-1.0):
         lib().lrr_oracle_inject_initial_scale(self._h, float(fwd), float(bwd))
 

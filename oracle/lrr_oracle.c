@@ -2003,6 +2003,14 @@ void lrr_oracle_set_features(lrr_oracle_est *e, const lrr_oracle_features *movin
   }
 }
 
+/* test hook (as the product's set_subset_seed): restarts the generators of the subset permutations, so that one estimator
+ * object re-used over many query locations (set_features + set_transform, rrl/itkLocationRegistration.cxx:1635-1637) gives
+ * every location the keys a freshly built estimator with that seed would use */
+void lrr_oracle_set_subset_seed(lrr_oracle_est *e, uint64_t seed) {
+  e->fwd->rng = seed;
+  if (e->bwd) e->bwd->rng = seed ^ 0xD1B54A32D192ED03ULL;
+}
+
 void lrr_oracle_weight_by_strength(lrr_oracle_est *e, int flag) {
   e->fwd->weight_by_strength = flag;
   if (e->bwd) e->bwd->weight_by_strength = flag;

@@ -67,6 +67,7 @@ void lrr_oracle_weight_by_strength(lrr_oracle_est *e, int flag);
 void lrr_oracle_normalize_matches(lrr_oracle_est *e);
 /* test hooks: not in the reference */
 void lrr_oracle_set_number_points(lrr_oracle_est *e, int64_t n);          /* protected in the reference */
+void lrr_oracle_set_subset_seed(lrr_oracle_est *e, uint64_t seed);        /* restart the subset-permutation generators */
 void lrr_oracle_inject_initial_scale(lrr_oracle_est *e, double fwd, double bwd); /* bypass MUSE; <=0 disables */
 void lrr_oracle_set_subset_order(lrr_oracle_est *e, int dir, const int64_t *order, int64_t n); /* explicit permutation for the next match */
 

@@ -229,6 +229,60 @@ def test_device_loop_equals_host_loop(E, monkeypatch):
             assert np.abs(a - h).max() <= 1e-9 * max(1.0, np.abs(h).max()), name
 
 
+def test_config5_full_size_against_oracle(E, ob):
+    """config 5 at its BASELINE size on one GPU: 256 query locations x a 200k-feature volume pair through the path bench.py
+    times (locations.register_locations: one batch, the caller's loop on the device, decision measurements), every
+    location against the CPU oracle driven as the reference's caller drives its estimator (one object, set_features +
+    set_transform per location, one_iteration until converged / 70): flags, iteration counts and matched-pair counts
+    exactly, final match sets of both lists exactly, transforms to 1e-6 (north star: 1e-4), errors to 1e-6."""
+    from lrr_amd import locations
+    n, nloc, seed = 200000, 256, 20245  # bench.py's workload (locations_measure)
+    pair = synth.make_pair(n, n, seed, kind="affine")
+    rois = synth.query_rois(pair, nloc, seed, half=25.0)
+    inits = [synth.perturbed(pair.planted, 1000 + i) for i in range(len(rois))]
+    assert len(rois) == nloc
+    bt = E.LocationBatch(pair.moving, pair.fixed)
+    rows, pairs = locations.register_locations(pair, rois, inits, batch=bt, seed=7)
+    C = bt.COL
+    assert rows.shape[0] == nloc and rows[:, C["enough_features"]].all()
+    assert int(rows[:, C["matched_pairs"]].sum()) == pairs
+    o = None
+    worst_A = worst_t = 0.0
+    for b, (_, _, mi, fi) in enumerate(rois):
+        m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[b]
+        assert int(rows[b, C["n_moving_inside"]]) == mi.size and int(rows[b, C["n_fixed_inside"]]) == fi.size, b
+        if o is None:
+            o = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in, seed=1)
+        o.set_features(m_in, f_in)
+        o.set_transform(T0.A, T0.t, T0.c)
+        o.set_subset_seed(locations.location_seed(7, b))
+        # the caller's loop, counting the pairs it forms
+        conv, it, npairs = False, 0, 0
+        while not conv and it < locations.MAX_ITERATIONS:
+            npairs += o.number_points(0) + o.number_points(1)
+            conv = o.one_iteration(it)
+            it += 1
+        assert bool(rows[b, C["converged"]]) == conv and int(rows[b, C["iterations"]]) == it, (b, conv, it, rows[b, :2])
+        assert int(rows[b, C["matched_pairs"]]) == npairs, b
+        assert bool(rows[b, C["valid"]]) and bool(rows[b, C["oscillated"]]) == o.oscillated(), b
+        Ao, to, co, _ = o.get_transform()
+        worst_A = max(worst_A, rel(rows[b, C["A"]].reshape(3, 3), Ao))
+        worst_t = max(worst_t, rel(rows[b, C["t"]], to))
+        assert rel(rows[b, C["A"]].reshape(3, 3), Ao) < 1e-6 and rel(rows[b, C["t"]], to) < 1e-6, b
+        assert abs(rows[b, C["weighted_error"]] - o.weighted_error()) <= 1e-6 * max(1.0, o.weighted_error()), b
+        for d in (0, 1):
+            fb, tb, wb = bt.matches(b, d)
+            fo, to_, wo = o.matches(d)
+            assert np.array_equal(fb, fo) and np.array_equal(tb, to_), (b, d)
+            # (weights: the batch's lists carry the re-weighting of estimate_LS_backward(false), the decision measurements' last step)
+    o.close()
+    bt.close()
+    its = rows[:, C["iterations"]]
+    assert its.min() >= 2 and np.unique(its).size >= 5  # locations stop at different iterations
+    print(f"config 5 full size: {nloc} locations, {pairs} matched pairs, iterations {int(its.min())}..{int(its.max())}, "
+          f"worst relative difference A {worst_A:.2e} t {worst_t:.2e}")
+
+
 def test_device_loop_many_locations(E, monkeypatch):
     """300 locations in one batch (more than one round of the per-location kernels; every fifth ROI holds fewer than
     1000 features and never runs, the rest converge at different iterations, so the chain of launches runs with a

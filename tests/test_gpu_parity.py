@@ -129,6 +129,74 @@ def test_bad_input_fails_loudly(E):
     e.close()
 
 
+@pytest.mark.parametrize("kind_name,bad", [("RRL_SYMMETRIC", -1), ("RRL_SYMMETRIC", 10**9), ("CDCL_FORWARD", -1)])
+def test_wild_match_index_is_an_error_not_a_fault(E, kind_name, bad):
+    """Round 2 lost a GPU box to a work-in-progress search that left -1 in m_to: the residual pass then gathered
+    to_rec[-1 * 10], below the cloud's slab.  K1 writes a valid index for every active source; should a
+    phase ever leave one unserved, the estimate must answer with an error: a match index outside the to-cloud is
+    planted through the test hook, the estimate fails with the library's message, and the estimator works again after
+    the next search."""
+    pair = synth.make_pair(3000, 3000, 31, kind="affine")
+    T0 = synth.perturbed(pair.planted, 2)
+    kind = getattr(E, kind_name)
+    sym = kind >= 2
+    e = E.Estimator(kind, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=pair.moving if sym else None,
+                    fixed_inside=pair.fixed if sym else None, seed=3)
+    e.find_closest_euclidean()
+    f, _, _ = e.matches(0)
+    e.debug_set_match(0, int(f[len(f) // 2]), bad)
+    with pytest.raises(RuntimeError, match="outside the to-cloud"):
+        e.estimate_LS(True)
+    e.set_transform(T0.A, T0.t, T0.c)
+    for it in range(3):
+        e.one_iteration(it)  # searches again: every stored index is valid again
+    assert np.isfinite(e.weighted_error())
+    e.close()
+
+
+def test_first_search_of_rois_at_the_volume_border(E, ob):
+    """First search of query locations whose ROIs hang over the border of the volume (the cells of the search grid there
+    are empty and the query's own row ends at the grid's edge: the re-seed of the ball search reads `cell_start` at the
+    clamped ends of the row and falls through to the wave-per-query phase when nothing bounds it).  Batch rows against
+    the oracle: the first iteration's match sets exactly."""
+    from lrr_amd import locations
+    pair = synth.make_pair(60000, 60000, 20260, kind="affine")
+    lo, hi = pair.fixed.loc.min(0), pair.fixed.loc.max(0)
+    half = 45.0
+    # centres ON the corners / faces of the bounding box: up to 7/8 of a box is outside the volume
+    cents = np.array([lo, hi, [lo[0], hi[1], 0.5 * (lo[2] + hi[2])], [0.5 * (lo[0] + hi[0]), lo[1], hi[2]], [hi[0], 0.5 * (lo[1] + hi[1]), lo[2]]])
+    Ti = pair.planted.inverse()
+    rois = []
+    for cf in cents:
+        cm = Ti.map(cf[None])[0]
+        rois.append((cf, cm, pair.moving.in_box(cm - half, cm + half), pair.fixed.in_box(cf - half, cf + half)))
+    assert all(r[2].size >= 1000 and r[3].size >= 1000 for r in rois), [(r[2].size, r[3].size) for r in rois]
+    # a start a few millimetres off: first searches without a previous match, many queries mapped outside the grid
+    inits = [synth.perturbed(pair.planted, 40 + i, rot_deg=2.0, trans_mm=6.0) for i in range(len(rois))]
+    mbox, fbox = locations.roi_boxes(rois, half)
+    seeds = np.array([locations.location_seed(5, i) for i in range(len(rois))], dtype=np.uint64)
+    bt = E.LocationBatch(pair.moving, pair.fixed)
+    A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
+    for max_it in (1, 4):
+        rows = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=max_it, diagnostics=False)
+        C = bt.COL
+        for b, (_, _, mi, fi) in enumerate(rois):
+            T0 = inits[b]
+            o = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=pair.moving.subset(mi),
+                                   fixed_inside=pair.fixed.subset(fi), seed=int(seeds[b]))
+            for it in range(max_it):
+                o.one_iteration(it)
+            assert int(rows[b, C["iterations"]]) == max_it
+            for d in (0, 1):
+                fb, tb, _ = bt.matches(b, d)
+                fo, to_, _ = o.matches(d)
+                assert np.array_equal(fb, fo) and np.array_equal(tb, to_), (max_it, b, d)
+            Ao, to, _, _ = o.get_transform()
+            assert rel(rows[b, C["A"]].reshape(3, 3), Ao) < 1e-6 and rel(rows[b, C["t"]], to) < 1e-6, (max_it, b)
+            o.close()
+    bt.close()
+
+
 # ---- golden fixtures ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 @pytest.mark.parametrize("method", ["grid", "brute"])

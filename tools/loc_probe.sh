@@ -2,6 +2,8 @@
 # locations workload: batch tests, phase timing, per-dispatch series of the batch kernels; $1 = tag
 out=gpurun_out/$1
 mkdir -p $out
+# which code these outputs belong to (.git does not travel to the GPU box): sha256 of the kernel sources + the time
+( cd ${GRAFT_REPO_ROOT:-.} && echo "code_sha $(python bench.py --code-stamp) $(date -u +%FT%TZ) $0 $*" ) > $out/code_stamp.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 600 python -m pytest tests/test_gpu_batch.py -m gpu -x -q > $out/tests.log 2>&1 || { tail -20 $out/tests.log; exit 1; }
 LRR_BATCH_TIMING=1 timeout -k 10 300 python bench.py --workload locations > $out/loc.json 2> $out/loc.err || exit 1
