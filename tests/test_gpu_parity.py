@@ -160,10 +160,11 @@ def test_first_search_of_rois_at_the_volume_border(E, ob):
     clamped ends of the row and falls through to the wave-per-query phase when nothing bounds it).  Batch rows against
     the oracle: the first iteration's match sets exactly."""
     from lrr_amd import locations
-    pair = synth.make_pair(60000, 60000, 20260, kind="affine")
+    pair = synth.make_pair(120000, 120000, 20260, kind="affine")
     lo, hi = pair.fixed.loc.min(0), pair.fixed.loc.max(0)
-    half = 45.0
+    half = 90.0
     # centres ON the corners / faces of the bounding box: up to 7/8 of a box is outside the volume
+    lo, hi = lo + 30.0, hi - 30.0  # (the outermost 30 mm hold only the scene's outliers: a box centred 30 mm inside still hangs 60 mm over the border)
     cents = np.array([lo, hi, [lo[0], hi[1], 0.5 * (lo[2] + hi[2])], [0.5 * (lo[0] + hi[0]), lo[1], hi[2]], [hi[0], 0.5 * (lo[1] + hi[1]), lo[2]]])
     Ti = pair.planted.inverse()
     rois = []
