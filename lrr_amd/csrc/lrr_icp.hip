@@ -1466,8 +1466,8 @@ int64_t lrr_icp_subset_perm(int64_t i, int64_t n, const uint32_t keys[4]) {
 // one launch): a quarter of the cloud or more, and — above what the coarse pair path takes — an eighth: a source without
 // a previous match is bounded by a point of its own cell (ball_search), so a grown subset needs no search from scratch,
 // and the thread-per-slot path it would take otherwise forks and joins two streams (32000 of 200k: 72 -> 45 us per direction).
-constexpr int64_t kCoarseMax = 16384;
-inline bool dense_level(int64_t n_points, int64_t N) { return n_points * 4 >= N || (n_points > kCoarseMax && n_points * 8 >= N); }
+constexpr int64_t kCoarseMax = 8192;  // (16384: the wave-per-query kernel took 51 us for 2 x 16000 queries, the thread-per-source search of that level 37 + 10)
+inline bool dense_level(int64_t n_points, int64_t N) { return n_points * 4 >= N || (n_points > kCoarseMax && n_points * 16 >= N); }
 
 struct MatchPrep {
   Keys kk;
@@ -1487,6 +1487,33 @@ struct MatchPrep {
   lrr_icp_xform prev_xf;  // transform of that search
   int method = LRR_ICP_NN_GRID;
 };
+
+// Is the certificate pass worth running?  It settles a source when (distance to the previous match) + u < bound, u = how far
+// the new transform moves the mapped source; the bound exceeds the previous distance by the gap to the second neighbour,
+// at most kBallMarginCells h (what the ball search covers beyond its best).  While a run still moves (u of that order or
+// more) nearly every certificate fails and the failures are searched through a list — certificate + list + wave-per-query
+// kernels then cost twice a plain ball search of everything (r03_h: 55-86 against 32 us per direction at 200k).  Decided
+// from what the host knows: how many sources the last certificate pass listed, and how far the transform has moved since the
+// bounds were written (the largest displacement over the corners of the from-cloud's grid).
+static bool certificate_pays(const lrr_icp_dir *d, const lrr_icp_xform *xf, int64_t N) {
+  static const bool always = std::getenv("LRR_ICP_CERT_ALWAYS") != nullptr;
+  if (always) return true;
+  if (d->last_list_count >= 0 && d->last_list_count * 8 > N) return false;  // an eighth of the cloud failed last time
+  const lrr_icp_cloud *c = d->from;
+  const lrr_icp_xform &p = d->prev_xf;
+  double umax = 0.0;
+  for (int k = 0; k < 8; ++k) {
+    const double x[3] = {c->lo[0] + ((k & 1) ? c->dim[0] * c->h : 0.0), c->lo[1] + ((k & 2) ? c->dim[1] * c->h : 0.0), c->lo[2] + ((k & 4) ? c->dim[2] * c->h : 0.0)};
+    double u2 = 0.0;
+    for (int r = 0; r < 3; ++r) {
+      double a = xf->t[r], b = p.t[r];
+      for (int q = 0; q < 3; ++q) { a += xf->A[3 * r + q] * (x[q] - xf->c[q]); b += p.A[3 * r + q] * (x[q] - p.c[q]); }
+      u2 += (a - b) * (a - b);
+    }
+    umax = std::max(umax, std::sqrt(u2));
+  }
+  return umax <= (double)kBallMarginCells * d->to->h;
+}
 
 // argument checks, capacities, explicit order upload, counters: everything before the launches.
 // Work is queued on `st`; scratch comes from lane L.
@@ -1558,6 +1585,7 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   // search covered every source (n_points == N twice in a row)
   static const bool no_cert = std::getenv("LRR_ICP_NO_CERT") != nullptr;
   P.cert = P.steady && n_points == N && d->have_bounds && !no_cert;
+  if (P.cert && !certificate_pays(d, xf, N)) P.cert = false;  // (the plain ball search leaves fresh bounds: the next search may certify again)
   P.prev_xf = d->prev_xf;
   // the ball kernels (with or without certificate) leave bounds; the wave-per-query kernel leaves one for a source it
   // settles through its previous match and 0 (= search next time) for one it serves without.  Not after a growth

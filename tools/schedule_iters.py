@@ -10,7 +10,7 @@ def main():
     nit = int(sys.argv[2]) if len(sys.argv) > 2 else 27
     acc = [i for i, r in enumerate(rows) if 'k_f_accumulate' in r['kernel']]
     i = acc[-nit]
-    firsts = ('k_slots_coarse2', 'k_match_ball2', 'k_match_cert', 'k_match_tile', 'k_match_direct')
+    firsts = ('k_slots_coarse2', 'k_match_ball2', 'k_match_cert', 'k_match_tile', 'k_match_direct', 'k_knn_cert')
     while not any(f in rows[i]['kernel'] for f in firsts):
         i -= 1
     out, cur = [], []
