@@ -9,14 +9,18 @@
 //   cdcl_estimation_em    compute_weights / estimate_parameters / estimate_covariance / one_iteration of
 //       cdcl_estimation<3,12> (cdcl/cdcl_estimation.txx:95-187, 210-338, 342-545)
 //
-// Not provided: the ICP base class that initialises the reference's estimator (cdcl_estimation_ICP: the caller passes an
-// initial transform with its covariance), resolution switching inside compute_weights, and the rigid small-angle
-// increment (its pre-mapped feature copies, :118-141): the affine transform only.
+// Affine (dof 12) and rigid with the small-angle increment (dof 6: pre-mapped feature copies, recompose_increment, the second
+// compute_weights on the global transform, :111-182), resolution switching inside compute_weights with the statistic and
+// the restart's from_weights quirk (:356-358, 491-517), the closest-point fallback (:543-544), cdcl_lbfgs' 5 % stop.
+// Not provided: the ICP base class that initialises the reference's estimator (cdcl_estimation_ICP::estimate_LS for the
+// initial covariance, the subsampled pyramid itself): the caller passes the clouds of every resolution and an initial
+// transform with its covariance.
 #ifndef LRR_AMD_CDCL_ESTIMATION_H_
 #define LRR_AMD_CDCL_ESTIMATION_H_
 
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "lrr_amd/icp_engine.h"
@@ -27,16 +31,18 @@ namespace lrr_amd {
 // match rows of a moving / fixed pair, resident on the device
 class cdc_match_rows {
  public:
-  cdc_match_rows(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, int max_matches = 100) : set_(nullptr) {
+  cdc_match_rows(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, int max_matches = 100) : set_(nullptr), moving_(moving) {
     check(lrr_icp_cdc_set_create(moving, fixed, max_matches, &set_), "cdc_set_create");
   }
   ~cdc_match_rows() { if (set_) lrr_icp_cdc_set_destroy(set_); }
   cdc_match_rows(const cdc_match_rows &) = delete;
   cdc_match_rows &operator=(const cdc_match_rows &) = delete;
   lrr_icp_cdc_set *handle() const { return set_; }
+  lrr_icp_cloud *moving() const { return moving_; }
 
  private:
   lrr_icp_cdc_set *set_;
+  lrr_icp_cloud *moving_;
 };
 
 // (cdcl/cdcl_obj_fun_par.h:24-52) constructor: matches + transform (its centre and covariance enter J_th C_theta J_th^T);
@@ -46,7 +52,7 @@ class cdcl_obj_fun_par {
  public:
   cdcl_obj_fun_par(cdc_match_rows const &rows, typename cdcl_trans<dim, dof>::sptr const &trans, const lrr_icp_norm *norm)
       : rows_(rows), trans_(trans), norm_(norm ? *norm : lrr_icp_norm()), has_norm_(norm != nullptr) {
-    static_assert(dim == 3 && dof == 12, "the affine transform in 3-D");
+    static_assert(dim == 3 && (dof == 12 || dof == 6), "affine or rigid transform in 3-D");
     vnl_matrix_fixed<double, dof, dof> const &C = trans_->get_covariance();
     for (unsigned i = 0; i < dof; ++i) for (unsigned j = 0; j < dof; ++j) covar_[i * dof + j] = C(i, j);
   }
@@ -78,7 +84,7 @@ class cdcl_obj_fun_cov {
  public:
   cdcl_obj_fun_cov(cdc_match_rows const &rows, typename cdcl_trans<dim, dof>::sptr const &trans, const lrr_icp_norm *norm)
       : rows_(rows), trans_(trans), norm_(norm ? *norm : lrr_icp_norm()), has_norm_(norm != nullptr) {
-    static_assert(dim == 3 && dof == 12, "the affine transform in 3-D");
+    static_assert(dim == 3 && (dof == 12 || dof == 6), "affine or rigid transform in 3-D");
   }
   void compute(const vnl_vector<double> &x, double *f, vnl_vector<double> *g) {
     const unsigned ncov = dof * (dof + 1) / 2;
@@ -143,40 +149,113 @@ class cdcl_lbfgs {
   lrr_lbfgs_result res_;
 };
 
-// The EM loop of cdcl_estimation<3,12> around the device pieces.  moving / fixed: device clouds with covariances
-// (lrr_icp_cloud_set_covariances); trans: the affine transform with its covariance, modified in place as the reference's
-// estimator modifies the caller's transform object.
-class cdcl_estimation_em {
+// The EM loop of cdcl_estimation<3, dof> around the device pieces (cdcl/cdcl_estimation.txx:95-187, 210-338, 342-545), for the
+// affine transform (dof 12) and for the rigid one with its small-angle increment (dof 6), at one resolution or over a
+// multi-resolution pyramid (the second constructor of the reference, cdcl/cdcl_estimation.txx:54-63).
+//   moving / fixed: device clouds with covariances (lrr_icp_cloud_set_covariances), [0] the finest resolution;
+//   fixed_spacing[r]: the point spacing of fixed[r] the resolution switch compares with (cdcl_estimation.txx:503-517);
+//   trans: the transform with its covariance, modified in place as the reference's estimator modifies the caller's object.
+// The estimator starts at the coarsest resolution (cdcl/cdcl_estimation_ICP.txx:118).
+template <unsigned dof>
+class cdcl_estimation_em_t {
  public:
-  static const unsigned dof = 12;
-  typedef cdcl_trans<3, 12>::sptr trans_sptr_type;
-  cdcl_estimation_em(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, trans_sptr_type const &trans, uint64_t seed = 1, int max_matches = 100)
-      : rows_(moving, fixed, max_matches), trans_(trans), seed_(seed), normalize_matches_(true), overflow_rows_(0) {
+  static_assert(dof == 6 || dof == 12, "rigid3d (6) or affine (12)");
+  typedef typename cdcl_trans<3, dof>::sptr trans_sptr_type;
+  cdcl_estimation_em_t(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, trans_sptr_type const &trans, uint64_t seed = 1, int max_matches = 100)
+      : trans_(trans), seed_(seed), normalize_matches_(true), overflow_rows_(0), res_(0), max_res_(0) {
+    rows_.push_back(std::unique_ptr<cdc_match_rows>(new cdc_match_rows(moving, fixed, max_matches)));
+    fixed_spacing_.push_back(1.0);  // (cdcl/cdcl_estimation_ICP.txx:84)
+    std::memset(&last_, 0, sizeof last_);
+  }
+  cdcl_estimation_em_t(std::vector<lrr_icp_cloud *> const &moving, std::vector<lrr_icp_cloud *> const &fixed, trans_sptr_type const &trans,
+                       std::vector<double> const &fixed_spacing, uint64_t seed = 1, int max_matches = 100)
+      : trans_(trans), seed_(seed), normalize_matches_(true), overflow_rows_(0), fixed_spacing_(fixed_spacing) {
+    const size_t levels = std::min(moving.size(), fixed.size());
+    if (levels == 0 || fixed_spacing.size() < levels) throw std::runtime_error("cdcl_estimation_em: empty pyramid or missing spacings");
+    for (size_t r = 0; r < levels; ++r) rows_.push_back(std::unique_ptr<cdc_match_rows>(new cdc_match_rows(moving[r], fixed[r], max_matches)));
+    res_ = max_res_ = (unsigned)levels - 1;  // set the coarsest resolution (cdcl/cdcl_estimation_ICP.txx:118)
     std::memset(&last_, 0, sizeof last_);
   }
   void normalize_matches(bool on = true) { normalize_matches_ = on; }
   trans_sptr_type get_transform() const { return trans_; }
-  cdc_match_rows const &rows() const { return rows_; }
+  cdc_match_rows const &rows() const { return *rows_[res_]; }
+  unsigned resolution() const { return res_; }
   int64_t overflow_rows() const { return overflow_rows_; }
+  int64_t matches_size() const { return matches_size_; }
+  bool used_closest_euclidean() const { return fell_back_; }
+  double avg_largest_eval() const { return avg_largest_eval_; }  // of the last pass of compute_weights (:491)
+  // resolution switches (to a finer, to a coarser level) since one_iteration() began
+  unsigned switches_down() const { return switches_down_; }
+  unsigned switches_up() const { return switches_up_; }
   struct step_info { double par_start, par_end, cov_start, cov_end; int par_code, cov_code, par_evals, cov_evals; };
   step_info const &last_step() const { return last_; }
 
-  // (cdcl/cdcl_estimation.txx:342-545, one resolution)
-  void compute_weights() {
-    lrr_icp_xform xf = xform();
-    uint32_t keys[4];
-    lrr_icp_perm_keys(&seed_, keys);
+  // (cdcl/cdcl_estimation.txx:342-545)  trans: the transform the features are mapped and the Jacobians taken with (default:
+  // trans_); the parameter covariance is trans_'s either way (transfer_covar, cdcl_estimation.h:96-98)
+  void compute_weights(bool resolution_switch_allowed = false, trans_sptr_type trans = trans_sptr_type()) {
+    if (!trans) trans = trans_;
+    lrr_icp_xform xf = xform(trans);
     double C[dof * dof];
     covariance(C);
-    check(lrr_icp_cdc_set_compute_weights(rows_.handle(), &xf, (int)dof, C, keys, &overflow_rows_), "cdc compute_weights");
+    std::vector<double> from_weights;  // (:356-358: declared outside the restart loop — a restart appends, it does not clear)
+    std::vector<int64_t> first_counts;
+    bool stop = false, not_restarted = true;
+    fell_back_ = false;
+    while (!stop) {
+      uint32_t keys[4];
+      lrr_icp_perm_keys(&seed_, keys);
+      // (rows with more candidates inside the radius than the device holds are an error: the reference has no cap)
+      check(lrr_icp_cdc_set_compute_weights(rows_[res_]->handle(), &xf, (int)dof, C, keys, nullptr), "cdc compute_weights");
+      overflow_rows_ = 0;
+      double eval_sum = 0.0;
+      check(lrr_icp_cdc_set_stats(rows_[res_]->handle(), &eval_sum, &matches_size_), "cdc statistics");
+      const double avg_largest_eval = eval_sum / (double)matches_size_;  // (:491; 0 matches: inf / nan, as the reference)
+      avg_largest_eval_ = avg_largest_eval;
+      const bool restart_pass = !not_restarted;
+      if (!restart_pass && rows_.size() > 1 && resolution_switch_allowed) {
+        // keep this pass's from_weights in match order: the second pass is normalised with them (see below)
+        const int64_t nm = lrr_icp_cloud_size(moving_of(res_));
+        std::vector<double> rs((size_t)nm);
+        std::vector<int64_t> rc((size_t)nm);
+        check(lrr_icp_cdc_set_row_sums(rows_[res_]->handle(), rs.data(), rc.data()), "cdc row sums");
+        for (int64_t i = 0; i < nm; ++i) if (rc[(size_t)i] > 0) from_weights.push_back(rs[(size_t)i]);
+      }
+      stop = true;
+      if (avg_largest_eval < 2.0 * fixed_spacing_[res_] && resolution_switch_allowed && not_restarted) {
+        if (res_ > 0) { --res_; stop = false; not_restarted = false; ++switches_down_; }
+      }
+      if (res_ + 1 <= max_res_ && avg_largest_eval > 2.0 * fixed_spacing_[res_ + 1] && resolution_switch_allowed && not_restarted) {
+        ++res_; stop = false; not_restarted = false; ++switches_up_;
+      }
+      if (stop && restart_pass && !from_weights.empty()) {
+        // match i of this pass takes from_weights[i]: an entry of the FIRST pass while there are any (:524-530 index the
+        // vector by the match's position; the restart appended this pass's sums behind the first pass's)
+        const int64_t nm = lrr_icp_cloud_size(moving_of(res_));
+        std::vector<double> rs((size_t)nm);
+        std::vector<int64_t> rc((size_t)nm);
+        check(lrr_icp_cdc_set_row_sums(rows_[res_]->handle(), rs.data(), rc.data()), "cdc row sums");
+        std::vector<double> all = from_weights;
+        for (int64_t i = 0; i < nm; ++i) if (rc[(size_t)i] > 0) all.push_back(rs[(size_t)i]);
+        size_t k = 0;
+        for (int64_t i = 0; i < nm; ++i) if (rc[(size_t)i] > 0) rs[(size_t)i] = all[k++];
+        check(lrr_icp_cdc_set_renormalize(rows_[res_]->handle(), rs.data()), "cdc renormalise");
+      }
+    }
+    // covariance is probably too small for any matches to be found, use closest points then (:543-544)
+    if (matches_size_ == 0) {
+      lrr_icp_xform own = xform(trans_);
+      check(lrr_icp_cdc_set_closest_euclidean(rows_[res_]->handle(), &own), "cdc closest points");
+      matches_size_ = lrr_icp_cloud_size(moving_of(res_));
+      fell_back_ = true;
+    }
   }
   // (:210-260)
   bool estimate_parameters() {
     lrr_icp_norm nm;
     normalize(nm);
-    cdcl_obj_fun_par<3, 12> f_par(rows_, trans_, normalize_matches_ ? &nm : nullptr);
+    cdcl_obj_fun_par<3, dof> f_par(*rows_[res_], trans_, normalize_matches_ ? &nm : nullptr);
     vnl_vector<double> x = trans_->get_parameterization(), x_old = x;
-    cdcl_lbfgs<cdcl_obj_fun_par<3, 12> > minimizer(f_par);
+    cdcl_lbfgs<cdcl_obj_fun_par<3, dof> > minimizer(f_par);
     minimizer.set_max_function_evals(5);
     bool converged = minimizer.minimize(x);
     bool parameters_converged = (minimizer.get_start_error() - minimizer.get_end_error()) < 1e-4;
@@ -191,7 +270,7 @@ class cdcl_estimation_em {
   bool estimate_covariance() {
     lrr_icp_norm nm;
     normalize(nm);
-    cdcl_obj_fun_cov<3, 12> f_cov(rows_, trans_, normalize_matches_ ? &nm : nullptr);
+    cdcl_obj_fun_cov<3, dof> f_cov(*rows_[res_], trans_, normalize_matches_ ? &nm : nullptr);
     const unsigned cov_dof = dof * (dof + 1) / 2;
     // upper triangular Cholesky factor of the covariance -> x (:283-293)
     double C[dof * dof], U[dof * dof];
@@ -206,7 +285,7 @@ class cdcl_estimation_em {
     unsigned ind = 0;
     for (unsigned d1 = 0; d1 < dof; ++d1) for (unsigned d2 = d1; d2 < dof; ++d2) x[ind++] = U[d1 * dof + d2];
     vnl_vector<double> x_old = x;
-    cdcl_lbfgs<cdcl_obj_fun_cov<3, 12> > minimizer(f_cov);
+    cdcl_lbfgs<cdcl_obj_fun_cov<3, dof> > minimizer(f_cov);
     minimizer.set_max_function_evals(5);
     bool converged = minimizer.minimize(x);
     bool covariance_converged = (minimizer.get_start_error() - minimizer.get_end_error()) < 1e-5;
@@ -221,16 +300,38 @@ class cdcl_estimation_em {
     last_.cov_code = minimizer.get_failure_code(); last_.cov_evals = minimizer.get_num_evaluations();
     return covariance_converged;
   }
-  // (:95-187) for the affine transform
+  // (:95-187)
   bool one_iteration(unsigned iteration) {
     const unsigned startEM = 5;
-    this->compute_weights();
+    const bool resolution_switch_allowed = iteration > startEM;
+    switches_down_ = switches_up_ = 0;
+    this->compute_weights(resolution_switch_allowed);
+    trans_sptr_type global_transform;
+    const bool rigid = is_rigid();
+    if (rigid) {  // from now on the transform is incremental (:111-141)
+      global_transform = trans_;
+      trans_ = trans_->create_new();  // identity
+      trans_->set_covariance(global_transform->get_covariance());
+      premap(global_transform);       // every matches_[i]->from_ becomes the copy at G(p) with covariance Jp C Jp^T
+      trans_->set_parameterization(vnl_vector<double>(dof, 0.0));
+    }
     bool parameters_converged = false, covariance_converged = false;
     if (iteration > startEM) {
       parameters_converged = this->estimate_parameters();
-      this->compute_weights();
+      if (rigid) {
+        global_transform->recompose_increment(trans_);                        // (:152)
+        this->compute_weights(resolution_switch_allowed, global_transform);   // (:153)
+        premap(global_transform);                                             // (:156-170)
+      } else {
+        this->compute_weights(resolution_switch_allowed);
+      }
     }
     covariance_converged = this->estimate_covariance();
+    if (rigid) {  // (:178-182)
+      global_transform->set_covariance(trans_->get_covariance());
+      trans_ = global_transform;
+      check(lrr_icp_cdc_set_premap(rows_[res_]->handle(), nullptr), "cdc premap");
+    }
     double fro = 0.0;
     vnl_matrix_fixed<double, dof, dof> const &C = trans_->get_covariance();
     for (unsigned i = 0; i < dof; ++i) for (unsigned j = 0; j < dof; ++j) fro += C(i, j) * C(i, j);
@@ -238,11 +339,17 @@ class cdcl_estimation_em {
   }
 
  private:
-  lrr_icp_xform xform() const {
+  bool is_rigid() const { return dof == 6 && trans_->is_type(cdcl_trans_rigid3d::type_id()); }
+  lrr_icp_cloud *moving_of(unsigned r) const { return rows_[r]->moving(); }
+  void premap(trans_sptr_type const &G) {
+    lrr_icp_xform g = xform(G);
+    check(lrr_icp_cdc_set_premap(rows_[res_]->handle(), &g), "cdc premap");
+  }
+  static lrr_icp_xform xform(trans_sptr_type const &T) {
     lrr_icp_xform x;
-    vnl_matrix_fixed<double, 3, 3> &A = trans_->get_A();
-    vnl_vector_fixed<double, 3> &t = trans_->get_translation();
-    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) x.A[3 * r + c] = A(r, c); x.t[r] = t[r]; x.c[r] = trans_->center_moving_[r]; }
+    vnl_matrix_fixed<double, 3, 3> &A = T->get_A();
+    vnl_vector_fixed<double, 3> &t = T->get_translation();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) x.A[3 * r + c] = A(r, c); x.t[r] = t[r]; x.c[r] = T->center_moving_[r]; }
     return x;
   }
   void covariance(double *C) const {
@@ -252,7 +359,7 @@ class cdcl_estimation_em {
   // cdcl_normalize_matches + trans_->normalize (:218-221); the features themselves are normalised on the fly by the kernels
   void normalize(lrr_icp_norm &nm) {
     if (!normalize_matches_) return;
-    check(lrr_icp_cdc_normalize_stats(rows_.handle(), &nm), "cdc normalize statistics");
+    check(lrr_icp_cdc_normalize_stats(rows_[res_]->handle(), &nm), "cdc normalize statistics");
     vnl_vector_fixed<double, 3> cm, cf;
     for (int d = 0; d < 3; ++d) { cm[d] = nm.cm[d]; cf[d] = nm.cf[d]; }
     trans_->normalize(nm.rm, nm.rf, cm, cf);
@@ -276,13 +383,21 @@ class cdcl_estimation_em {
     return true;
   }
 
-  cdc_match_rows rows_;
+  std::vector<std::unique_ptr<cdc_match_rows> > rows_;  // one set of match rows per resolution
   trans_sptr_type trans_;
   uint64_t seed_;
   bool normalize_matches_;
   int64_t overflow_rows_;
+  std::vector<double> fixed_spacing_;
+  unsigned res_, max_res_;
+  int64_t matches_size_ = 0;
+  bool fell_back_ = false;
+  double avg_largest_eval_ = 0.0;
+  unsigned switches_down_ = 0, switches_up_ = 0;
   step_info last_;
 };
+typedef cdcl_estimation_em_t<12> cdcl_estimation_em;
+typedef cdcl_estimation_em_t<6> cdcl_estimation_em_rigid;
 
 }  // namespace lrr_amd
 #endif

@@ -1,7 +1,7 @@
 /* lbfgs_standin.h — a small limited-memory BFGS minimiser in plain C (header-only), the stand-in for the optimiser the
  * reference calls through cdcl_lbfgs (cdcl/cdcl_lbfgs.h: a thin wrapper of vnl_lbfgs, i.e. netlib's LBFGS — third party,
  * absent here, "parity unpinned").  It is NOT a restatement of that routine: same family (two-loop recursion over the
- * last m = 5 curvature pairs, initial step 1 / |g|, Armijo backtracking), same contract as the caller uses it
+ * last m = 5 curvature pairs, initial step 1 / |g|, Armijo backtracking with safeguarded quadratic interpolation), same contract as the caller uses it
  * (cdcl/cdcl_estimation.txx:230-248, 298-311): a cap on function evaluations, the function value at the start and at the
  * end, a return code that is negative only when no descent step was found at all, and (lrr_lbfgs_minimize_stop) the 5 %
  * stopping rule that is the one thing cdcl_lbfgs adds to vnl_lbfgs.
@@ -97,7 +97,17 @@ static inline lrr_lbfgs_result lrr_lbfgs_minimize_stop(int n, double *x, lrr_lbf
       fg(user, xt, &ft, gt);
       ++R.evals;
       if (ft == ft && ft <= f + c1 * step * gd) { accepted = 1; break; }
-      step *= 0.5;
+      /* next trial: the minimiser of the parabola through f, its slope gd and ft, kept inside [0.05, 0.5] step (the
+       * safeguarded interpolation every line search of this family uses; a plain halving needs more trials than the five
+       * evaluations the caller allows when the first step 1 / |g| overshoots by orders of magnitude) */
+      double shrink = 0.5;
+      if (ft == ft) {
+        const double curv = ft - f - gd * step;
+        if (curv > 0.0) { shrink = -gd * step / (2.0 * curv); if (shrink < 0.05) shrink = 0.05; if (shrink > 0.5) shrink = 0.5; }
+      } else {
+        shrink = 0.05;
+      }
+      step *= shrink;
     }
     if (!accepted) break;
     /* curvature pair */

@@ -331,7 +331,8 @@ int  lrr_icp_cloud_set_covariances(lrr_icp_cloud *cloud, const double *cov9);
  * w_ij^2 / (sum_j w_ij sum_i w_ij).  Rows of max_matches slots per moving feature (original order): row_count[i]
  * matches, to_idx = original fixed indices (-1 in unused slots), in no particular order inside a row.
  * overflow_rows: moving features with more candidates inside the radius than one wavefront holds (1536): their
- * selection is taken among the first 1536 found. */
+ * selection is taken among the first 1536 found.  NULL: such a row is an error (LRR_ICP_ERR_STATE) — the reference
+ * has no cap, a caller that does not look at the count must not get a silently different match set. */
 int  lrr_icp_cdc_compute_weights(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, const lrr_icp_xform *xf, int dof,
                                  const double *param_covar, const uint32_t keys[4], int max_matches,
                                  int64_t *row_count, int64_t *to_idx, double *w, int64_t *overflow_rows);
@@ -344,6 +345,21 @@ void lrr_icp_cdc_set_destroy(lrr_icp_cdc_set *set);
 int  lrr_icp_cdc_set_compute_weights(lrr_icp_cdc_set *set, const lrr_icp_xform *xf, int dof, const double *param_covar,
                                      const uint32_t keys[4], int64_t *overflow_rows);
 int  lrr_icp_cdc_set_get(lrr_icp_cdc_set *set, int64_t *row_count, int64_t *to_idx, double *w);
+/* what the resolution switch inside compute_weights reads (cdcl/cdcl_estimation.txx:384, 491-517) after an E-step: the sum over
+ * ALL moving features of sqrt(lambda_max(J_th C_theta J_th^T)), and matches_.size() = the moving features whose row is not empty */
+int  lrr_icp_cdc_set_stats(lrr_icp_cdc_set *set, double *eval_sum, int64_t *rows_with_matches);
+/* from_weights of the last E-step: sum_j w_ij before the normalisation, per moving feature (original order); row_count may be NULL */
+int  lrr_icp_cdc_set_row_sums(lrr_icp_cdc_set *set, double *row_sum, int64_t *row_count);
+/* w_ij^2 / (wi wj) again with the caller's from-side sums wi: after a resolution switch the reference's restart appends to
+ * from_weights instead of clearing it (:356-358), so match i of the second pass is normalised by entry i of the first pass */
+int  lrr_icp_cdc_set_renormalize(lrr_icp_cdc_set *set, const double *row_sum);
+/* the rigid increment of the EM loop (cdcl/cdcl_estimation.txx:118-141, 157-166): until the next compute_weights every
+ * matches_[i]->from_ is the copy of the moving feature at G(p) with covariance R C_p R^T — the objectives and the normalisation
+ * statistics below see those copies.  G = NULL: the features themselves. */
+int  lrr_icp_cdc_set_premap(lrr_icp_cdc_set *set, const lrr_icp_xform *G);
+/* `if( matches_.size() == 0 ) find_closest_euclidean()` (cdcl/cdcl_estimation.txx:543-544; cdcl/cdcl_estimation_ICP.txx:451-489):
+ * every moving feature gets its Euclidean-nearest fixed feature under xf, weight 1 */
+int  lrr_icp_cdc_set_closest_euclidean(lrr_icp_cdc_set *set, const lrr_icp_xform *xf);
 /* M-step, parameters: cdcl_obj_fun_par::compute (cdcl/cdcl_obj_fun_par.txx:44-142; constructor :20-41) at the
  * transform x over the resident rows: f = (1/R) sum w (rho(r) + ln det C_ij) and, when g != NULL, its gradient
  * (dof values: 2 J_th^T C_ij^-1 e and the two correction terms of d C_ij / d theta), R = rows that are not empty.

@@ -297,6 +297,22 @@ int guard(Fn fn) {
 
 }  // namespace
 
+// info[8]: objective of the parameter estimate at the start / end, of the covariance estimate at the start / end, the two
+// optimiser codes, the two evaluation counts (zeros where a step did not run); state[3] (may be NULL): resolution after the
+// iteration, matches_.size() of its last compute_weights, 1 when that fell back to the closest points, its avg_largest_eval
+template <class EM>
+static void cdc_em_iterate(EM *em, unsigned iteration, int *converged, double *info, double *state) {
+  bool cv = em->one_iteration(iteration);
+  if (converged) *converged = cv ? 1 : 0;
+  if (info) {
+    const typename EM::step_info &s = em->last_step();
+    const bool par = iteration > 5;
+    info[0] = par ? s.par_start : 0.0; info[1] = par ? s.par_end : 0.0; info[2] = s.cov_start; info[3] = s.cov_end;
+    info[4] = par ? s.par_code : 0; info[5] = s.cov_code; info[6] = par ? s.par_evals : 0; info[7] = s.cov_evals;
+  }
+  if (state) { state[0] = em->resolution(); state[1] = (double)em->matches_size(); state[2] = em->used_closest_euclidean() ? 1.0 : 0.0; state[3] = em->avg_largest_eval(); state[4] = em->switches_down(); state[5] = em->switches_up(); }
+}
+
 extern "C" {
 
 typedef struct lrr_est lrr_est;
@@ -510,13 +526,17 @@ int lrr_vtp_features(lrr_vtp *v, double *loc, double *proj, double *strength, ui
 
 // ---- covariance-driven EM estimator (cdcl_estimation, include/lrr_amd/cdcl_estimation.h) ------------------------------
 struct lrr_cdc_em {
-  lrr_icp_cloud *moving = nullptr, *fixed = nullptr;
-  cdcl_trans<3, 12>::sptr trans;
-  lrr_amd::cdcl_estimation_em *em = nullptr;
+  int dof = 12;
+  std::vector<lrr_icp_cloud *> moving, fixed;   // one pair per resolution, [0] the finest
+  cdcl_trans<3, 12>::sptr trans12;
+  cdcl_trans<3, 6>::sptr trans6;
+  lrr_amd::cdcl_estimation_em *em12 = nullptr;
+  lrr_amd::cdcl_estimation_em_rigid *em6 = nullptr;
   ~lrr_cdc_em() {
-    delete em;
-    if (moving) lrr_icp_cloud_destroy(moving);
-    if (fixed) lrr_icp_cloud_destroy(fixed);
+    delete em12;
+    delete em6;
+    for (lrr_icp_cloud *c : moving) if (c) lrr_icp_cloud_destroy(c);
+    for (lrr_icp_cloud *c : fixed) if (c) lrr_icp_cloud_destroy(c);
   }
 };
 static lrr_icp_cloud *cdc_cloud(const lrr_est_features *f) {
@@ -526,40 +546,51 @@ static lrr_icp_cloud *cdc_cloud(const lrr_est_features *f) {
   if (lrr_icp_cloud_set_covariances(c, f->cov) != 0) { lrr_icp_cloud_destroy(c); throw std::runtime_error("cdc_em: covariance upload failed"); }
   return c;
 }
-int lrr_cdc_em_create(const lrr_est_features *moving, const lrr_est_features *fixed, const double *A, const double *t, const double *c,
-                      const double *covar144, uint64_t seed, int max_matches, lrr_cdc_em **out) {
+// dof 12: affine; dof 6: rigid3d (small-angle increment).  levels pairs of feature sets, [0] the finest, with the point spacing
+// of every fixed set (levels == 1: spacing may be NULL); covar: dof x dof
+int lrr_cdc_em_create_pyramid(int dof, int levels, const lrr_est_features *const *moving, const lrr_est_features *const *fixed, const double *spacing,
+                              const double *A, const double *t, const double *c, const double *covar, uint64_t seed, int max_matches, lrr_cdc_em **out) {
   return guard([&] {
+    if ((dof != 6 && dof != 12) || levels < 1 || !moving || !fixed) throw std::runtime_error("cdc_em: bad argument");
     std::unique_ptr<lrr_cdc_em> h(new lrr_cdc_em);
-    h->moving = cdc_cloud(moving);
-    h->fixed = cdc_cloud(fixed);
-    h->trans = trans_factory<12>::make(A, t, c);
-    vnl_matrix_fixed<double, 12, 12> C;
-    for (unsigned r = 0; r < 12; ++r) for (unsigned k = 0; k < 12; ++k) C(r, k) = covar144[r * 12 + k];
-    h->trans->set_covariance(C);
-    h->em = new lrr_amd::cdcl_estimation_em(h->moving, h->fixed, h->trans, seed, max_matches);
+    h->dof = dof;
+    for (int r = 0; r < levels; ++r) { h->moving.push_back(cdc_cloud(moving[r])); h->fixed.push_back(cdc_cloud(fixed[r])); }
+    std::vector<double> sp(spacing ? spacing : nullptr, spacing ? spacing + levels : nullptr);
+    if (dof == 12) {
+      h->trans12 = trans_factory<12>::make(A, t, c);
+      vnl_matrix_fixed<double, 12, 12> C;
+      for (unsigned r = 0; r < 12; ++r) for (unsigned k = 0; k < 12; ++k) C(r, k) = covar[r * 12 + k];
+      h->trans12->set_covariance(C);
+      if (levels == 1) h->em12 = new lrr_amd::cdcl_estimation_em(h->moving[0], h->fixed[0], h->trans12, seed, max_matches);
+      else h->em12 = new lrr_amd::cdcl_estimation_em(h->moving, h->fixed, h->trans12, sp, seed, max_matches);
+    } else {
+      h->trans6 = trans_factory<6>::make(A, t, c);
+      vnl_matrix_fixed<double, 6, 6> C;
+      for (unsigned r = 0; r < 6; ++r) for (unsigned k = 0; k < 6; ++k) C(r, k) = covar[r * 6 + k];
+      h->trans6->set_covariance(C);
+      if (levels == 1) h->em6 = new lrr_amd::cdcl_estimation_em_rigid(h->moving[0], h->fixed[0], h->trans6, seed, max_matches);
+      else h->em6 = new lrr_amd::cdcl_estimation_em_rigid(h->moving, h->fixed, h->trans6, sp, seed, max_matches);
+    }
     *out = h.release();
   });
 }
+int lrr_cdc_em_create(const lrr_est_features *moving, const lrr_est_features *fixed, const double *A, const double *t, const double *c,
+                      const double *covar144, uint64_t seed, int max_matches, lrr_cdc_em **out) {
+  return lrr_cdc_em_create_pyramid(12, 1, &moving, &fixed, nullptr, A, t, c, covar144, seed, max_matches, out);
+}
 void lrr_cdc_em_destroy(lrr_cdc_em *h) { delete h; }
-// info[8]: objective of the parameter estimate at the start / end, of the covariance estimate at the start / end, the two
-// optimiser codes, the two evaluation counts (zeros where a step did not run)
 int lrr_cdc_em_one_iteration(lrr_cdc_em *h, unsigned iteration, int *converged, double *info) {
-  return guard([&] {
-    bool cv = h->em->one_iteration(iteration);
-    if (converged) *converged = cv ? 1 : 0;
-    if (info) {
-      const lrr_amd::cdcl_estimation_em::step_info &s = h->em->last_step();
-      const bool par = iteration > 5;
-      info[0] = par ? s.par_start : 0.0; info[1] = par ? s.par_end : 0.0; info[2] = s.cov_start; info[3] = s.cov_end;
-      info[4] = par ? s.par_code : 0; info[5] = s.cov_code; info[6] = par ? s.par_evals : 0; info[7] = s.cov_evals;
-    }
-  });
+  return guard([&] { if (h->em12) cdc_em_iterate(h->em12, iteration, converged, info, (double *)nullptr); else cdc_em_iterate(h->em6, iteration, converged, info, (double *)nullptr); });
 }
-int lrr_cdc_em_get_transform(lrr_cdc_em *h, double *A, double *t, double *c, double *covar144) {
-  return guard([&] { read_trans<12>(h->em->get_transform(), A, t, c, covar144); });
+int lrr_cdc_em_one_iteration_state(lrr_cdc_em *h, unsigned iteration, int *converged, double *info, double *state) {
+  return guard([&] { if (h->em12) cdc_em_iterate(h->em12, iteration, converged, info, state); else cdc_em_iterate(h->em6, iteration, converged, info, state); });
 }
+int lrr_cdc_em_get_transform(lrr_cdc_em *h, double *A, double *t, double *c, double *covar) {
+  return guard([&] { if (h->em12) read_trans<12>(h->em12->get_transform(), A, t, c, covar); else read_trans<6>(h->em6->get_transform(), A, t, c, covar); });
+}
+// rows of the CURRENT resolution (row_count: one entry per moving feature of that resolution)
 int lrr_cdc_em_rows(lrr_cdc_em *h, int64_t *row_count, int64_t *to_idx, double *w) {
-  return guard([&] { lrr_amd::check(lrr_icp_cdc_set_get(h->em->rows().handle(), row_count, to_idx, w), "cdc rows"); });
+  return guard([&] { lrr_amd::check(lrr_icp_cdc_set_get(h->em12 ? h->em12->rows().handle() : h->em6->rows().handle(), row_count, to_idx, w), "cdc rows"); });
 }
 
 }  // extern "C"

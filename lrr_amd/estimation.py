@@ -34,7 +34,7 @@ ICP_SYMBOLS = [
     "lrr_icp_weight_spatially", "lrr_icp_accumulate", "lrr_icp_errors", "lrr_icp_errors_launch", "lrr_icp_errors_collect", "lrr_icp_median_error", "lrr_icp_cloud_set_shapes", "lrr_icp_cloud_set_shape_vectors", "lrr_icp_angles", "lrr_icp_angles_unmapped", "lrr_icp_transfer_covariance", "lrr_icp_get_matches",
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
     "lrr_icp_nearest", "lrr_icp_debug_set_match", "lrr_icp_cloud_set_covariances", "lrr_icp_cdc_compute_weights",
-    "lrr_icp_cdc_set_create", "lrr_icp_cdc_set_destroy", "lrr_icp_cdc_set_compute_weights", "lrr_icp_cdc_set_get", "lrr_icp_cdc_objective_par", "lrr_icp_cdc_objective_cov", "lrr_icp_cdc_normalize_stats",
+    "lrr_icp_cdc_set_create", "lrr_icp_cdc_set_destroy", "lrr_icp_cdc_set_compute_weights", "lrr_icp_cdc_set_get", "lrr_icp_cdc_set_stats", "lrr_icp_cdc_set_row_sums", "lrr_icp_cdc_set_renormalize", "lrr_icp_cdc_set_premap", "lrr_icp_cdc_set_closest_euclidean", "lrr_icp_cdc_objective_par", "lrr_icp_cdc_objective_cov", "lrr_icp_cdc_normalize_stats",
     "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
     "lrr_icp_batch_match", "lrr_icp_batch_estimate", "lrr_icp_batch_errors", "lrr_icp_batch_angles", "lrr_icp_batch_iterate",
     "lrr_icp_batch_num_matches", "lrr_icp_batch_get_matches",
@@ -391,47 +391,68 @@ class CdcSet:
 
 
 class CdcEm:
-    """cdcl_estimation's EM loop (include/lrr_amd/cdcl_estimation.h: lrr_amd::cdcl_estimation_em) for the affine
-    transform: one_iteration() = compute_weights, from iteration 6 on estimate_parameters + compute_weights,
-    estimate_covariance (cdcl/cdcl_estimation.txx:95-187)."""
+    """cdcl_estimation's EM loop (include/lrr_amd/cdcl_estimation.h: lrr_amd::cdcl_estimation_em_t<dof>): one_iteration() =
+    compute_weights, from iteration 6 on estimate_parameters + compute_weights, estimate_covariance
+    (cdcl/cdcl_estimation.txx:95-187).  dof 12: the affine transform; dof 6: the rigid one with its small-angle increment.
+    moving / fixed: one feature set, or a list of them ([0] the finest resolution, with `spacing` = the fixed sets' point
+    spacings): the estimator starts at the coarsest and switches resolution as compute_weights decides (:491-517)."""
 
-    def __init__(self, moving, fixed, A, t, c, covar, seed=1, max_matches=100):
+    def __init__(self, moving, fixed, A, t, c, covar, seed=1, max_matches=100, dof=12, spacing=None):
         L = est_lib()
         self.L = L
         self._keep = []
-        fm, ff = _features(moving, self._keep), _features(fixed, self._keep)
+        mv = list(moving) if isinstance(moving, (list, tuple)) else [moving]
+        fx = list(fixed) if isinstance(fixed, (list, tuple)) else [fixed]
+        if len(mv) != len(fx) or (len(mv) > 1 and (spacing is None or len(spacing) != len(mv))):
+            raise ValueError("one fixed set and one spacing per moving set")
+        levels = len(mv)
+        fms = [_features(m, self._keep) for m in mv]
+        ffs = [_features(f, self._keep) for f in fx]
+        FP = C.POINTER(_Features)
+        pm = (FP * levels)(*[C.pointer(f) for f in fms])
+        pf = (FP * levels)(*[C.pointer(f) for f in ffs])
+        sp = np.ascontiguousarray(spacing if spacing is not None else [1.0] * levels, dtype=np.float64)
         A, t, c = (np.ascontiguousarray(x, dtype=np.float64) for x in (A, t, c))
         cv = np.ascontiguousarray(covar, dtype=np.float64)
-        self.nm, self.max_matches = moving.n, int(max_matches)
+        if cv.size != dof * dof:
+            raise ValueError("covar must be dof x dof")
+        self.dof, self.sizes, self.max_matches = int(dof), [m.n for m in mv], int(max_matches)
+        self.resolution, self.matches_size, self.fell_back = levels - 1, 0, False
         self.h = C.c_void_p()
-        L.lrr_cdc_em_create.argtypes = [C.POINTER(_Features), C.POINTER(_Features), _dp, _dp, _dp, _dp, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]
+        L.lrr_cdc_em_create_pyramid.argtypes = [C.c_int, C.c_int, C.POINTER(FP), C.POINTER(FP), _dp, _dp, _dp, _dp, _dp, C.c_uint64, C.c_int,
+                                                C.POINTER(C.c_void_p)]
         L.lrr_cdc_em_destroy.argtypes = [C.c_void_p]
         L.lrr_cdc_em_destroy.restype = None
-        L.lrr_cdc_em_one_iteration.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int), _dp]
+        L.lrr_cdc_em_one_iteration_state.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int), _dp, _dp]
         L.lrr_cdc_em_get_transform.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
         L.lrr_cdc_em_rows.argtypes = [C.c_void_p, _ip, _ip, _dp]
-        self._ck(L.lrr_cdc_em_create(C.byref(fm), C.byref(ff), _d(A), _d(t), _d(c), _d(cv), seed, self.max_matches, C.byref(self.h)))
+        self._ck(L.lrr_cdc_em_create_pyramid(self.dof, levels, pm, pf, _d(sp), _d(A), _d(t), _d(c), _d(cv), seed, self.max_matches, C.byref(self.h)))
 
     def _ck(self, rc):
         if rc != 0:
             raise RuntimeError(self.L.lrr_est_last_error().decode())
 
     def one_iteration(self, iteration):
-        """(converged, info[8]: par f start/end, cov f start/end, optimiser codes, evaluations)"""
+        """(converged, info[8]: par f start/end, cov f start/end, optimiser codes, evaluations); afterwards .resolution,
+        .matches_size (matches_.size()) and .fell_back (find_closest_euclidean() supplied the matches)"""
         conv = C.c_int(0)
-        info = np.zeros(8)
-        self._ck(self.L.lrr_cdc_em_one_iteration(self.h, int(iteration), C.byref(conv), _d(info)))
+        info, state = np.zeros(8), np.zeros(6)
+        self._ck(self.L.lrr_cdc_em_one_iteration_state(self.h, int(iteration), C.byref(conv), _d(info), _d(state)))
+        self.resolution, self.matches_size, self.fell_back, self.avg_largest_eval = int(state[0]), int(state[1]), bool(state[2]), float(state[3])
+        self.switches = (int(state[4]), int(state[5]))  # to a finer, to a coarser resolution, this iteration
         return bool(conv.value), info
 
     def get_transform(self):
-        A, t, c, cov = np.zeros((3, 3)), np.zeros(3), np.zeros(3), np.zeros((12, 12))
+        A, t, c, cov = np.zeros((3, 3)), np.zeros(3), np.zeros(3), np.zeros((self.dof, self.dof))
         self._ck(self.L.lrr_cdc_em_get_transform(self.h, _d(A), _d(t), _d(c), _d(cov)))
         return A, t, c, cov
 
     def rows(self):
-        rc = np.zeros(self.nm, dtype=np.int64)
-        ti = np.zeros((self.nm, self.max_matches), dtype=np.int64)
-        w = np.zeros((self.nm, self.max_matches))
+        """the match rows of the current resolution"""
+        nm = self.sizes[self.resolution]
+        rc = np.zeros(nm, dtype=np.int64)
+        ti = np.zeros((nm, self.max_matches), dtype=np.int64)
+        w = np.zeros((nm, self.max_matches))
         self._ck(self.L.lrr_cdc_em_rows(self.h, rc.ctypes.data_as(_ip), ti.ctypes.data_as(_ip), _d(w)))
         return rc, ti, w
 

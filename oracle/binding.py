@@ -186,34 +186,63 @@ def cdc_obj_cov(moving, fixed, dof, A, t, c, x_upper, row_count, to_idx, w, norm
 
 
 class CdcEmOracle:
-    """The oracle's EM loop of cdcl_estimation (affine): state in numpy arrays, one_iteration() as the reference orders it"""
+    """The oracle's EM loop of cdcl_estimation (dof 12 affine, dof 6 rigid increment; one resolution or a pyramid, [0] the finest):
+    state in numpy arrays, one_iteration() as the reference orders it"""
 
-    def __init__(self, moving, fixed, A, t, c, covar, seed=1, max_matches=100):
-        self.mv, self.fx = moving, fixed
+    def __init__(self, moving, fixed, A, t, c, covar, seed=1, max_matches=100, dof=12, spacing=None):
+        self.mv = list(moving) if isinstance(moving, (list, tuple)) else [moving]
+        self.fx = list(fixed) if isinstance(fixed, (list, tuple)) else [fixed]
+        self.dof = int(dof)
+        self.spacing = np.ascontiguousarray(spacing if spacing is not None else [1.0] * len(self.mv), dtype=np.float64)
         self.A = np.array(A, dtype=np.float64).reshape(3, 3).copy()
         self.t = np.array(t, dtype=np.float64).copy()
         self.c = np.array(c, dtype=np.float64).copy()
-        self.cov = np.array(covar, dtype=np.float64).reshape(12, 12).copy()
+        self.cov = np.array(covar, dtype=np.float64).reshape(self.dof, self.dof).copy()
         self.state = C.c_uint64(seed)
         self.mm = int(max_matches)
-        self.rc = np.zeros(moving.n, dtype=np.int64)
-        self.ti = np.full((moving.n, self.mm), -1, dtype=np.int64)
-        self.w = np.zeros((moving.n, self.mm))
+        self.resolution, self.matches_size, self.fell_back = len(self.mv) - 1, 0, False
+        nmax = max(m.n for m in self.mv)
+        self._rc = np.zeros(nmax, dtype=np.int64)
+        self._ti = np.full(nmax * self.mm, -1, dtype=np.int64)
+        self._w = np.zeros(nmax * self.mm)
+
+    # the rows of the current resolution
+    @property
+    def rc(self):
+        return self._rc[:self.mv[self.resolution].n]
+
+    @property
+    def ti(self):
+        n = self.mv[self.resolution].n
+        return self._ti[:n * self.mm].reshape(n, self.mm)
+
+    @property
+    def w(self):
+        n = self.mv[self.resolution].n
+        return self._w[:n * self.mm].reshape(n, self.mm)
 
     def one_iteration(self, iteration):
         L = lib()
         keep = []
-        fm, ff = _features(self.mv, keep), _features(self.fx, keep)
-        info = np.zeros(8)
+        levels = len(self.mv)
+        fms = [_features(m, keep) for m in self.mv]
+        ffs = [_features(f, keep) for f in self.fx]
+        FP = C.POINTER(_Features)
+        pm = (FP * levels)(*[C.pointer(f) for f in fms])
+        pf = (FP * levels)(*[C.pointer(f) for f in ffs])
+        info, state = np.zeros(8), np.zeros(6)
+        res = C.c_int(self.resolution)
         i64p = C.POINTER(C.c_int64)
-        L.lrr_oracle_cdc_em_iteration.restype = C.c_int
-        L.lrr_oracle_cdc_em_iteration.argtypes = [C.POINTER(_Features), C.POINTER(_Features), _dp, _dp, _dp, _dp, C.c_uint, C.POINTER(C.c_uint64),
-                                                  C.c_int, i64p, i64p, _dp, _dp]
-        self.ti.fill(-1)
-        self.w.fill(0.0)
-        r = L.lrr_oracle_cdc_em_iteration(C.byref(fm), C.byref(ff), _d(self.A), _d(self.t), _d(self.c), _d(self.cov), int(iteration),
-                                          C.byref(self.state), self.mm, self.rc.ctypes.data_as(i64p), self.ti.ctypes.data_as(i64p), _d(self.w),
-                                          _d(info))
+        L.lrr_oracle_cdc_em_iteration_pyramid.restype = C.c_int
+        L.lrr_oracle_cdc_em_iteration_pyramid.argtypes = [C.c_int, C.c_int, C.POINTER(FP), C.POINTER(FP), _dp, _dp, _dp, _dp, _dp, C.c_uint,
+                                                          C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int), i64p, i64p, _dp, _dp, _dp]
+        self._ti.fill(-1)
+        self._w.fill(0.0)
+        r = L.lrr_oracle_cdc_em_iteration_pyramid(self.dof, levels, pm, pf, _d(self.spacing), _d(self.A), _d(self.t), _d(self.c), _d(self.cov),
+                                                  int(iteration), C.byref(self.state), self.mm, C.byref(res), self._rc.ctypes.data_as(i64p),
+                                                  self._ti.ctypes.data_as(i64p), _d(self._w), _d(info), _d(state))
+        self.resolution, self.matches_size, self.fell_back, self.avg_largest_eval = int(state[0]), int(state[1]), bool(state[2]), float(state[3])
+        self.switches = (int(state[4]), int(state[5]))  # to a finer, to a coarser resolution, this iteration
         if r < 0:
             raise RuntimeError("oracle EM iteration: covariance not positive definite")
         return bool(r), info

@@ -1212,16 +1212,23 @@ void lrr_oracle_cdc_normalize_stats(const lrr_oracle_features *moving, const lrr
   norm[7] = rf / nd;
 }
 
-/* One EM iteration of cdcl_estimation for the affine transform (cdcl/cdcl_estimation.txx:95-187), without resolution
- * switching: compute_weights; from iteration 6 on estimate_parameters() (:210-260) and compute_weights again;
- * estimate_covariance() (:264-338).  Both estimates: cdcl_normalize_matches + trans->normalize, L-BFGS capped at five
- * function evaluations on cdcl_obj_fun_par / cdcl_obj_fun_cov, un-normalise.  The optimiser is the stand-in of
- * include/lrr_amd/lbfgs_standin.h (vnl_lbfgs is third party and absent).  T (A, t, c, covar) is updated in place;
- * returns parameters_converged && covariance_converged && |covar|_F < 1e-3 (:186). */
+/* One EM iteration of cdcl_estimation (cdcl/cdcl_estimation.txx:95-187) for the affine transform (dof 12) and for the rigid
+ * one with its small-angle increment (dof 6), over a pyramid of `levels` resolutions ([0] the finest; the estimator starts at
+ * the coarsest, cdcl/cdcl_estimation_ICP.txx:118):
+ *   compute_weights(resolution_switch_allowed = iteration > 5) (:342-545) with its resolution switch (:491-517: the statistic
+ *   avg_largest_eval of :384 against twice the fixed spacing, one restart at most) — the restart APPENDS to from_weights (:356-358
+ *   are outside the loop), so match i of the second pass is normalised with entry i of the first pass (:524-537) — and the
+ *   closest-point fallback (:543-544);
+ *   rigid: the transform becomes an increment (identity, the global covariance), every from_ a copy at G(p) with Jp C Jp^T (:111-141);
+ *   from iteration 6 on estimate_parameters() (:210-260), rigid: recompose_increment + compute_weights on the global transform + the
+ *   copies again (:150-171), else compute_weights; estimate_covariance() (:264-338); rigid: the global transform takes the covariance (:178-182).
+ * Both estimates: cdcl_normalize_matches + trans->normalize, the stand-in optimiser of include/lrr_amd/lbfgs_standin.h (vnl_lbfgs is
+ * third party and absent) capped at five evaluations with cdcl_lbfgs' 5 % stop, un-normalise.  T (A, t, c, covar) is updated in place;
+ * returns parameters_converged && covariance_converged && |covar|_F < 1e-3 (:186), -1 when the covariance lost positive definiteness. */
 #include "lrr_amd/lbfgs_standin.h"
 typedef struct {
-  const lrr_oracle_features *mv, *fx;
-  int max_matches;
+  const lrr_oracle_features *mv, *fx;   /* the features the objective sees (rigid: the pre-mapped copies) */
+  int dof, max_matches;
   const int64_t *rc, *ti;
   const double *w;
   const double *norm;
@@ -1229,11 +1236,13 @@ typedef struct {
 } em_ctx;
 static void em_fg_par(void *u, const double *x, double *f, double *g) {
   em_ctx *E = (em_ctx *)u;
-  lrr_oracle_cdc_obj_par(E->mv, E->fx, 12, x, x + 9, E->T->c, E->T->covar, E->max_matches, E->rc, E->ti, E->w, E->norm, f, g);
+  trans Tx = *E->T;
+  trans_set_param(&Tx, x);  /* (cdcl_obj_fun_par.txx:50) */
+  lrr_oracle_cdc_obj_par(E->mv, E->fx, E->dof, Tx.A, Tx.t, Tx.c, Tx.covar, E->max_matches, E->rc, E->ti, E->w, E->norm, f, g);
 }
 static void em_fg_cov(void *u, const double *x, double *f, double *g) {
   em_ctx *E = (em_ctx *)u;
-  lrr_oracle_cdc_obj_cov(E->mv, E->fx, 12, E->T->A, E->T->t, E->T->c, x, E->max_matches, E->rc, E->ti, E->w, E->norm, f, g);
+  lrr_oracle_cdc_obj_cov(E->mv, E->fx, E->dof, E->T->A, E->T->t, E->T->c, x, E->max_matches, E->rc, E->ti, E->w, E->norm, f, g);
 }
 /* upper-triangular Cholesky factor U (U^T U = C), row-major n x n; returns 0 when C is not positive definite */
 static int chol_upper(int n, const double *C, double *U) {
@@ -1248,66 +1257,274 @@ static int chol_upper(int n, const double *C, double *U) {
   }
   return 1;
 }
-int lrr_oracle_cdc_em_iteration(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, double *A, double *t, double *c,
-                                double *covar, unsigned iteration, uint64_t *seed_state, int max_matches,
-                                int64_t *row_count, int64_t *to_idx, double *w, double *info /* 8: f_par start/end, f_cov start/end, codes, evals */) {
-  const int dof = 12, ncov = 78;
+/* one pass of compute_weights at one resolution, BEFORE the normalisation (:369-488): raw weights in the rows, sum_j w_ij per
+ * moving feature, sum_i w_ij per fixed feature; *eval_sum = sum over ALL moving features of sqrt(lambda_max(J C_theta J^T)) (:384).
+ * Tm: the transform the features are mapped and the Jacobians taken with; covar: the parameter covariance (transfer_covar uses
+ * trans_'s, cdcl_estimation.h:96-98).  Returns matches_.size() (rows that are not empty). */
+static int64_t cdc_weights_pass(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int dof, const trans *Tm, const double *covar,
+                                const uint32_t keys[4], int max_matches, int64_t *row_count, int64_t *to_idx, double *w, double *from_sum,
+                                double *to_sum, double *eval_sum) {
+  const int64_t nm = moving->n, nf = fixed->n;
+  int64_t rows = 0;
+  int64_t *cand = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)(nf > 0 ? nf : 1));
+  for (int64_t j = 0; j < nf; ++j) to_sum[j] = 0.0;
+  *eval_sum = 0.0;
+  for (int64_t i = 0; i < nm; ++i) {
+    const double *p = moving->loc + 3 * i;
+    double y[3], J[3 * MAXDOF], JC[3 * MAXDOF], Cp[9];
+    trans_map(Tm, p, y);
+    trans_jac(Tm, p, J);
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < dof; ++cc) {
+        double s2 = 0.0;
+        for (int k = 0; k < dof; ++k) s2 += J[r * dof + k] * covar[k * dof + cc];
+        JC[r * dof + cc] = s2;
+      }
+    for (int r = 0; r < 3; ++r)
+      for (int e = 0; e < 3; ++e) {
+        double s2 = 0.0;
+        for (int k = 0; k < dof; ++k) s2 += JC[r * dof + k] * J[e * dof + k];
+        Cp[3 * r + e] = s2;
+      }
+    double l1, l2, l3;
+    sym3_eigenvalues(Cp[0], Cp[1], Cp[2], Cp[4], Cp[5], Cp[8], &l1, &l2, &l3);
+    *eval_sum += sqrt(l3);
+    {
+      const double *Cm = moving->cov + 9 * i;
+      double AC[9];
+      for (int r = 0; r < 3; ++r)
+        for (int e = 0; e < 3; ++e) AC[3 * r + e] = (Tm->A[3 * r] * Cm[e] + Tm->A[3 * r + 1] * Cm[3 + e]) + Tm->A[3 * r + 2] * Cm[6 + e];
+      for (int r = 0; r < 3; ++r)
+        for (int e = 0; e < 3; ++e) Cp[3 * r + e] += (AC[3 * r] * Tm->A[3 * e] + AC[3 * r + 1] * Tm->A[3 * e + 1]) + AC[3 * r + 2] * Tm->A[3 * e + 2];
+    }
+    sym3_eigenvalues(Cp[0], Cp[1], Cp[2], Cp[4], Cp[5], Cp[8], &l1, &l2, &l3);
+    const double radius = 5.0 * sqrt(l3), r2 = radius * radius;
+    int64_t nc = 0;
+    for (int64_t j = 0; j < nf; ++j)
+      if (dist2(y, fixed->loc + 3 * j) <= r2) { cand[2 * nc] = lrr_oracle_subset_perm(j, nf, keys); cand[2 * nc + 1] = j; ++nc; }
+    if (nc > max_matches) { qsort(cand, (size_t)nc, 2 * sizeof(int64_t), cmp_i64_pair); nc = max_matches; }
+    for (int64_t k = 0; k < nc; ++k) { cand[2 * k] = cand[2 * k + 1]; }
+    qsort(cand, (size_t)nc, 2 * sizeof(int64_t), cmp_i64_pair);
+    int64_t kept = 0;
+    double sum_w = 0.0;
+    for (int64_t k = 0; k < nc; ++k) {
+      int64_t j = cand[2 * k];
+      const double *q = fixed->loc + 3 * j, *Cq = fixed->cov + 9 * j;
+      double e[3] = { y[0] - q[0], y[1] - q[1], y[2] - q[2] }, Cij[9], Ci[9];
+      for (int a2 = 0; a2 < 9; ++a2) Cij[a2] = Cp[a2] + Cq[a2];
+      inverse3_cofactor(Cij, Ci);
+      double v0 = (e[0] * Ci[0] + e[1] * Ci[3]) + e[2] * Ci[6];
+      double v1 = (e[0] * Ci[1] + e[1] * Ci[4]) + e[2] * Ci[7];
+      double v2 = (e[0] * Ci[2] + e[1] * Ci[5]) + e[2] * Ci[8];
+      double residual = (v0 * e[0] + v1 * e[1]) + v2 * e[2];
+      double w0 = cdc_weight(residual);
+      if (w0 > 0.0) {
+        to_idx[i * max_matches + kept] = j;
+        w[i * max_matches + kept] = w0;
+        to_sum[j] += w0;
+        sum_w += w0;
+        ++kept;
+      }
+    }
+    row_count[i] = kept;
+    from_sum[i] = sum_w;
+    if (kept > 0) ++rows;
+  }
+  free(cand);
+  return rows;
+}
+typedef struct {
+  int dof, levels, max_matches, res, max_res;
+  const lrr_oracle_features *const *moving, *const *fixed;
+  const double *spacing;
+  uint64_t *seed;
+  int64_t *rc, *ti;
+  double *w;
+  int64_t matches;   /* matches_.size() after compute_weights */
+  int fell_back;
+  double avg;        /* avg_largest_eval of the last pass */
+  int downs, ups;    /* resolution switches of this iteration */
+} em_state;
+/* compute_weights (:342-545) */
+static void em_compute_weights(em_state *S, int allowed, const trans *Tm, const trans *Tcur) {
+  double *all_from = NULL;   /* from_weights: appended across the restart */
+  int64_t n_all = 0, cap_all = 0;
+  int stop = 0, not_restarted = 1;
+  double *from_sum = NULL, *to_sum = NULL;
+  S->fell_back = 0;
+  while (!stop) {
+    const lrr_oracle_features *mv = S->moving[S->res], *fx = S->fixed[S->res];
+    uint32_t keys[4];
+    lrr_oracle_perm_keys(S->seed, keys);
+    free(from_sum); free(to_sum);
+    from_sum = (double *)calloc((size_t)(mv->n > 0 ? mv->n : 1), sizeof(double));
+    to_sum = (double *)calloc((size_t)(fx->n > 0 ? fx->n : 1), sizeof(double));
+    double eval_sum = 0.0;
+    S->matches = cdc_weights_pass(mv, fx, S->dof, Tm, Tcur->covar, keys, S->max_matches, S->rc, S->ti, S->w, from_sum, to_sum, &eval_sum);
+    for (int64_t i = 0; i < mv->n; ++i)
+      if (S->rc[i] > 0) {
+        if (n_all == cap_all) { cap_all = cap_all ? 2 * cap_all : 1024; all_from = (double *)realloc(all_from, sizeof(double) * (size_t)cap_all); }
+        all_from[n_all++] = from_sum[i];
+      }
+    const double avg_largest_eval = eval_sum / (double)S->matches;
+    S->avg = avg_largest_eval;
+    stop = 1;
+    if (avg_largest_eval < 2.0 * S->spacing[S->res] && allowed && not_restarted) {
+      if (S->res > 0) { --S->res; stop = 0; not_restarted = 0; ++S->downs; }
+    }
+    if (S->res + 1 <= S->max_res && avg_largest_eval > 2.0 * S->spacing[S->res + 1] && allowed && not_restarted) {
+      ++S->res; stop = 0; not_restarted = 0; ++S->ups;
+    }
+  }
+  /* normalise (:524-537): wi = from_weights[i], i the match's position in matches_ */
+  {
+    const lrr_oracle_features *mv = S->moving[S->res];
+    int64_t k = 0;
+    for (int64_t i = 0; i < mv->n; ++i) {
+      if (S->rc[i] <= 0) continue;
+      const double wi = all_from[k++];
+      for (int64_t j = 0; j < S->rc[i]; ++j) {
+        const double w0 = S->w[i * S->max_matches + j];
+        S->w[i * S->max_matches + j] = w0 * w0 / (wi * to_sum[S->ti[i * S->max_matches + j]]);
+      }
+    }
+  }
+  free(all_from); free(from_sum); free(to_sum);
+  if (S->matches == 0) {  /* find_closest_euclidean (cdcl_estimation_ICP.txx:451-489): nearest fixed feature under trans_, weight 1 */
+    const lrr_oracle_features *mv = S->moving[S->res], *fx = S->fixed[S->res];
+    for (int64_t i = 0; i < mv->n; ++i) {
+      double y[3], best = INFINITY;
+      int64_t bj = 0;
+      trans_map(Tcur, mv->loc + 3 * i, y);
+      for (int64_t j = 0; j < fx->n; ++j) { const double d = dist2(y, fx->loc + 3 * j); if (d < best) { best = d; bj = j; } }
+      S->rc[i] = fx->n > 0 ? 1 : 0;
+      S->ti[i * S->max_matches] = bj;
+      S->w[i * S->max_matches] = 1.0;
+    }
+    S->matches = fx->n > 0 ? mv->n : 0;
+    S->fell_back = 1;
+  }
+}
+/* the copies the rigid increment works on (:118-141): location G(p), covariance Jp C Jp^T, Jp = R */
+static void em_premap(const lrr_oracle_features *mv, const trans *G, lrr_oracle_features *out, double *loc, double *cov) {
+  for (int64_t i = 0; i < mv->n; ++i) {
+    trans_map(G, mv->loc + 3 * i, loc + 3 * i);
+    const double *Cm = mv->cov + 9 * i;
+    double RC[9];
+    for (int r = 0; r < 3; ++r)
+      for (int e = 0; e < 3; ++e) RC[3 * r + e] = (G->A[3 * r] * Cm[e] + G->A[3 * r + 1] * Cm[3 + e]) + G->A[3 * r + 2] * Cm[6 + e];
+    for (int r = 0; r < 3; ++r)
+      for (int e = 0; e < 3; ++e) cov[9 * i + 3 * r + e] = (RC[3 * r] * G->A[3 * e] + RC[3 * r + 1] * G->A[3 * e + 1]) + RC[3 * r + 2] * G->A[3 * e + 2];
+  }
+  *out = *mv;
+  out->loc = loc;
+  out->cov = cov;
+}
+static void em_get_param(const trans *T, double *x) {
+  if (T->dof == 6) { for (int i = 0; i < 3; ++i) { x[i] = T->abg[i]; x[3 + i] = T->t[i]; } }
+  else { for (int i = 0; i < 9; ++i) x[i] = T->A[i]; for (int i = 0; i < 3; ++i) x[9 + i] = T->t[i]; }
+}
+int lrr_oracle_cdc_em_iteration_pyramid(int dof, int levels, const lrr_oracle_features *const *moving, const lrr_oracle_features *const *fixed,
+                                        const double *spacing, double *A, double *t, double *c, double *covar, unsigned iteration,
+                                        uint64_t *seed_state, int max_matches, int *res_inout, int64_t *row_count, int64_t *to_idx, double *w,
+                                        double *info /* 8 */, double *state /* 6: resolution, matches_.size(), fell back, avg_largest_eval, switches to a finer / a coarser resolution; may be NULL */) {
+  const int ncov = dof * (dof + 1) / 2;
   const unsigned startEM = 5;
+  const int allowed = iteration > startEM;
+  const double one = 1.0;
   trans T;
-  trans_identity(&T, dof);
-  memcpy(T.A, A, sizeof T.A); memcpy(T.t, t, sizeof T.t); memcpy(T.c, c, sizeof T.c);
-  memcpy(T.covar, covar, sizeof(double) * 144);
-  uint32_t keys[4];
+  trans_from_Atc(&T, dof, A, t, c);
+  memcpy(T.covar, covar, sizeof(double) * (size_t)dof * dof);
   for (int k = 0; k < 8; ++k) info[k] = 0.0;
-  lrr_oracle_perm_keys(seed_state, keys);
-  lrr_oracle_cdc_compute_weights(moving, fixed, dof, T.A, T.t, T.c, T.covar, keys, max_matches, row_count, to_idx, w);
+  em_state S;
+  S.dof = dof; S.levels = levels; S.max_matches = max_matches; S.res = *res_inout; S.max_res = levels - 1;
+  S.moving = moving; S.fixed = fixed; S.spacing = spacing ? spacing : &one; S.seed = seed_state;
+  S.rc = row_count; S.ti = to_idx; S.w = w; S.matches = 0; S.fell_back = 0; S.avg = 0.0; S.downs = S.ups = 0;
+  int64_t nm_max = 1;
+  for (int r = 0; r < levels; ++r) if (moving[r]->n > nm_max) nm_max = moving[r]->n;
+  double *pm_loc = (double *)malloc(sizeof(double) * 3 * (size_t)nm_max), *pm_cov = (double *)malloc(sizeof(double) * 9 * (size_t)nm_max);
+  lrr_oracle_features pm;
+  const int rigid = dof == 6;
+  int rcode = 0;
+
+  em_compute_weights(&S, allowed, &T, &T);
+  trans G = T, *cur = &T;  /* cur: trans_ */
+  trans inc;
+  if (rigid) {  /* from now on, transform is incremental (:111-141) */
+    trans_identity(&inc, dof);
+    memcpy(inc.covar, G.covar, sizeof(double) * (size_t)dof * dof);
+    em_premap(moving[S.res], &G, &pm, pm_loc, pm_cov);
+    cur = &inc;
+  }
   int parameters_converged = 0, covariance_converged = 0;
   double norm[8];
   em_ctx E;
-  E.mv = moving; E.fx = fixed; E.max_matches = max_matches; E.rc = row_count; E.ti = to_idx; E.w = w; E.norm = norm; E.T = &T;
+  E.dof = dof; E.max_matches = max_matches; E.rc = row_count; E.ti = to_idx; E.w = w; E.norm = norm; E.T = cur;
   if (iteration > startEM) {
-    lrr_oracle_cdc_normalize_stats(moving, fixed, max_matches, row_count, to_idx, norm);
-    trans_normalize(&T, norm[3], norm[7], norm, norm + 4);
-    double x[12], x_old[12];
-    for (int i = 0; i < 9; ++i) x[i] = T.A[i];
-    for (int i = 0; i < 3; ++i) x[9 + i] = T.t[i];
+    E.mv = rigid ? &pm : moving[S.res]; E.fx = fixed[S.res];
+    lrr_oracle_cdc_normalize_stats(E.mv, E.fx, max_matches, row_count, to_idx, norm);
+    trans_normalize(cur, norm[3], norm[7], norm, norm + 4);
+    double x[MAXDOF], x_old[MAXDOF];
+    em_get_param(cur, x);
     memcpy(x_old, x, sizeof x);
-    lrr_lbfgs_result r = lrr_lbfgs_minimize_stop(12, x, em_fg_par, &E, 5, LRR_CDCL_LBFGS_STOP_FRACTION);  /* cdcl/cdcl_lbfgs.h:28-36 */
+    lrr_lbfgs_result r = lrr_lbfgs_minimize_stop(dof, x, em_fg_par, &E, 5, LRR_CDCL_LBFGS_STOP_FRACTION);  /* cdcl/cdcl_lbfgs.h:28-36 */
     parameters_converged = (r.f_start - r.f_end) < 1e-4;
     if (r.code < 0) memcpy(x, x_old, sizeof x);
-    for (int i = 0; i < 9; ++i) T.A[i] = x[i];
-    for (int i = 0; i < 3; ++i) T.t[i] = x[9 + i];
-    trans_unnormalize(&T, norm[3], norm[7], norm, norm + 4);
+    trans_set_param(cur, x);
+    trans_unnormalize(cur, norm[3], norm[7], norm, norm + 4);
     info[0] = r.f_start; info[1] = r.f_end; info[4] = (double)r.code; info[6] = (double)r.evals;
-    lrr_oracle_perm_keys(seed_state, keys);
-    lrr_oracle_cdc_compute_weights(moving, fixed, dof, T.A, T.t, T.c, T.covar, keys, max_matches, row_count, to_idx, w);
+    if (rigid) {
+      trans_recompose_increment(&G, cur);
+      em_compute_weights(&S, allowed, &G, cur);   /* J and map of the global transform, covariance of trans_ (:153) */
+      em_premap(moving[S.res], &G, &pm, pm_loc, pm_cov);
+    } else {
+      em_compute_weights(&S, allowed, cur, cur);
+    }
   }
   {
-    lrr_oracle_cdc_normalize_stats(moving, fixed, max_matches, row_count, to_idx, norm);
-    trans_normalize(&T, norm[3], norm[7], norm, norm + 4);
-    double U[144], x[78], x_old[78];
-    if (!chol_upper(dof, T.covar, U)) return -1;
+    E.mv = rigid ? &pm : moving[S.res]; E.fx = fixed[S.res];
+    lrr_oracle_cdc_normalize_stats(E.mv, E.fx, max_matches, row_count, to_idx, norm);
+    trans_normalize(cur, norm[3], norm[7], norm, norm + 4);
+    double U[MAXDOF * MAXDOF], x[MAXDOF * (MAXDOF + 1) / 2], x_old[MAXDOF * (MAXDOF + 1) / 2];
+    if (!chol_upper(dof, cur->covar, U)) { rcode = -1; goto done; }
     { int ind = 0; for (int d1 = 0; d1 < dof; ++d1) for (int d2 = d1; d2 < dof; ++d2) x[ind++] = U[d1 * dof + d2]; }
-    memcpy(x_old, x, sizeof x);
+    memcpy(x_old, x, sizeof(double) * (size_t)ncov);
     lrr_lbfgs_result r = lrr_lbfgs_minimize_stop(ncov, x, em_fg_cov, &E, 5, LRR_CDCL_LBFGS_STOP_FRACTION);
     covariance_converged = (r.f_start - r.f_end) < 1e-5;
-    if (r.code < 0) memcpy(x, x_old, sizeof x);
+    if (r.code < 0) memcpy(x, x_old, sizeof(double) * (size_t)ncov);
     memset(U, 0, sizeof U);
     { int ind = 0; for (int d1 = 0; d1 < dof; ++d1) for (int d2 = d1; d2 < dof; ++d2) U[d1 * dof + d2] = x[ind++]; }
-    for (int a = 0; a < dof; ++a)
-      for (int b = 0; b < dof; ++b) {
+    for (int a2 = 0; a2 < dof; ++a2)
+      for (int b2 = 0; b2 < dof; ++b2) {
         double s2 = 0.0;
-        for (int k = 0; k < dof; ++k) s2 += U[k * dof + a] * U[k * dof + b];
-        T.covar[a * dof + b] = s2;
+        for (int k = 0; k < dof; ++k) s2 += U[k * dof + a2] * U[k * dof + b2];
+        cur->covar[a2 * dof + b2] = s2;
       }
-    trans_unnormalize(&T, norm[3], norm[7], norm, norm + 4);
+    trans_unnormalize(cur, norm[3], norm[7], norm, norm + 4);
     info[2] = r.f_start; info[3] = r.f_end; info[5] = (double)r.code; info[7] = (double)r.evals;
   }
+  if (rigid) {  /* (:178-182) */
+    memcpy(G.covar, cur->covar, sizeof(double) * (size_t)dof * dof);
+    T = G;
+  }
   memcpy(A, T.A, sizeof T.A); memcpy(t, T.t, sizeof T.t); memcpy(c, T.c, sizeof T.c);
-  memcpy(covar, T.covar, sizeof(double) * 144);
-  double fro = 0.0;
-  for (int i = 0; i < 144; ++i) fro += T.covar[i] * T.covar[i];
-  return parameters_converged && covariance_converged && sqrt(fro) < 1e-3;
+  memcpy(covar, T.covar, sizeof(double) * (size_t)dof * dof);
+  {
+    double fro = 0.0;
+    for (int i = 0; i < dof * dof; ++i) fro += T.covar[i] * T.covar[i];
+    rcode = parameters_converged && covariance_converged && sqrt(fro) < 1e-3;
+  }
+done:
+  *res_inout = S.res;
+  if (state) { state[0] = (double)S.res; state[1] = (double)S.matches; state[2] = (double)S.fell_back; state[3] = S.avg; state[4] = (double)S.downs; state[5] = (double)S.ups; }
+  free(pm_loc); free(pm_cov);
+  return rcode;
+}
+int lrr_oracle_cdc_em_iteration(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, double *A, double *t, double *c,
+                                double *covar, unsigned iteration, uint64_t *seed_state, int max_matches,
+                                int64_t *row_count, int64_t *to_idx, double *w, double *info /* 8: f_par start/end, f_cov start/end, codes, evals */) {
+  int res = 0;
+  return lrr_oracle_cdc_em_iteration_pyramid(12, 1, &moving, &fixed, NULL, A, t, c, covar, iteration, seed_state, max_matches, &res, row_count, to_idx, w, info, NULL);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -115,6 +115,12 @@ int64_t lrr_oracle_cdc_obj_cov(const lrr_oracle_features *moving, const lrr_orac
 void lrr_oracle_cdc_normalize_stats(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, int max_matches,
                                     const int64_t *row_count, const int64_t *to_idx, double *norm);
 /* one EM iteration of cdcl_estimation, affine transform, no resolution switching (cdcl/cdcl_estimation.txx:95-187, 210-338) */
+/* the same for dof 6 (rigid, small-angle increment) or 12 over a pyramid of resolutions ([0] the finest; *res_inout: the current one,
+ * coarsest at the start); spacing[r]: point spacing of fixed[r] (NULL with one level); rows of the resolution left in *res_inout */
+int lrr_oracle_cdc_em_iteration_pyramid(int dof, int levels, const lrr_oracle_features *const *moving, const lrr_oracle_features *const *fixed,
+                                        const double *spacing, double *A, double *t, double *c, double *covar, unsigned iteration,
+                                        uint64_t *seed_state, int max_matches, int *res_inout, int64_t *row_count, int64_t *to_idx, double *w,
+                                        double *info, double *state);
 int lrr_oracle_cdc_em_iteration(const lrr_oracle_features *moving, const lrr_oracle_features *fixed, double *A, double *t, double *c,
                                 double *covar, unsigned iteration, uint64_t *seed_state, int max_matches,
                                 int64_t *row_count, int64_t *to_idx, double *w, double *info);

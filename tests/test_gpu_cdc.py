@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from lrr_amd import synth
+from tests.cdc_scenarios import EM_CASES, scenario
 
 pytestmark = pytest.mark.gpu
 
@@ -234,37 +235,40 @@ def test_em_steps_driven_by_lbfgs_improve_the_transform(E):
     cf.close()
 
 
-def test_em_iterations_equal_the_oracle(E, ob):
-    """cdcl_estimation::one_iteration for the affine transform (cdcl/cdcl_estimation.txx:95-187: compute_weights, from
-    iteration 6 on estimate_parameters + compute_weights, estimate_covariance), the device path behind the drop-in class
-    lrr_amd::cdcl_estimation_em against the oracle's restatement, both driven by the same stand-in optimiser (five
-    function evaluations per estimate, as the reference caps vnl_lbfgs): match rows exact, objective values, transform and
-    covariance to tolerance, iteration by iteration through the switch at iteration 6."""
-    n = 5000
-    pair = synth.make_pair(n, n - 400, 313, kind="affine", extent=60.0)
-    mv = dataclasses.replace(pair.moving, cov=synth.covariances(pair.moving))
-    fx = dataclasses.replace(pair.fixed, cov=synth.covariances(pair.fixed))
-    T0 = synth.perturbed(pair.planted, 5, rot_deg=0.4, trans_mm=0.5)
-    B = np.random.default_rng(4).normal(size=(12, 12)) * 2e-3
-    B[9:] *= 50.0
-    Ct = B @ B.T
-    g = E.CdcEm(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, max_matches=100)
-    c = ob.CdcEmOracle(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, max_matches=100)
+@pytest.mark.parametrize("name,dof,kw,spacing,its,switches", EM_CASES, ids=[c[0] for c in EM_CASES])
+def test_em_iterations_equal_the_oracle(E, ob, name, dof, kw, spacing, its, switches):
+    """cdcl_estimation::one_iteration (cdcl/cdcl_estimation.txx:95-187: compute_weights, from iteration 6 on
+    estimate_parameters + compute_weights, estimate_covariance) for the affine transform (dof 12) and the rigid one with its
+    small-angle increment and pre-mapped features (dof 6, :111-182), at one resolution and over a two-resolution pyramid with
+    the resolution switch of compute_weights in both directions (:491-517, including the from_weights that survive the
+    restart, :356-358): the device path behind the drop-in class lrr_amd::cdcl_estimation_em_t<dof> against the oracle's
+    restatement, both driven by the same stand-in optimiser (five function evaluations per estimate, the 5 % stop of
+    cdcl_lbfgs): match rows exact, objective values, transform and covariance to tolerance, iteration by iteration."""
+    mv, fx, T0, Ct = scenario(dof, **kw)
+    g = E.CdcEm(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, max_matches=100, dof=dof, spacing=spacing)
+    c = ob.CdcEmOracle(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, max_matches=100, dof=dof, spacing=spacing)
     saw_parameters = False
-    for it in range(9):
+    down = up = 0
+    for it in its:
         cg, ig = g.one_iteration(it)
         cc, ic = c.one_iteration(it)
         assert cg == cc, it
+        assert (g.resolution, g.matches_size, g.fell_back, g.switches) == (c.resolution, c.matches_size, c.fell_back, c.switches), it
+        assert np.isclose(g.avg_largest_eval, c.avg_largest_eval, rtol=1e-9), it
+        down, up = down + g.switches[0], up + g.switches[1]
         rc, ti, w = g.rows()
         assert np.array_equal(rc, c.rc), it
         for i in np.flatnonzero(rc)[::37]:
             k = int(rc[i])
             o = np.argsort(ti[i, :k], kind="stable")
             assert np.array_equal(ti[i, :k][o], c.ti[i, :k]), (it, i)
-            assert np.allclose(w[i, :k][o], c.w[i, :k], rtol=1e-7, atol=1e-300), (it, i)
-        # optimiser codes and evaluation counts equal; objective values close
+            # (a weight next to the cut-off of the Beaton-Tukey function is (1 - r / 16)^2 of a difference that cancels: its
+            # relative error is unbounded; the absolute one is held against the row's largest weight)
+            assert np.allclose(w[i, :k][o], c.w[i, :k], rtol=1e-7, atol=1e-9 * c.w[i, :k].max()), (it, i)
+        # optimiser codes and evaluation counts equal; objective values close (the two transforms drift apart by ~1e-8 over
+        # the iterations: different summation orders feeding five line-search steps each)
         assert np.array_equal(ig[4:], ic[4:]), (it, ig, ic)
-        assert np.allclose(ig[:4], ic[:4], rtol=1e-8, atol=1e-12), (it, ig, ic)
+        assert np.allclose(ig[:4], ic[:4], rtol=1e-6, atol=1e-12), (it, ig, ic)
         A, t, cen, cov = g.get_transform()
         assert np.allclose(A, c.A, rtol=0, atol=1e-8 * np.abs(c.A).max()), it
         assert np.allclose(t, c.t, rtol=0, atol=1e-7 * max(1.0, np.abs(c.t).max())), it
@@ -275,4 +279,43 @@ def test_em_iterations_equal_the_oracle(E, ob):
             assert ig[6] >= 2 and ig[1] <= ig[0]   # the parameter estimate ran and did not raise its objective
         assert ig[7] >= 2 and ig[3] <= ig[2]
     assert saw_parameters
+    assert (down, up) == switches
+    if dof == 6:
+        assert np.allclose(A @ A.T, np.eye(3), atol=1e-12)   # (recompose_increment keeps the global transform a rotation)
+    g.close()
+
+
+@pytest.mark.parametrize("dof", [12, 6])
+def test_em_closest_point_fallback_equals_the_oracle(E, ob, dof):
+    """(:543-544, cdcl/cdcl_estimation_ICP.txx:451-489) the start is 150 mm off: no fixed feature inside any search radius, so
+    compute_weights hands every moving feature its nearest fixed feature with weight 1, and the covariance estimate runs on those"""
+    mv, fx, T0, Ct = scenario(dof, n=1500, cov_scale=2e-4, shift=np.array([150.0, 0.0, 0.0]))
+    g = E.CdcEm(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, dof=dof)
+    c = ob.CdcEmOracle(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, dof=dof)
+    for it in (0, 1, 6):
+        cg, ig = g.one_iteration(it)
+        cc, ic = c.one_iteration(it)
+        assert g.fell_back and c.fell_back and g.matches_size == c.matches_size == mv.n, it
+        assert np.isinf(g.avg_largest_eval) and np.isinf(c.avg_largest_eval)
+        rc, ti, w = g.rows()
+        assert np.all(rc == 1) and np.array_equal(ti[:, 0], c.ti[:, 0]) and np.all(w[:, 0] == 1.0), it
+        assert cg == cc and np.array_equal(ig[4:], ic[4:]), (it, ig, ic)
+        assert np.allclose(ig[:4], ic[:4], rtol=1e-8, atol=1e-12), (it, ig, ic)
+        A, t, cen, cov = g.get_transform()
+        assert np.allclose(A, c.A, rtol=0, atol=1e-8) and np.allclose(t, c.t, rtol=0, atol=1e-6), it
+        assert np.allclose(cov, c.cov, rtol=1e-5, atol=1e-7 * np.abs(c.cov).max()), it
+    g.close()
+
+
+def test_em_rows_beyond_the_device_capacity_are_an_error(E):
+    """the reference keeps every candidate inside the radius before it draws 100 of them (:385-404); the device rows hold a fixed
+    number of candidates, and the drop-in class has no CPU path to finish such a row with: it must say so"""
+    rng = np.random.default_rng(3)
+    n = 6000
+    loc = rng.uniform(-2.0, 2.0, size=(n, 3))     # a dense clump: thousands of candidates inside every radius
+    fs = synth.FeatureSet(loc=loc, proj=np.tile(np.eye(3).ravel(), (n, 1)), strength=np.ones(n), shape=np.zeros(n, dtype=np.uint8),
+                          dirs=np.tile(np.r_[1.0, 0, 0, 0, 1.0, 0], (n, 1)), cov=np.tile(np.eye(3).ravel() * 4.0, (n, 1)))
+    g = E.CdcEm(fs, fs, np.eye(3), np.zeros(3), np.zeros(3), np.eye(12) * 1e-4, seed=1, dof=12)
+    with pytest.raises(RuntimeError, match="compute_weights"):
+        g.one_iteration(0)
     g.close()
