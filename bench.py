@@ -344,7 +344,7 @@ def locations_measure(args, rank, local_rank, world, cpu=True):
         # SURVEY 8(d)'s 180 algorithmic bytes per pair, over the time the device works on the iterations (the slowest
         # rank's lrr_icp_batch_iterate: the host queues ahead of the device there)
         ach = pairs / world * ITER_BYTES_PER_PAIR / (it_ms * 1e-3) / 1e9
-        rec["roofline"] = {"bound": "hbm", "kernel": "one lockstep iteration of all locations of a rank = k_b_match + k_match_hard2 + k_match_overflow2 "
+        rec["roofline"] = {"bound": "hbm", "kernel": "one lockstep iteration of all locations of a rank = k_b_match + k_match_hard2 "
                                                      "+ k_b_residual, k_b_stats, k_b_weights, k_b_select, k_b_accumulate + k_run_solve, k_b_errors, k_run_decide "
                                                      "(lrr_icp_batch_iterate); latency-bound: a location is a few thousand pairs",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,

@@ -4,7 +4,8 @@
 //   K1  map moving features + exact nearest fixed feature      (k_match_ball[2] on the later iterations
 //                                                               of a level, k_match_tile on the first,
 //                                                               k_match_direct on coarse levels; then
-//                                                               k_match_hard[2], k_match_overflow;
+//                                                               k_match_hard[2] (wave per query, with the
+//                                                               full scan for what no ring settles);
 //                                                               k_match_brute: literal all-vs-all)
 //   K2  projected residuals, robust scale, Beaton-Tukey weights (k_f_residual, k_f_weights, k_selw_*;
 //                                                               forward classes: k_fw_residual, k_fw_weights)
@@ -113,7 +114,7 @@ struct SelPack { SelJob j[kSelPack]; };  // the jobs of one windowed selection, 
 struct K1Lane {
   hipStream_t stream = nullptr;
   double *d_bd = nullptr; int *d_bi = nullptr; size_t brute_cap = 0;   // brute-force partial argmin
-  int *d_hard = nullptr, *d_overflow = nullptr, *d_active = nullptr; size_t list_cap = 0;
+  int *d_hard = nullptr, *d_active = nullptr; size_t list_cap = 0;
   int *d_counts = nullptr;       // kCountSlots x {hard, overflow, active, -}: one zeroed slot per K1 submission
   int count_slot = 0;
   int *d_order = nullptr; size_t order_cap = 0;
@@ -806,12 +807,10 @@ int ensure_dir_capacity(lrr_icp_dir *d) {
 int ensure_lists(lrr_icp_ctx *ctx, K1Lane &L, size_t need) {
   if (need <= L.list_cap) return LRR_ICP_OK;
   if (L.d_hard) (void)hipFree(L.d_hard);
-  if (L.d_overflow) (void)hipFree(L.d_overflow);
   if (L.d_active) (void)hipFree(L.d_active);
-  L.d_hard = L.d_overflow = L.d_active = nullptr;
+  L.d_hard = L.d_active = nullptr;
   L.list_cap = 0;
   HIPCHK(ctx, hipMalloc(&L.d_hard, sizeof(int) * need));
-  HIPCHK(ctx, hipMalloc(&L.d_overflow, sizeof(int) * need));
   HIPCHK(ctx, hipMalloc(&L.d_active, sizeof(int) * need));
   L.list_cap = need;
   return LRR_ICP_OK;
@@ -837,8 +836,7 @@ int fresh_counts(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, int **counts) {
   return LRR_ICP_OK;
 }
 
-// phases 2 and 3 of the grid search; both read their list length on the device and fall through
-// when it is 0
+// phase 2 of the grid search; reads its list length on the device and falls through when it is 0
 HardArgs hard_args(K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int *m_to, int *counts,
                    float *d2lb = nullptr) {
   HardArgs a;
@@ -848,32 +846,21 @@ HardArgs hard_args(K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const 
   a.hard = L.d_hard; a.hard_count = counts;
   a.use_prev = q.src ? 1 : 0;
   a.to_pt = to->cpt;
-  a.m_to = m_to; a.overflow = L.d_overflow; a.overflow_count = counts + 1;
-  return a;
-}
-OverArgs over_args(const HardArgs &h) {
-  OverArgs a;
-  a.g = h.g; a.q = h.q; a.xf = h.xf; a.overflow = h.overflow; a.overflow_count = h.overflow_count; a.m_to = h.m_to;
+  a.m_to = m_to; a.overflow_count = counts + 1;
   return a;
 }
 // blocks of the ball kernels: one wavefront each, rounded up to a multiple of 8 for the XCD mapping
 inline unsigned ball_blocks_for(int64_t n) { return (unsigned)((((n + kBallBlock - 1) / kBallBlock) + 7) / 8 * 8); }
 inline int hard_blocks_for(int64_t n) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + 3) / 4)); }
 
-// all_have_prev: every handed-over query carries a previous match, so phase 2 settles all of them and
-// phase 3 has nothing to do.  That holds only when the WHOLE cloud was matched by the previous search
-// (n_points == N twice in a row): at a dense sub-full level the keyed subset changes with every
-// search, sources that were never matched enter phase 2 without a bound, walk the rings and may end
-// in the overflow list, which phase 3 must then serve.
-int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts, bool all_have_prev,
+// phase 2 of the grid search: the wave-per-query kernel (a query its ring walk cannot settle is scanned against every
+// target by the same wavefront, wave_scan_all: no third phase)
+int launch_hard_phases(lrr_icp_ctx *ctx, K1Lane &L, hipStream_t st, const lrr_icp_cloud *to, const GridView &g, const QSrc &q, const XfD &xf, int n, int *m_to, int *counts, bool /*all_have_prev*/,
                        float *d2lb = nullptr, bool cert = false, bool short_list = false) {
   HardArgs h = hard_args(L, to, g, q, xf, m_to, counts, d2lb);
   if (cert && ctx->prof) { h.stats = ctx->d_cert_stats; h.seen = (unsigned long long)n; }
   if (short_list) { h.hard = L.d_active; h.hard_count = counts + 2; }  // the certificate kernel's list itself
   hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n)), dim3(kBlock), 0, st, h);
-  HIPCHK(ctx, hipGetLastError());
-  if (all_have_prev) return LRR_ICP_OK;
-  hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, st, over_args(h));
   HIPCHK(ctx, hipGetLastError());
   return LRR_ICP_OK;
 }
@@ -1048,7 +1035,7 @@ void lrr_icp_destroy(lrr_icp_ctx *ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (K1Lane &L : ctx->lane) {
-    void *ls[] = {L.d_bd, L.d_bi, L.d_hard, L.d_overflow, L.d_active, L.d_counts, L.d_order};
+    void *ls[] = {L.d_bd, L.d_bi, L.d_hard, L.d_active, L.d_counts, L.d_order};
     for (void *p : ls) if (p) (void)hipFree(p);
   }
   if (ctx->lane[1].stream) (void)hipStreamDestroy(ctx->lane[1].stream);
@@ -1663,8 +1650,6 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     h.use_prev = 0;
     hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n_points)), dim3(kBlock), 0, st, h);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_match_overflow, dim3(256), dim3(kBlock), 0, st, over_args(h));
-    HIPCHK(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_vor_remap, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->slot, d->m_to, d->to->vor_site_to_feature, (int)N);
     HIPCHK(ctx, hipGetLastError());
     return LRR_ICP_OK;
@@ -1755,12 +1740,6 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       }
       hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
       HIPCHK(ctx, hipGetLastError());
-      // no phase 3 when both whole clouds were matched last time: every query then carries a previous
-      // match, which phase 2 settles.  At a dense sub-full level some sources have none (see
-      // launch_hard_phases) and may overflow the ring walk.
-      if (n_f == Pf.N && n_b == Pb.N && !Pf.growth && !Pb.growth) return LRR_ICP_OK;
-      hipLaunchKernelGGL(k_match_overflow2, dim3(128, 2), dim3(kBlock), 0, st, over_args(hf), over_args(hb));
-      HIPCHK(ctx, hipGetLastError());
       return LRR_ICP_OK;
     }
     // (not reached: the test above mirrors match_prepare's) fall through to separate launches
@@ -1792,8 +1771,6 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);
     HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
     hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
-    HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_match_overflow2, dim3(128, 2), dim3(kBlock), 0, st, over_args(hf), over_args(hb));
     HIPCHK(ctx, hipGetLastError());
     return LRR_ICP_OK;
   }
