@@ -90,22 +90,25 @@ class device {
   static state &slot() { static thread_local state s; return s; }
 };
 
-// how set_voronoi_maps() / set_fixed_voronoi_map() of the rrl classes are honoured (see icp_symmetric)
+// how set_voronoi_maps() / set_fixed_voronoi_map() of the rrl classes are honoured (see icp_symmetric): by default the call
+// selects the SEMANTICS of the reference's map lookup (LRR_ICP_NN_VORONOI: what the production binary computes);
+// voronoi_lookup::enable(false) — or LRR_ICP_VORONOI=0 in the environment — keeps the exact nearest-neighbour search
+// (faster on the device and exact where the 1 mm maps approximate, but not the reference's match sets)
 struct voronoi_lookup {
   static void enable(bool on) { flag() = on ? 1 : 0; }
   static bool enabled() {
     if (flag() < 0) {
       const char *e = std::getenv("LRR_ICP_VORONOI");
-      flag() = (e && e[0] && e[0] != '0') ? 1 : 0;
+      flag() = (e && e[0] == '0') ? 0 : 1;
     }
     return flag() == 1;
   }
-  static void note_ignored() {
+  static void note_exact() {
     static bool said = false;
     if (!said) {
       said = true;
-      std::fprintf(stderr, "lrr_amd: set_voronoi_maps(): the maps are not used — matches are the exact nearest neighbours, which the "
-                           "1 mm maps approximate (lrr_amd::voronoi_lookup::enable(true) or LRR_ICP_VORONOI=1 selects the lookup semantics)\n");
+      std::fprintf(stderr, "lrr_amd: set_voronoi_maps(): the lookup semantics of the maps are switched off (LRR_ICP_VORONOI=0 / "
+                           "voronoi_lookup::enable(false)) — matches are the exact nearest neighbours, which the 1 mm maps approximate\n");
     }
   }
  private:
@@ -843,13 +846,13 @@ class icp_symmetric : public cdcl_estimation_abs<3, dof, FeatureT> {
     backward_->set_moving_data(ff);
     reset_schedule();
   }
-  // (rrl sym .txx:293-299) The reference hands its two precomputed 1 mm Voronoi index volumes over here; the
-  // device needs neither.  By default the search is the EXACT nearest neighbour (what the volumes approximate);
-  // with voronoi_lookup::enable(true) — or LRR_ICP_VORONOI=1 in the environment — this call switches both
-  // directions to the quantised lookup semantics of the volumes (LRR_ICP_NN_VORONOI, include/lrr_icp.h).
+  // (rrl sym .txx:293-299) The reference hands its two precomputed 1 mm Voronoi index volumes over here.  The images
+  // themselves are not read: the call switches both directions to the quantised lookup SEMANTICS of the volumes
+  // (LRR_ICP_NN_VORONOI, include/lrr_icp.h: the device rebuilds the equivalent of the volume from the feature set), so the
+  // match sets are the production binary's.  voronoi_lookup::enable(false) / LRR_ICP_VORONOI=0 keeps the exact search.
   template <class VoronoiPointer> void set_voronoi_maps(VoronoiPointer const &, VoronoiPointer const &) {
     if (voronoi_lookup::enabled()) set_nn_method(LRR_ICP_NN_VORONOI);
-    else voronoi_lookup::note_ignored();
+    else voronoi_lookup::note_exact();
   }
   // (rrl sym .txx:303-315)
   void set_transform(trans_sptr_type const &trans) {

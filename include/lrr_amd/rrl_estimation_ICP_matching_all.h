@@ -18,11 +18,11 @@ class rrl_estimation_ICP_matching_all : public lrr_amd::icp_direction<dof, cdcl_
   rrl_estimation_ICP_matching_all(vcl_vector<feature_sptr_type> const &moving, vcl_vector<feature_sptr_type> const &fixed,
      trans_sptr_type const &trans)
       : engine_type(moving, fixed, trans) {}
-  // (rrl/rrl_estimation_ICP_matching_all.h:101) the map itself is not used: exact nearest neighbours by default, the
-  // map's quantised lookup semantics with lrr_amd::voronoi_lookup::enable(true) (see icp_symmetric::set_voronoi_maps)
+  // (rrl/rrl_estimation_ICP_matching_all.h:101) the image is not read: the call selects the map's quantised lookup semantics
+  // (LRR_ICP_NN_VORONOI); lrr_amd::voronoi_lookup::enable(false) keeps the exact search (see icp_symmetric::set_voronoi_maps)
   template <class VoronoiPointer> void set_fixed_voronoi_map(VoronoiPointer const &) {
     if (lrr_amd::voronoi_lookup::enabled()) this->set_nn_method(LRR_ICP_NN_VORONOI);
-    else lrr_amd::voronoi_lookup::note_ignored();
+    else lrr_amd::voronoi_lookup::note_exact();
   }
 };
 #endif

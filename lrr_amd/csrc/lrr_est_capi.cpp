@@ -10,6 +10,7 @@
 #include <exception>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "lrr_amd/cdcl_estimation_ICP_matching_all.h"
@@ -117,6 +118,19 @@ bool singular_values_in_range(typename cdcl_trans<3, dof>::sptr const &T) {
   return true;
 }
 
+// set_voronoi_maps(moving_map, fixed_map) of the symmetric classes / set_fixed_voronoi_map(map) of the rrl forward class, called
+// the way the reference's caller does (rrl/itkLocationRegistration.cxx hands the two index images over); classes without
+// the method (the cdcl forward class) have nothing to call
+template <class Est, class = void> struct voronoi_call {
+  static void apply(Est &) { throw std::runtime_error("this class has no Voronoi-map setter"); }
+};
+template <class Est> struct voronoi_call<Est, decltype(std::declval<Est &>().set_voronoi_maps((const void *)0, (const void *)0))> {
+  static void apply(Est &e) { e.set_voronoi_maps((const void *)0, (const void *)0); }
+};
+template <unsigned dim, unsigned dof> struct voronoi_call<rrl_estimation_ICP_matching_all<dim, dof>, void> {
+  static void apply(rrl_estimation_ICP_matching_all<dim, dof> &e) { e.set_fixed_voronoi_map((const void *)0); }
+};
+
 struct est_base {
   int dof = 0;
   virtual ~est_base() {}
@@ -128,6 +142,7 @@ struct est_base {
   virtual void inject_initial_scale(double f, double b) = 0;
   virtual void set_subset_order(int dir, const int64_t *order, int64_t n) = 0;
   virtual void set_nn_method(int m) = 0;
+  virtual void set_voronoi_maps() = 0;  // the class's own call, with null images (the drop-in never reads them)
   virtual void set_subset_seed(uint64_t seed) = 0;
   virtual void find_closest_euclidean() = 0;
   virtual bool one_iteration(unsigned it) = 0;
@@ -176,6 +191,7 @@ struct fwd_impl : est_base {
   void inject_initial_scale(double f, double) override { e->inject_initial_scale(f); }
   void set_subset_order(int, const int64_t *order, int64_t n) override { e->set_subset_order(std::vector<int64_t>(order, order + n)); }
   void set_nn_method(int m) override { e->set_nn_method(m); }
+  void set_voronoi_maps() override { voronoi_call<Est>::apply(*e); }
   void set_subset_seed(uint64_t seed) override { e->set_subset_seed(seed); }
   void find_closest_euclidean() override { e->find_closest_euclidean(); }
   bool one_iteration(unsigned it) override { return e->one_iteration(0, 0, it); }
@@ -236,6 +252,7 @@ struct sym_impl : est_base {
   void inject_initial_scale(double f, double b) override { e->inject_initial_scale(f, b); }
   void set_subset_order(int dir, const int64_t *order, int64_t n) override { d(dir).set_subset_order(std::vector<int64_t>(order, order + n)); }
   void set_nn_method(int m) override { e->set_nn_method(m); }
+  void set_voronoi_maps() override { voronoi_call<Est>::apply(*e); }
   void set_subset_seed(uint64_t seed) override { e->set_subset_seed(seed); }
   void find_closest_euclidean() override { e->find_closest_euclidean(); }
   bool one_iteration(unsigned it) override { return e->one_iteration(0, 0, it); }
@@ -368,6 +385,10 @@ int lrr_est_set_number_points(lrr_est *e, int64_t n) { return guard([&] { E(e)->
 int lrr_est_inject_initial_scale(lrr_est *e, double f, double b) { return guard([&] { E(e)->inject_initial_scale(f, b); }); }
 int lrr_est_set_subset_order(lrr_est *e, int dir, const int64_t *order, int64_t n) { return guard([&] { E(e)->set_subset_order(dir, order, n); }); }
 int lrr_est_set_nn_method(lrr_est *e, int m) { return guard([&] { E(e)->set_nn_method(m); }); }
+// the caller's set_voronoi_maps() / set_fixed_voronoi_map(); lookup: what lrr_amd::voronoi_lookup::enable() is set to first (-1: leave)
+int lrr_est_set_voronoi_maps(lrr_est *e, int lookup) {
+  return guard([&] { if (lookup >= 0) lrr_amd::voronoi_lookup::enable(lookup != 0); E(e)->set_voronoi_maps(); });
+}
 int lrr_est_find_closest_euclidean(lrr_est *e) { return guard([&] { E(e)->find_closest_euclidean(); }); }
 int lrr_est_one_iteration(lrr_est *e, unsigned it, int *converged) { return guard([&] { bool c = E(e)->one_iteration(it); if (converged) *converged = c ? 1 : 0; }); }
 // `count` iterations numbered from `first`, whatever they report (a benchmark's timed steps: no interpreter between them)

@@ -116,6 +116,7 @@ def est_lib() -> C.CDLL:
         L.lrr_est_inject_initial_scale.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.lrr_est_set_subset_order.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int64]
         L.lrr_est_set_nn_method.argtypes = [C.c_void_p, C.c_int]
+        L.lrr_est_set_voronoi_maps.argtypes = [C.c_void_p, C.c_int]
         L.lrr_est_find_closest_euclidean.argtypes = [C.c_void_p]
         L.lrr_est_one_iteration.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
         L.lrr_est_iterate.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(C.c_int)]
@@ -533,6 +534,12 @@ class Estimator:
 
     def set_nn_method(self, method):
         self._ck(est_lib().lrr_est_set_nn_method(self._h, int(method)))
+
+    def set_voronoi_maps(self, lookup=None):
+        """The class's set_voronoi_maps() / set_fixed_voronoi_map() as the reference's caller issues it (the images are never
+        read).  lookup: None = the process default (the maps' lookup semantics unless LRR_ICP_VORONOI=0), True / False =
+        lrr_amd::voronoi_lookup::enable() first."""
+        self._ck(est_lib().lrr_est_set_voronoi_maps(self._h, -1 if lookup is None else int(bool(lookup))))
 
     def find_closest_euclidean(self):
         self._ck(est_lib().lrr_est_find_closest_euclidean(self._h))

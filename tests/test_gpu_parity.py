@@ -690,6 +690,36 @@ def test_voronoi_lookup_equals_oracle(E, ob):
     g.close()
 
 
+def test_set_voronoi_maps_selects_the_lookup_semantics_by_default(E, ob):
+    """The caller of the rrl classes hands the two 1 mm Voronoi index volumes over (rrl sym .txx:293-299) and the class then
+    looks matches up in them (rrl .txx:530-543).  The drop-in's set_voronoi_maps() — called as the caller calls it — selects
+    those semantics by default, so its iterations are the oracle's with the Voronoi backend; switched off
+    (lrr_amd::voronoi_lookup::enable(false) / LRR_ICP_VORONOI=0) the same call keeps the exact search."""
+    pair = synth.make_pair(30000, 30000, 20245, kind="affine")
+    T0 = synth.perturbed(pair.planted, 4)
+    args = dict(moving_inside=pair.moving, fixed_inside=pair.fixed, seed=31)
+    for lookup, backend in ((True, ob.NN_VORONOI), (False, ob.NN_KDTREE)):
+        g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, **args)
+        g.set_voronoi_maps(lookup)
+        c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, nn_backend=backend, **args)
+        for it in range(12):
+            if _compare_iteration(g, c, it, (0, 1)):
+                break
+        g.close()
+    # the process default: the lookup semantics
+    g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, **args)
+    g.set_voronoi_maps(True)   # (restores the default for whatever test runs next in this process)
+    g.close()
+    # the rrl forward class has set_fixed_voronoi_map(); the cdcl forward class has no such setter
+    f = E.Estimator(E.RRL_FORWARD, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=31)
+    f.set_voronoi_maps()
+    f.close()
+    f = E.Estimator(E.CDCL_FORWARD, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=31)
+    with pytest.raises(RuntimeError, match="no Voronoi-map setter"):
+        f.set_voronoi_maps()
+    f.close()
+
+
 @pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("CDCL_SYMMETRIC", 6), ("CDCL_SYMMETRIC", 12)])
 def test_cdcl_covariance_angles(E, ob, kind_name, dof):
     """sheet_angles / tube_angles of the cdcl classes compare eigenvectors of the features' covariances (cdcl .txx:273-382):
