@@ -218,6 +218,8 @@ struct lrr_icp_dir {
   int64_t searches = 0; // grid searches on this source cloud so far (m_to holds the last match of every source ever active)
   int *slot = nullptr;   // list position of source s, -1 when s is not in the active subset
   int *m_to = nullptr;   // canonical target index
+  int *m_site = nullptr; // Voronoi-lookup semantics: canonical index of the matched SITE in to->vor (-1: never searched); m_to then holds the feature behind it
+  bool last_voronoi = false;  // the last search ran with the lookup semantics (its bounds refer to the site cloud)
   double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
   double *q_loc = nullptr;     // 3 per source: location of the matched target, cached by the fused residual pass
   double *from_loc = nullptr;  // 3 per source: pre-mapped copies
@@ -784,15 +786,16 @@ int ensure_dir_capacity(lrr_icp_dir *d) {
   lrr_icp_ctx *ctx = d->ctx;
   int64_t need = std::max<int64_t>(d->from->n, 1);
   if (need <= d->cap) return LRR_ICP_OK;
-  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->d2lb};
+  void *ptrs[] = {d->slot, d->m_to, d->m_site, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->d2lb};
   for (void *p : ptrs) if (p) (void)hipFree(p);
-  d->slot = d->m_to = nullptr; d->w = d->wc = d->r2 = d->key_g = d->key_s = d->from_loc = d->q_loc = nullptr;
+  d->slot = d->m_to = d->m_site = nullptr; d->w = d->wc = d->r2 = d->key_g = d->key_s = d->from_loc = d->q_loc = nullptr;
   d->d2lb = nullptr;
   d->have_bounds = false;
   d->cap = 0;
   HIPCHK(ctx, hipMalloc(&d->d2lb, sizeof(float) * need));
   HIPCHK(ctx, hipMalloc(&d->slot, sizeof(int) * need));
   HIPCHK(ctx, hipMalloc(&d->m_to, sizeof(int) * need));
+  HIPCHK(ctx, hipMalloc(&d->m_site, sizeof(int) * need));
   HIPCHK(ctx, hipMalloc(&d->w, sizeof(double) * need));
   HIPCHK(ctx, hipMalloc(&d->wc, sizeof(double) * need));
   HIPCHK(ctx, hipMalloc(&d->r2, sizeof(double) * need));
@@ -847,6 +850,7 @@ HardArgs hard_args(K1Lane &L, const lrr_icp_cloud *to, const GridView &g, const 
   a.use_prev = q.src ? 1 : 0;
   a.to_pt = to->cpt;
   a.m_to = m_to; a.overflow_count = counts + 1;
+  a.m_feat = nullptr; a.s2f = nullptr;
   return a;
 }
 // blocks of the ball kernels: one wavefront each, rounded up to a multiple of 8 for the XCD mapping
@@ -1387,6 +1391,7 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
   int rc = ensure_dir_capacity(d);
   if (rc) { lrr_icp_dir_destroy(d); return rc; }
   if (hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(d->m_site, 0xff, sizeof(int) * d->cap, ctx->stream) != hipSuccess ||
       hipMemsetAsync(d->m_to, 0xff, sizeof(int) * d->cap, ctx->stream) != hipSuccess) { lrr_icp_dir_destroy(d); return fail(ctx, LRR_ICP_ERR_HIP, "dir_create: memset failed"); }
   *out = d;
   return LRR_ICP_OK;
@@ -1395,7 +1400,7 @@ int lrr_icp_dir_create(lrr_icp_ctx *ctx, lrr_icp_cloud *from, lrr_icp_cloud *to,
 void lrr_icp_dir_destroy(lrr_icp_dir *d) {
   if (!d) return;
   if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); if (d->ctx->err_pending == d) d->ctx->err_pending = nullptr; }
-  void *ptrs[] = {d->slot, d->m_to, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->flag, d->d2lb};
+  void *ptrs[] = {d->slot, d->m_to, d->m_site, d->w, d->wc, d->r2, d->key_g, d->key_s, d->from_loc, d->q_loc, d->flag, d->d2lb};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete d;
 }
@@ -1416,6 +1421,7 @@ int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
   if (rc) return rc;
   HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(d->m_to, 0xff, sizeof(int) * d->cap, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(d->m_site, 0xff, sizeof(int) * d->cap, ctx->stream));
   return LRR_ICP_OK;
 }
 
@@ -1482,7 +1488,7 @@ struct MatchPrep {
 // kernels then cost twice a plain ball search of everything (r03_h: 55-86 against 32 us per direction at 200k).  Decided
 // from what the host knows: how many sources the last certificate pass listed, and how far the transform has moved since the
 // bounds were written (the largest displacement over the corners of the from-cloud's grid).
-static bool certificate_pays(const lrr_icp_dir *d, const lrr_icp_xform *xf, int64_t N) {
+static bool certificate_pays(const lrr_icp_dir *d, const lrr_icp_xform *xf, int64_t N, double cell, bool quantized) {
   static const bool always = std::getenv("LRR_ICP_CERT_ALWAYS") != nullptr;
   if (always) return true;
   if (d->last_list_count >= 0 && d->last_list_count * 8 > N) return false;  // an eighth of the cloud failed last time
@@ -1499,7 +1505,10 @@ static bool certificate_pays(const lrr_icp_dir *d, const lrr_icp_xform *xf, int6
     }
     umax = std::max(umax, std::sqrt(u2));
   }
-  return umax <= (double)kBallMarginCells * d->to->h;
+  // (lookup semantics: a query that stays in its voxel is settled whatever the bound; a displacement of u millimetres moves
+  // about 3 u of the mapped points across a voxel face: a tenth of a voxel leaves two thirds of the sources to the certificate)
+  if (quantized) return umax <= 0.1;
+  return umax <= (double)kBallMarginCells * cell;
 }
 
 // argument checks, capacities, explicit order upload, counters: everything before the launches.
@@ -1558,7 +1567,12 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   P.g = P.voronoi ? view_of_voronoi(d->to) : view_of(d->to);
   P.q.src = d->from->src; P.q.raw = nullptr; P.q.want_orig = 0; P.q.pidx = nullptr; P.q.bloc = nullptr; P.q.loc_of = nullptr; P.q.dir = 0;
   P.x = to_dev(xf);
-  P.dense = !order && dense_level(n_points, N) && !P.voronoi;  // fine levels: every source feature is looked at
+  P.dense = !order && dense_level(n_points, N);  // fine levels: every source feature is looked at
+  if (P.voronoi != d->last_voronoi) {  // previous matches stay valid bounds (m_to: features, m_site: sites), second-nearest bounds do not
+    d->have_bounds = false;
+    d->prev_n = -1;
+    d->last_voronoi = P.voronoi;
+  }
   if ((rc = fresh_counts(ctx, L, st, &P.counts))) return rc;
   // a level's later iterations: every active source carries its previous match -> ball search
   // ... and so does the first search after a dense level has grown: the sources of the old subset carry a match (any
@@ -1566,13 +1580,16 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   // and brute-force phases — cheaper than the tile kernel's search from scratch (135-160 -> 75-90 us per direction)
   static const bool tile_on_growth = std::getenv("LRR_ICP_TILE_ON_GROWTH") != nullptr;
   P.growth = !tile_on_growth && P.method == LRR_ICP_NN_GRID && P.dense && d->searches > 0 && d->prev_n != n_points;
+  // (lookup semantics: the tile kernel does not round its queries — the first search of a dense level is a ball search
+  // too, whose sources without a previous site are bounded by a site of their own cell or walk the rings)
+  if (P.voronoi && P.dense && d->prev_n != n_points) P.growth = true;
   P.steady = P.method == LRR_ICP_NN_GRID && P.dense && (d->prev_n == n_points || P.growth);
   if (P.method == LRR_ICP_NN_GRID) { d->prev_n = P.dense ? n_points : -1; ++d->searches; }
   // bounds are per source and refer to the transform of the search that wrote them: usable only when that
   // search covered every source (n_points == N twice in a row)
   static const bool no_cert = std::getenv("LRR_ICP_NO_CERT") != nullptr;
   P.cert = P.steady && n_points == N && d->have_bounds && !no_cert;
-  if (P.cert && !certificate_pays(d, xf, N)) P.cert = false;  // (the plain ball search leaves fresh bounds: the next search may certify again)
+  if (P.cert && !certificate_pays(d, xf, N, P.g.h, P.voronoi)) P.cert = false;  // (the plain ball search leaves fresh bounds: the next search may certify again)
   P.prev_xf = d->prev_xf;
   // the ball kernels (with or without certificate) leave bounds; the wave-per-query kernel leaves one for a source it
   // settles through its previous match and 0 (= search next time) for one it serves without.  Not after a growth
@@ -1593,13 +1610,21 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
 static BallArgs ball_args(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L) {
   BallArgs a;
   a.g = P.g; a.src = d->from->src; a.keys = P.kk; a.half = P.half; a.nsrc = (int)P.N; a.n_points = (int)d->n;
-  a.xf = P.x; a.to_pt = d->to->cpt;
-  a.slot = d->slot; a.m_to = d->m_to; a.w = d->w; a.hard = L.d_hard; a.hard_count = P.counts;
+  a.xf = P.x; a.to_pt = P.voronoi ? d->to->vor->cpt : d->to->cpt;
+  a.slot = d->slot; a.m_to = P.voronoi ? d->m_site : d->m_to; a.w = d->w; a.hard = L.d_hard; a.hard_count = P.counts;
+  a.m_feat = P.voronoi ? d->m_to : nullptr; a.s2f = P.voronoi ? d->to->vor_site_to_feature : nullptr;
   a.budget = kBallBudget; a.max_rad = kBallCells * P.g.h;
   a.d2lb = d->d2lb;
   a.xf_prev = to_dev(&P.prev_xf);
   a.list = L.d_active; a.list_count = P.counts + 2;
   return a;
+}
+// the wave-per-query arguments of one direction's search: with the lookup semantics the search runs in the to-cloud's site
+// cloud around the previous SITE, and the feature behind the site found goes to m_to
+static HardArgs hard_args_of(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, bool with_bounds) {
+  HardArgs h = hard_args(L, P.voronoi ? d->to->vor : d->to, P.g, P.q, P.x, P.voronoi ? d->m_site : d->m_to, P.counts, with_bounds ? d->d2lb : nullptr);
+  if (P.voronoi) { h.m_feat = d->m_to; h.s2f = d->to->vor_site_to_feature; }
+  return h;
 }
 inline unsigned cert_blocks_for(int64_t n) { return (unsigned)((((n + kCertBlock - 1) / kCertBlock) + 7) / 8 * 8); }
 
@@ -1641,20 +1666,23 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
   } else {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
     ctx->k1_paths[LRR_ICP_K1_DIRECT] += 1;
-    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot, d->m_to, d->w, L.d_hard, P.counts);
+    hipLaunchKernelGGL(k_match_direct, dim3(blocks_for(n_points)), dim3(kBlock), 0, st, P.g, P.q, P.d_order, P.use_keys ? 1 : 0, P.kk, P.half, (int)N, d->from->canon_of, P.x, (int)n_points, d->slot,
+                       P.voronoi ? d->m_site : d->m_to, d->w, L.d_hard, P.counts);
   }
   HIPCHK(ctx, hipGetLastError());
-  if (P.voronoi) {
-    // previous matches are feature indices, not site indices: the wave-per-query phase starts from scratch
-    HardArgs h = hard_args(L, d->to->vor, P.g, P.q, P.x, d->m_to, P.counts);
-    h.use_prev = 0;
+  const bool direct = !P.cert && !P.steady && !P.dense;
+  {
+    HardArgs h = hard_args_of(d, P, L, P.steady && n_points == N && !P.growth);
+    if (P.cert && ctx->prof) { h.stats = ctx->d_cert_stats; h.seen = (unsigned long long)n_points; }
+    if (P.short_list) { h.hard = L.d_active; h.hard_count = P.counts + 2; }  // the certificate kernel's list itself
     hipLaunchKernelGGL(k_match_hard, dim3(hard_blocks_for(n_points)), dim3(kBlock), 0, st, h);
     HIPCHK(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_vor_remap, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->slot, d->m_to, d->to->vor_site_to_feature, (int)N);
-    HIPCHK(ctx, hipGetLastError());
-    return LRR_ICP_OK;
   }
-  return launch_hard_phases(ctx, L, st, d->to, P.g, P.q, P.x, (int)n_points, d->m_to, P.counts, P.steady && n_points == N && !P.growth, d->d2lb, P.cert, P.short_list);
+  if (P.voronoi && direct) {  // the thread-per-slot kernel knows sites only: the features behind them (the other kernels write both)
+    hipLaunchKernelGGL(k_vor_remap, dim3(blocks_for(N)), dim3(kBlock), 0, st, d->slot, d->m_site, d->m_to, d->to->vor_site_to_feature, (int)N);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return LRR_ICP_OK;
 }
 
 // one K1 submission on lane L and its stream
@@ -1688,7 +1716,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
   int rc, rc2;
   // Later iterations of a level (both directions in the ball-search state): every phase handles both
   // directions in ONE launch on the main stream (blockIdx.y = direction) — no fork/join at all.
-  const bool both_steady = method != LRR_ICP_NN_BRUTE && method != LRR_ICP_NN_VORONOI && !order_f && !order_b && n_f > 0 && n_b > 0 &&
+  const bool both_steady = method != LRR_ICP_NN_BRUTE && !order_f && !order_b && n_f > 0 && n_b > 0 &&
                            dense_level(n_f, f->from->n) && dense_level(n_b, b->from->n) && f->searches > 0 && b->searches > 0;
   if (both_steady) {
     MatchPrep Pf, Pb;
@@ -1728,8 +1756,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
         hipLaunchKernelGGL(k_match_ball2, dim3(ball_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBallBlock), 0, st, af, ab);
       }
       HIPCHK(ctx, hipGetLastError());
-      HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts, f->d2lb);
-      HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts, b->d2lb);
+      HardArgs hf = hard_args_of(f, Pf, ctx->lane[0], true), hb = hard_args_of(b, Pb, ctx->lane[1], true);
       if (Pf.cert && Pb.cert && ctx->prof) {
         hf.stats = hb.stats = ctx->d_cert_stats;
         hf.seen = (unsigned long long)Pf.N; hb.seen = (unsigned long long)Pb.N;
@@ -1752,7 +1779,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
   // Coarse levels (both subsets sparse and small, keyed permutations): one stream, three launches for both directions
   // — list positions + work lists, wave-per-query search (around the previous match where there is one), brute force
   // for what is left.
-  if ((method == LRR_ICP_NN_GRID || method == LRR_ICP_NN_AUTO) && !order_f && !order_b && keys_f && keys_b && n_f > 0 && n_b > 0 &&
+  if ((method == LRR_ICP_NN_GRID || method == LRR_ICP_NN_AUTO || method == LRR_ICP_NN_VORONOI) && !order_f && !order_b && keys_f && keys_b && n_f > 0 && n_b > 0 &&
       n_f * 4 < f->from->n && n_b * 4 < b->from->n && n_f <= kCoarseMax && n_b <= kCoarseMax && std::getenv("LRR_ICP_NO_COARSE_PAIR") == nullptr) {
     MatchPrep Pf, Pb;
     hipStream_t st = ctx->stream;
@@ -1768,8 +1795,7 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
     ctx->k1_paths[LRR_ICP_K1_COARSE_PAIR] += 2;
     hipLaunchKernelGGL(k_slots_coarse2, dim3(blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kBlock), 0, st, cf, cb);
     HIPCHK(ctx, hipGetLastError());
-    HardArgs hf = hard_args(ctx->lane[0], f->to, Pf.g, Pf.q, Pf.x, f->m_to, Pf.counts);
-    HardArgs hb = hard_args(ctx->lane[1], b->to, Pb.g, Pb.q, Pb.x, b->m_to, Pb.counts);
+    HardArgs hf = hard_args_of(f, Pf, ctx->lane[0], false), hb = hard_args_of(b, Pb, ctx->lane[1], false);
     hipLaunchKernelGGL(k_match_hard2, dim3(hard_blocks_for(std::max(n_f, n_b)), 2), dim3(kBlock), 0, st, hf, hb);
     HIPCHK(ctx, hipGetLastError());
     return LRR_ICP_OK;

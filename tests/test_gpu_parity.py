@@ -439,8 +439,8 @@ def test_certificate_skips_only_provable_matches(E, ob):
     """K1 at the finest level keeps the previous match of a source without searching when a second-nearest bound
     proves it is still the unique nearest neighbour.  Sequences of searches whose transform moves by 0, 1e-7, 1e-4,
     1e-2 and 0.3 mm (rotation included), on a noisy cloud pair and on a lattice pair full of exact ties (a tie can
-    never be certified): every search equals the oracle's, and the certificate did skip most searches of the small
-    steps."""
+    never be certified once the query has moved; an unmoved query keeps its answer): every search equals the oracle's,
+    and the certificate did skip most searches of the small steps."""
     timer = E.DeviceTimer()
     rng = np.random.default_rng(8)
 
@@ -481,8 +481,12 @@ def test_certificate_skips_only_provable_matches(E, ob):
         n = loc.shape[0]
         return synth.FeatureSet(loc, np.tile(np.eye(3).ravel(), (n, 1)), np.ones(n), np.full(n, 2, np.uint8),
                                 np.tile(np.array([0, 0, 1.0, 1.0, 0, 0]), (n, 1)))
-    seen, searched = run(feats(mloc), feats(floc), [0.0, 0.0, 0.0, 1e-9, 0.0, 0.25, 0.0, 0.0], False)
-    assert searched > 0.9 * seen * 5 / 8  # ties are never certified (the first two searches do not run the kernel)
+    seen, searched = run(feats(mloc), feats(floc), [0.0, 0.0, 1e-9, 2e-9, 1e-9, 0.25, 1e-9, 2e-9], False)
+    assert searched > 0.9 * seen * 5 / 8  # a tie is never certified once the query has moved (the first two searches do not run the kernel)
+    # ... but a query that has not moved at all keeps its answer, tie or not (the same question has the same answer: the
+    # usual case under the Voronoi-lookup semantics, where mapped points are rounded to their voxel)
+    seen, searched = run(feats(mloc), feats(floc), [0.0, 0.0, 0.0, 0.0, 0.0], False)
+    assert seen > 0 and searched == 0
 
 
 def test_match_ties_through_every_search_path(E, ob):
