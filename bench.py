@@ -71,8 +71,8 @@ def parse():
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a rendezvous in the environment: this process has made no GPU call (torch is not
     even imported yet) and starts the N ranks as children through torch.distributed.run, one per GPU, rendezvous on
-    127.0.0.1; rank 0's JSON line goes to the inherited stdout.  Never an exec: the parent waits and returns the
-    children's exit code."""
+    127.0.0.1; rank 0's JSON line is passed through to stdout (anything else the children write there goes to stderr).  Never
+    an exec: the parent waits and returns the children's exit code."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -83,7 +83,22 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    # the contract is ONE JSON line on stdout: whatever else the children (or the collective library under them) write to
+    # stdout goes to stderr, rank 0's line is printed last
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        rc = 1
+    return rc
 
 
 def _oracle_iterations(pair, T0, n, iters, nn_backend, out, k):

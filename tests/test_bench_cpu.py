@@ -15,15 +15,25 @@ def _bench():
     return importlib.import_module("bench")
 
 
-def test_gpus_flag_starts_the_ranks(monkeypatch):
+class _FakeProc:
+    """stands in for the torch.distributed.run child: some noise on stdout, then rank 0's line"""
+
+    def __init__(self, lines, rc=0):
+        self.stdout, self._rc = iter(lines), rc
+
+    def wait(self):
+        return self._rc
+
+
+def test_gpus_flag_starts_the_ranks(monkeypatch, capsys):
     bench = _bench()
     seen = {}
 
-    def fake_call(cmd, env=None):
+    def fake_popen(cmd, env=None, stdout=None, text=None):
         seen["cmd"], seen["env"] = cmd, env
-        return 0
+        return _FakeProc(["[Gloo] Rank 0 is connected to 3 peer ranks.\n", '{"metric": "ICP matched-feature-pairs/sec", "n_gpus": 4}\n'])
 
-    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
     assert bench.main() == 0
@@ -35,13 +45,24 @@ def test_gpus_flag_starts_the_ranks(monkeypatch):
     k = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[k + 1:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"]  # the ranks get the same arguments
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # ONE JSON line on stdout, whatever else the children wrote there goes to stderr
+    io = capsys.readouterr()
+    assert io.out.strip() == '{"metric": "ICP matched-feature-pairs/sec", "n_gpus": 4}' and "Gloo" in io.err
+
+
+def test_ranks_without_a_result_line_are_a_failure(monkeypatch):
+    bench = _bench()
+    monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: _FakeProc(["noise\n"]))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    assert bench.main() != 0
 
 
 def test_a_rank_does_not_spawn_again(monkeypatch):
     """inside a rank (WORLD_SIZE set by torch.distributed.run) --gpus N must not start ranks of its own"""
     bench = _bench()
     called = []
-    monkeypatch.setattr(subprocess, "call", lambda *a, **k: called.append(a) or 0)
+    monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: called.append(a) or _FakeProc([]))
     monkeypatch.setenv("WORLD_SIZE", "4")
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--code-stamp"])
     assert bench.main() == 0 and not called
@@ -49,8 +70,13 @@ def test_a_rank_does_not_spawn_again(monkeypatch):
 
 def test_the_parent_makes_no_gpu_call():
     """the spawning parent must not have initialised the GPU (not even imported torch) when it starts its children"""
-    code = ("import sys, subprocess; sys.argv=['bench.py','--gpus','2']; subprocess.call=lambda *a, **k: 0; import os; os.environ.pop('WORLD_SIZE', None);"
-            f"sys.path.insert(0, {ROOT!r}); import bench; rc = bench.main(); assert rc == 0; assert 'torch' not in sys.modules, 'torch imported by the parent'")
+    code = ("import sys, subprocess, os\n"
+            "class P:\n"
+            "    stdout = iter(['{\"metric\": 1}\\n'])\n"
+            "    def wait(self): return 0\n"
+            "sys.argv = ['bench.py', '--gpus', '2']; subprocess.Popen = lambda *a, **k: P(); os.environ.pop('WORLD_SIZE', None)\n"
+            f"sys.path.insert(0, {ROOT!r}); import bench; rc = bench.main(); assert rc == 0\n"
+            "assert 'torch' not in sys.modules, 'torch imported by the parent'\n")
     subprocess.check_call([sys.executable, "-c", code])
 
 
