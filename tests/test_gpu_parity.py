@@ -444,10 +444,12 @@ def test_certificate_skips_only_provable_matches(E, ob):
     timer = E.DeviceTimer()
     rng = np.random.default_rng(8)
 
-    def run(mv, fx, steps, expect_skips):
+    def run(mv, fx, steps, expect_skips, voronoi=False):
         I, z = np.eye(3), np.zeros(3)
-        g = E.Estimator(E.RRL_SYMMETRIC, 12, mv, fx, I, z, z, moving_inside=mv, fixed_inside=fx, seed=9)
-        c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, mv, fx, I, z, z, moving_inside=mv, fixed_inside=fx, seed=9)
+        g = E.Estimator(E.RRL_SYMMETRIC, 12, mv, fx, I, z, z, moving_inside=mv, fixed_inside=fx, seed=9,
+                        nn_method=E.NN_VORONOI if voronoi else E.NN_AUTO)
+        c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, mv, fx, I, z, z, moving_inside=mv, fixed_inside=fx, seed=9,
+                               nn_backend=ob.NN_VORONOI if voronoi else ob.NN_KDTREE)
         timer.match_profile(enable=True, reset=True)
         timer.cert_stats(reset=True)
         T = synth.Transform(synth.rotation_xyz(0.01, -0.02, 0.015), np.array([0.3, -0.2, 0.1]), np.array([5.0, 5.0, 5.0]))
@@ -473,6 +475,10 @@ def test_certificate_skips_only_provable_matches(E, ob):
 
     pair = synth.make_pair(30000, 30000, 404, kind="affine")
     run(pair.moving, pair.fixed, [0.0, 0.0, 0.0, 1e-7, 1e-7, 1e-4, 1e-4, 1e-2, 1e-2, 0.3, 0.3, 0.0, 1e-7], True)
+    # the lookup semantics of the Voronoi maps: sites on the voxel lattice (ties everywhere), queries rounded to voxel
+    # centres — a query that stays in its voxel keeps its answer, one that crosses a face is searched again; steps from far
+    # below a voxel to a third of one, then back to rest
+    run(pair.moving, pair.fixed, [0.0, 0.0, 0.0, 1e-7, 1e-4, 1e-4, 1e-2, 1e-2, 0.05, 0.05, 0.3, 0.3, 0.0, 1e-7, 1e-3], True, voronoi=True)
     # lattice with duplicates: every query has exactly equidistant targets or a duplicate runner-up
     floc = rng.integers(0, 14, size=(9000, 3)).astype(np.float64)
     mloc = rng.integers(0, 14, size=(8000, 3)).astype(np.float64) + 0.5
