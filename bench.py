@@ -321,11 +321,28 @@ def locations_measure(args, rank, local_rank, world, cpu=True):
         times.append(time.perf_counter() - t0)
         if not sequential:
             phases.append(batch.last_timing())
+    vor = None
     if sequential:
         for e in ests:
             if e is not None:
                 e.close()
     else:
+        if world == 1 and not args.no_voronoi:
+            # the same batch with the lookup semantics of the Voronoi maps (what rrl_location_batch::set_voronoi_maps() selects)
+            batch.set_nn_method(E.NN_VORONOI)
+            locations.register_locations(pair, rois, inits, 0, 1, batch=batch)  # builds the site clouds, sizes the buffers
+            vt = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                vrows, vpairs = locations.register_locations(pair, rois, inits, 0, 1, batch=batch)
+                torch.cuda.synchronize()
+                vt.append(time.perf_counter() - t0)
+            vdt = float(np.median(vt))
+            VC = E.LocationBatch.COL
+            vor = {"what": "the same locations matched with the lookup semantics of the 1 mm Voronoi maps (LRR_ICP_NN_VORONOI)",
+                   "locations_per_s": len(rois) / vdt, "value": vpairs / vdt, "unit": "pairs/s", "ms_total": 1e3 * vdt,
+                   "converged": int(vrows[:, VC["converged"]].sum()), "mean_iterations": float(vrows[:, VC["iterations"]].mean())}
         batch.close()
     dt = float(np.median(times))
     ph = phases[int(np.argsort(times)[len(times) // 2])] if phases else {}
@@ -369,6 +386,8 @@ def locations_measure(args, rank, local_rank, world, cpu=True):
     if cpu and world == 1 and not args.no_cpu_baseline and not sequential:
         rec["cpu_baseline"] = cpu_locations(pair, rois, inits, rows, args.cpu_locations)
         rec["speedup_vs_cpu_1thread"] = rec["value"] / rec["cpu_baseline"]["value"]
+    if vor is not None:
+        rec["voronoi"] = vor
     return rec
 
 

@@ -222,6 +222,15 @@ class rrl_location_batch {
   void set_check_valid_transform(bool on) { check_valid_ = on; } // `if (!validTransform(...)) break;` (:2482)
   void set_device_loop(bool on) { device_loop_ = on; }           // false: the host half of every iteration on the host
   void set_sampling(double voxel_spacing, double interval) { voxel_spacing_ = voxel_spacing; sample_interval_ = interval; }
+  // The caller hands the two 1 mm Voronoi index volumes to every location's estimator (set_voronoi_maps,
+  // rrl/itkLocationRegistration.cxx:1641-1643).  Here once for the batch: every location is then matched with the maps'
+  // lookup semantics (LRR_ICP_NN_VORONOI; the images are not read), unless lrr_amd::voronoi_lookup::enable(false) /
+  // LRR_ICP_VORONOI=0 keeps the exact search — the same rule as icp_symmetric::set_voronoi_maps.
+  template <class VoronoiPointer> void set_voronoi_maps(VoronoiPointer const &, VoronoiPointer const &) {
+    if (voronoi_lookup::enabled()) check(lrr_icp_batch_set_nn_method(batch_, LRR_ICP_NN_VORONOI), "batch matcher");
+    else { voronoi_lookup::note_exact(); check(lrr_icp_batch_set_nn_method(batch_, LRR_ICP_NN_GRID), "batch matcher"); }
+  }
+  void set_nn_method(int method) { check(lrr_icp_batch_set_nn_method(batch_, method), "batch matcher"); }
   lrr_icp_batch *handle() const { return batch_; }
   // wall-clock milliseconds of the phases of the last run() (roi, host, iterate, rebuild, angles, ...): what bench.py prices
   // the device-bound part of a batch with

@@ -263,6 +263,10 @@ typedef struct lrr_icp_batch lrr_icp_batch;
 int  lrr_icp_batch_create(lrr_icp_ctx *ctx, lrr_icp_cloud *moving_all, lrr_icp_cloud *fixed_all, lrr_icp_batch **out);
 void lrr_icp_batch_destroy(lrr_icp_batch *batch);
 int64_t lrr_icp_batch_size(const lrr_icp_batch *batch);
+/* the matcher of every location: LRR_ICP_NN_AUTO / _GRID = exact nearest neighbour (default); LRR_ICP_NN_VORONOI = the lookup
+ * semantics of the 1 mm Voronoi maps the caller hands to every estimator (set_voronoi_maps, rrl sym .txx:293-299; the lookup
+ * rrl/rrl_estimation_ICP_matching_all.txx:530-543).  Call before lrr_icp_batch_set_rois. */
+int  lrr_icp_batch_set_nn_method(lrr_icp_batch *batch, int method);
 /* FeaturesInROIs (rrl/itkLocationRegistration.cxx:1324-1360) for B locations at once, on the device:
  * box b = {x0[3], x1[3]}; a feature is inside when x0[d] <= p[d] <= x1[d] for every d; the ROI list keeps
  * the volume's original order.  Also set_features: matches and schedule state of every location are

@@ -446,6 +446,15 @@ lrr_est_batch *lrr_est_batch_create(const lrr_est_features *moving, const lrr_es
   return rc ? nullptr : reinterpret_cast<lrr_est_batch *>(out);
 }
 void lrr_est_batch_destroy(lrr_est_batch *b) { delete BT(b); }
+// the batch's matcher: method >= 0: set_nn_method(method); method < 0: the caller's set_voronoi_maps() (null images), after
+// lrr_amd::voronoi_lookup::enable(lookup != 0) when lookup >= 0
+int lrr_est_batch_set_matcher(lrr_est_batch *b, int method, int lookup) {
+  return guard([&] {
+    if (method >= 0) { BT(b)->set_nn_method(method); return; }
+    if (lookup >= 0) lrr_amd::voronoi_lookup::enable(lookup != 0);
+    BT(b)->set_voronoi_maps((const void *)0, (const void *)0);
+  });
+}
 lrr_icp_batch *lrr_est_batch_handle(lrr_est_batch *b) { return BT(b)->handle(); }
 
 int lrr_est_batch_run(lrr_est_batch *bt, int64_t B, const double *A0, const double *t0, const double *c0, const double *moving_box,

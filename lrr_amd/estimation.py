@@ -35,7 +35,7 @@ ICP_SYMBOLS = [
     "lrr_icp_estimate_symmetric", "lrr_icp_estimate_forward",
     "lrr_icp_nearest", "lrr_icp_debug_set_match", "lrr_icp_cloud_set_covariances", "lrr_icp_cdc_compute_weights",
     "lrr_icp_cdc_set_create", "lrr_icp_cdc_set_destroy", "lrr_icp_cdc_set_compute_weights", "lrr_icp_cdc_set_get", "lrr_icp_cdc_set_stats", "lrr_icp_cdc_set_row_sums", "lrr_icp_cdc_set_renormalize", "lrr_icp_cdc_set_premap", "lrr_icp_cdc_set_closest_euclidean", "lrr_icp_cdc_objective_par", "lrr_icp_cdc_objective_cov", "lrr_icp_cdc_normalize_stats",
-    "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
+    "lrr_icp_batch_create", "lrr_icp_batch_destroy", "lrr_icp_batch_size", "lrr_icp_batch_set_nn_method", "lrr_icp_batch_set_rois", "lrr_icp_batch_get_roi",
     "lrr_icp_batch_match", "lrr_icp_batch_estimate", "lrr_icp_batch_errors", "lrr_icp_batch_angles", "lrr_icp_batch_iterate",
     "lrr_icp_batch_num_matches", "lrr_icp_batch_get_matches",
 ]
@@ -671,6 +671,22 @@ class LocationBatch:
             self._h = None
 
     __del__ = close
+
+    def set_nn_method(self, method):
+        """NN_AUTO / NN_GRID: exact search (default); NN_VORONOI: the lookup semantics of the 1 mm Voronoi maps"""
+        L = est_lib()
+        L.lrr_est_batch_set_matcher.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if L.lrr_est_batch_set_matcher(self._h, int(method), -1) != 0:
+            raise RuntimeError(L.lrr_est_last_error().decode())
+
+    def set_voronoi_maps(self, lookup=None):
+        """rrl_location_batch::set_voronoi_maps() as the caller of the reference issues it per estimator (the images are never
+        read); lookup: None = the process default (the maps' semantics unless LRR_ICP_VORONOI=0), True / False =
+        lrr_amd::voronoi_lookup::enable() first"""
+        L = est_lib()
+        L.lrr_est_batch_set_matcher.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if L.lrr_est_batch_set_matcher(self._h, -1, -1 if lookup is None else int(bool(lookup))) != 0:
+            raise RuntimeError(L.lrr_est_last_error().decode())
 
     def run(self, A0, t0, c0, moving_box, fixed_box, seeds, max_iterations=70, diagnostics=True, check_valid=True):
         """A0 (B,3,3), t0 (B,3), c0 (B,3): initial transforms; *_box (B,6): x0, x1 of the ROIs; seeds (B,).

@@ -73,15 +73,21 @@ def test_device_roi_selection_equals_numpy(E, monkeypatch, form):
     bt.close()
 
 
-def test_batch_equals_one_at_a_time_and_oracle(E, ob):
+@pytest.mark.parametrize("matcher", ["exact", "voronoi"])
+def test_batch_equals_one_at_a_time_and_oracle(E, ob, matcher):
     """config 5 in miniature: 6 locations x 40k-feature volumes.  Batch rows against the sequential class
     path per location (exact flags / iteration counts / final match sets, transforms to rounding), and the
-    sequential path's oracle twin for two of them."""
+    sequential path's oracle twin for two of them.  matcher = voronoi: the caller has handed the Voronoi maps over
+    (rrl_location_batch::set_voronoi_maps(), as per estimator in rrl/itkLocationRegistration.cxx:1641-1643): every location is
+    matched with the maps' lookup semantics, like the class after its own set_voronoi_maps() and the oracle's Voronoi backend."""
     from lrr_amd import locations
     pair, rois, inits, mbox, fbox, seeds = _setup(40000, 6, 20247, 50.0)
     B = len(rois)
     assert B == 6
+    vor = matcher == "voronoi"
     bt = E.LocationBatch(pair.moving, pair.fixed)
+    if vor:
+        bt.set_voronoi_maps(True)
     A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
     rows = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=locations.MAX_ITERATIONS, diagnostics=False)
     C = bt.COL
@@ -89,6 +95,8 @@ def test_batch_equals_one_at_a_time_and_oracle(E, ob):
         m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[b]
         g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in,
                         seed=int(seeds[b]))
+        if vor:
+            g.set_voronoi_maps(True)
         conv, its, npairs = g.run_counted(locations.MAX_ITERATIONS, check_valid=True)
         assert bool(rows[b, C["converged"]]) == conv and int(rows[b, C["iterations"]]) == its, b
         assert int(rows[b, C["matched_pairs"]]) == npairs
@@ -106,7 +114,7 @@ def test_batch_equals_one_at_a_time_and_oracle(E, ob):
         g.close()
         if b < 2:
             o = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in,
-                                   fixed_inside=f_in, seed=int(seeds[b]))
+                                   fixed_inside=f_in, seed=int(seeds[b]), nn_backend=ob.NN_VORONOI if vor else ob.NN_KDTREE)
             oconv, oits = o.run(locations.MAX_ITERATIONS)
             assert bool(rows[b, C["converged"]]) == oconv and int(rows[b, C["iterations"]]) == oits
             Ao, to, _, _ = o.get_transform()
