@@ -34,6 +34,21 @@ __device__ __forceinline__ bool grid_barrier(Bar *b, unsigned nblocks, unsigned 
 }
 
 // work: y[i] = a * x[i] + stage over n doubles, grid-stride; then barrier; repeated `stages` times
+__global__ __launch_bounds__(256) void k_persist_xcd(Bar *b, const double *x, double *y, int n, int stages, int do_work) {
+  // only the workgroups of ONE XCD take part (workgroups go round robin over the 8 XCDs): the barrier's atomics and the data
+  // stay in that XCD's L2
+  if (blockIdx.x & 7) return;
+  unsigned gen = 0;
+  const unsigned nb = gridDim.x >> 3, bid = blockIdx.x >> 3;
+  for (int s = 0; s < stages; ++s) {
+    if (do_work) {
+      const double *in = (s & 1) ? y : x;
+      double *out = (s & 1) ? (double *)x : y;
+      for (int i = bid * 256 + threadIdx.x; i < n; i += nb * 256) out[i] = in[i] * 1.0000001 + s;
+    }
+    if (!grid_barrier(b, nb, gen)) return;
+  }
+}
 __global__ __launch_bounds__(256) void k_persist(Bar *b, const double *x, double *y, int n, int stages, int do_work) {
   unsigned gen = 0;
   const unsigned nb = gridDim.x;
@@ -82,6 +97,23 @@ int main() {
       float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
       Bar hb; CK(hipMemcpy(&hb, b, sizeof hb, hipMemcpyDeviceToHost));
       printf("persistent grid %5d work %d: %.2f us per stage+barrier (fail %u)\n", grid, work, 1000.0 * ms / stages, hb.fail);
+    }
+  }
+  for (int per_xcd = 8; per_xcd <= 64; per_xcd *= 2) {
+    for (int work = 0; work < 2; ++work) {
+      const int grid = 8 * per_xcd;
+      int nn = work ? 16384 * 6 : n, stg = stages, w = work;  // a coarse level: 16k pairs
+      void *args[] = { &b, &x, &y, &nn, &stg, &w };
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipMemsetAsync(b, 0, sizeof(Bar), st));
+        CK(hipEventRecord(e0, st));
+        CK(hipLaunchCooperativeKernel((const void *)k_persist_xcd, dim3(grid), dim3(256), args, 0, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+      }
+      float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+      Bar hb; CK(hipMemcpy(&hb, b, sizeof hb, hipMemcpyDeviceToHost));
+      printf("one XCD, %3d workgroups, work %d (0.8 MB per stage): %.2f us per stage+barrier (fail %u)\n", per_xcd, work, 1000.0 * ms / stages, hb.fail);
     }
   }
   for (int work = 0; work < 2; ++work) {
