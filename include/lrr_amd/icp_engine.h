@@ -515,15 +515,15 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     o.dof = (int)dof;
     o.normalize = normalize_matches_ ? 1 : 0;
     o.strength = weight_by_strength_ ? 1 : 0;
-    o.rigid_transform = is_rigid() ? 1 : 0;
-    o.rigid_increment = (!RRL && is_rigid()) ? 1 : 0;
+    o.rigid_transform = is_rigid_transform() ? 1 : 0;  // (cdcl_trans_rigid3d::normalize keeps its centre, whichever class calls it)
+    o.rigid_increment = is_rigid() ? 1 : 0;
     o.injected = 0.0;
     if (scale_estimated_) o.scale_mode = LRR_ICP_SCALE_RMS;
     else if (injected_scale_ > 0.0) { o.scale_mode = LRR_ICP_SCALE_INJECTED; o.injected = injected_scale_; }
     else o.scale_mode = LRR_ICP_SCALE_MUSE;
     // centre of the transform as the accumulation sees it: the affine normalize() zeroes it
     // (cdcl_trans_affine.txx:252), the rigid one keeps it (cdcl_trans_rigid3d.cxx:260-280)
-    for (int d = 0; d < 3; ++d) o.jac_centre[d] = (normalize_matches_ && !is_rigid()) ? 0.0 : trans_->center_moving_[d];
+    for (int d = 0; d < 3; ++d) o.jac_centre[d] = (normalize_matches_ && !is_rigid_transform()) ? 0.0 : trans_->center_moving_[d];
     lrr_icp_xform xf = xform_of(trans_);
     lrr_icp_sym_out r;
     check(lrr_icp_estimate_forward(dir_, &xf, &o, &r), "fused forward estimate");
@@ -646,7 +646,10 @@ class icp_direction : public cdcl_estimation_abs<3, dof, FeatureT> {
     for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) x.A[3 * r + c] = A(r, c); x.t[r] = t[r]; x.c[r] = T->center_moving_[r]; }
     return x;
   }
-  bool is_rigid() const { return !RRL && dof == 6 && trans_->is_type(cdcl_trans_rigid3d::type_id()); }
+  // the rigid INCREMENT (pre-mapped from_ copies, recompose_increment) is the cdcl classes' (cdcl .txx:434-509); the rrl classes
+  // estimate a cdcl_trans_rigid3d like any other transform
+  bool is_rigid() const { return !RRL && is_rigid_transform(); }
+  bool is_rigid_transform() const { return dof == 6 && trans_->is_type(cdcl_trans_rigid3d::type_id()); }
   void init_state() {
     dir_ = nullptr;
     rng_ = 1;

@@ -243,7 +243,7 @@ def _compare_iteration(g, c, it, dirs, tol=1e-8):
     return cg
 
 
-@pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("RRL_FORWARD", 12)])
+@pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("RRL_FORWARD", 12), ("RRL_FORWARD", 6)])
 def test_forward_run_matches_oracle_config1(E, ob, kind_name, dof):
     """config 1: 5k x 5k, rigid3d init = identity, faithful run() (1000 points, <= 30 iterations)"""
     pair = synth.make_pair(5000, 5000, 20241, kind="rigid" if dof == 6 else "affine")
@@ -263,7 +263,7 @@ def test_forward_run_matches_oracle_config1(E, ob, kind_name, dof):
     g.close()
 
 
-@pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("RRL_FORWARD", 12)])
+@pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("RRL_FORWARD", 12), ("RRL_FORWARD", 6)])
 def test_forward_normalised_strength_weighted(E, ob, kind_name, dof):
     """estimate_LS of the forward classes with normalize_matches and weight_by_strength on: the fused
     forward estimate normalises the transform on the device (rigid: centre kept, affine: centre
@@ -728,6 +728,38 @@ def test_set_voronoi_maps_selects_the_lookup_semantics_by_default(E, ob):
     with pytest.raises(RuntimeError, match="no Voronoi-map setter"):
         f.set_voronoi_maps()
     f.close()
+
+
+@pytest.mark.parametrize("kind_name,dof", [("RRL_SYMMETRIC", 6), ("RRL_FORWARD", 12), ("RRL_FORWARD", 6)])
+def test_lookup_semantics_in_the_other_rrl_instantiations(E, ob, kind_name, dof):
+    """the Voronoi-lookup semantics behind set_voronoi_maps() / set_fixed_voronoi_map() for the rigid symmetric class and the
+    forward class (one direction: lrr_icp_match instead of lrr_icp_match_pair): the faithful schedule, iteration by iteration
+    against the oracle's Voronoi backend — coarse levels, growth, dense levels, certificate"""
+    import dataclasses
+    sym = kind_name == "RRL_SYMMETRIC"
+    pair = synth.make_pair(30000, 30000, 20246, kind="rigid" if dof == 6 else "affine")
+    # (clouds centred on the origin: the rigid classes with normalisation drift otherwise — the reference's normalize() leaves
+    # the rigid transform's centre where it was, DESIGN.md "reproduced defects")
+    shift = 150.0
+    pair = dataclasses.replace(pair, moving=dataclasses.replace(pair.moving, loc=pair.moving.loc - shift),
+                               fixed=dataclasses.replace(pair.fixed, loc=pair.fixed.loc - shift),
+                               planted=synth.Transform(pair.planted.A, pair.planted.t - shift, pair.planted.c - shift))
+    T0 = synth.perturbed(pair.planted, 4)
+    args = dict(moving_inside=pair.moving if sym else None, fixed_inside=pair.fixed if sym else None, seed=33)
+    g = E.Estimator(getattr(E, kind_name), dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c, **args)
+    g.set_voronoi_maps(True)
+    c = ob.OracleEstimator(getattr(ob, kind_name), dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c, nn_backend=ob.NN_VORONOI, **args)
+    if not sym:
+        for e in (g, c):
+            e.normalize_matches()
+            e.weight_by_strength(True)
+            e.set_transform(T0.A, T0.t, T0.c)
+            e.set_number_points(30000)
+    for it in range(25):
+        if _compare_iteration(g, c, it, (0, 1) if sym else (0,)):
+            break
+    assert it >= 3
+    g.close()
 
 
 @pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("CDCL_SYMMETRIC", 6), ("CDCL_SYMMETRIC", 12)])
