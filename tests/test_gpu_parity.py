@@ -730,8 +730,9 @@ def test_set_voronoi_maps_selects_the_lookup_semantics_by_default(E, ob):
     f.close()
 
 
+@pytest.mark.parametrize("lookup", [True, False])
 @pytest.mark.parametrize("kind_name,dof", [("RRL_SYMMETRIC", 6), ("RRL_FORWARD", 12), ("RRL_FORWARD", 6)])
-def test_lookup_semantics_in_the_other_rrl_instantiations(E, ob, kind_name, dof):
+def test_lookup_semantics_in_the_other_rrl_instantiations(E, ob, kind_name, dof, lookup):
     """the Voronoi-lookup semantics behind set_voronoi_maps() / set_fixed_voronoi_map() for the rigid symmetric class and the
     forward class (one direction: lrr_icp_match instead of lrr_icp_match_pair): the faithful schedule, iteration by iteration
     against the oracle's Voronoi backend — coarse levels, growth, dense levels, certificate"""
@@ -747,8 +748,9 @@ def test_lookup_semantics_in_the_other_rrl_instantiations(E, ob, kind_name, dof)
     T0 = synth.perturbed(pair.planted, 4)
     args = dict(moving_inside=pair.moving if sym else None, fixed_inside=pair.fixed if sym else None, seed=33)
     g = E.Estimator(getattr(E, kind_name), dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c, **args)
-    g.set_voronoi_maps(True)
-    c = ob.OracleEstimator(getattr(ob, kind_name), dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c, nn_backend=ob.NN_VORONOI, **args)
+    g.set_voronoi_maps(lookup)   # (False: the same call keeps the exact search — the rrl <3,6> classes are in no other test)
+    c = ob.OracleEstimator(getattr(ob, kind_name), dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                           nn_backend=ob.NN_VORONOI if lookup else ob.NN_KDTREE, **args)
     if not sym:
         for e in (g, c):
             e.normalize_matches()
@@ -760,6 +762,7 @@ def test_lookup_semantics_in_the_other_rrl_instantiations(E, ob, kind_name, dof)
             break
     assert it >= 3
     g.close()
+    E.Estimator(E.RRL_FORWARD, 12, pair.moving.subset(np.arange(10)), pair.fixed.subset(np.arange(10)), T0.A, T0.t, T0.c).set_voronoi_maps(True)  # (process default back on)
 
 
 @pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("CDCL_SYMMETRIC", 6), ("CDCL_SYMMETRIC", 12)])
