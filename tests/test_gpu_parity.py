@@ -325,6 +325,20 @@ def test_symmetric_full_schedule_matches_oracle(E, ob, kind_name, dof):
     g.close()
 
 
+@pytest.mark.parametrize("kind_name,dof", [("RRL_SYMMETRIC", 12), ("CDCL_SYMMETRIC", 12), ("CDCL_SYMMETRIC", 6)])
+def test_symmetric_without_strength_weighting(E, ob, kind_name, dof):
+    """weight_by_strength(false) on the symmetric classes (the caller switches it on, rrl/itkLocationRegistration.cxx:1638: the
+    other setting is the classes' default): no strength gain, no gradient order statistic, spatial weights only"""
+    pair = synth.make_pair(20000, 19000, 777, kind="rigid" if dof == 6 else "affine")
+    T0 = synth.perturbed(pair.planted, 4)
+    g, c = _both(E, ob, getattr(E, kind_name), dof, pair, T0, 5, True)
+    for e in (g, c):
+        e.weight_by_strength(False)
+    for it in range(8):
+        _compare_iteration(g, c, it, (0, 1))
+    g.close()
+
+
 def test_roi_queries_set_features(E, ob):
     """config 5 in miniature: one estimator object re-used over query locations
     (set_features + set_transform, rrl/itkLocationRegistration.cxx:1635-1637)"""
