@@ -779,6 +779,22 @@ def test_lookup_semantics_in_the_other_rrl_instantiations(E, ob, kind_name, dof,
     E.Estimator(E.RRL_FORWARD, 12, pair.moving.subset(np.arange(10)), pair.fixed.subset(np.arange(10)), T0.A, T0.t, T0.c).set_voronoi_maps(True)  # (process default back on)
 
 
+def test_lookup_semantics_through_the_thread_per_slot_kernel(E, ob):
+    """the forward class's faithful run() keeps number_points_ at 1000 (of 12000 here): every search goes through the
+    thread-per-slot kernel (k_match_direct) and, with the lookup semantics, the pass that fetches the features behind the sites"""
+    pair = synth.make_pair(12000, 12000, 20249, kind="affine")
+    T0 = synth.perturbed(pair.planted, 3)
+    g = E.Estimator(E.RRL_FORWARD, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=17)
+    g.set_voronoi_maps(True)
+    c = ob.OracleEstimator(ob.RRL_FORWARD, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, seed=17, nn_backend=ob.NN_VORONOI)
+    timer = E.DeviceTimer()
+    timer.k1_path_counts(reset=True)
+    for it in range(6):
+        _compare_iteration(g, c, it, (0,))
+    assert timer.k1_path_counts()["direct"] >= 6, timer.k1_path_counts()
+    g.close()
+
+
 @pytest.mark.parametrize("kind_name,dof", [("CDCL_FORWARD", 6), ("CDCL_FORWARD", 12), ("CDCL_SYMMETRIC", 6), ("CDCL_SYMMETRIC", 12)])
 def test_cdcl_covariance_angles(E, ob, kind_name, dof):
     """sheet_angles / tube_angles of the cdcl classes compare eigenvectors of the features' covariances (cdcl .txx:273-382):
