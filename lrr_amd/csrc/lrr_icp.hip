@@ -105,7 +105,7 @@ struct SelJob {
   int row_a0, row_a1, row_b0, row_b1, col;
 };
 constexpr int kFoldStage = 192;     // in-window keys a block of the weight pass can stage per selection
-constexpr int kSelPack = 4;
+constexpr int kSelPack = 16;     // (the 30 order statistics of a pair of MUSE lists: two packs)
 struct SelPack { SelJob j[kSelPack]; };  // the jobs of one windowed selection, passed as a kernel argument
 
 
@@ -1870,12 +1870,81 @@ static double norm_inv_cdf(double p) {
   return x - u / (1.0 + x * u / 2.0);
 }
 
+// rrel_muset_obj(0,false): the candidate inlier fractions 0.25..0.95 step 0.05 of n residuals with their order-statistic constants
+struct MuseCandidate { int64_t k; double ek, sd, div; };
+static std::vector<MuseCandidate> muse_candidate_table(int64_t n) {
+  std::vector<MuseCandidate> cands;
+  for (double frac = 0.25; frac <= 0.95 + 0.00001; frac += 0.05) {
+    int64_t k = (int64_t)std::floor(frac * (double)n + 0.5);
+    if (k > n) k = n;
+    if (k <= 0) k = 1;
+    double pk = (double)k / (double)(n + 1), qk = 1.0 - pk;
+    double Qk = norm_inv_cdf((1.0 + pk) / 2.0);
+    double pQk = std::sqrt(2.0 / M_PI) * std::exp(-Qk * Qk / 2.0);
+    double Qp = 1.0 / pQk, Qpp = Qk / (pQk * pQk), Qppp = (1.0 + 2.0 * Qk * Qk) / (pQk * pQk * pQk);
+    double np2 = (double)n + 2.0;
+    double vrk = (pk * qk / np2) * Qp * Qp + (pk * qk / (np2 * np2)) * (2.0 * (qk - pk) * Qp * Qpp + pk * qk * (Qp * Qppp + Qpp * Qpp / 2.0));
+    double sd = std::sqrt(vrk);
+    if (Qk / sd < 3.0) continue;  // min_exp_kth_to_stddev_ratio
+    double div = (double)(n + 1) * std::sqrt(2.0 / M_PI) * (1.0 - std::exp(-Qk * Qk / 2.0));
+    cands.push_back({k, Qk, sd, div});
+  }
+  return cands;
+}
+static double muse_argmin(const std::vector<MuseCandidate> &cands, const double *res) {
+  bool at_start = true;
+  double best_sk = 0.0, best_obj = 0.0;
+  for (size_t c = 0; c < cands.size(); ++c) {
+    double vk = res[4 * c], sum_less = res[4 * c + 1], cnt_less = res[4 * c + 2];
+    // sum of the k smallest = sum of keys below the k-th value + copies of the k-th value
+    double sum_k = sum_less + ((double)cands[c].k - cnt_less) * vk;
+    double sk = sum_k / cands[c].div;
+    double obj = sk * cands[c].sd / cands[c].ek;
+    if (at_start || obj < best_obj) { at_start = false; best_sk = sk; best_obj = obj; }
+  }
+  return best_sk;
+}
+
+// MUSE of one or two LONG lists (the first estimate after set_transform at a fine level) in one go: see k_muse_sums
+constexpr int64_t kMuseLong = 32768;  // shorter lists: the single-workgroup select (microseconds there)
+static int muse_scale_long(lrr_icp_ctx *ctx, lrr_icp_dir *const *dirs, int nd, double *const *sigma) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<MuseCandidate> cands[2];
+  MuseList L[2];
+  double *d_out = ctx->d_final + kMaxRed;
+  int nj = 0, first[2] = {0, 0};
+  for (int q = 0; q < nd; ++q) {
+    lrr_icp_dir *d = dirs[q];
+    cands[q] = muse_candidate_table(d->n);
+    if ((int)cands[q].size() > kMuseMaxCand || nj + (int)cands[q].size() > kMaxSelJobs) return fail(ctx, LRR_ICP_ERR_STATE, "muse_scale: candidate table overflow");
+    first[q] = nj;
+    for (const MuseCandidate &c : cands[q]) {
+      SelJob j = make_job(d->key_s, (int)d->from->n, nullptr, 0, c.k - 1, d->n);  // keys of inactive sources are +inf and sort last
+      j.out = d_out + 4 * nj;
+      ctx->h_jobs[nj++] = j;
+    }
+    L[q].keys = d->key_s; L[q].n = (int)d->from->n; L[q].sel = d_out + 4 * first[q]; L[q].ncand = (int)cands[q].size();
+  }
+  if (nd == 1) { L[1] = L[0]; L[1].ncand = 0; L[1].n = 0; }
+  int rc = launch_select_kth(ctx, nj);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_muse_sums, dim3(kMuseBlocks, nd), dim3(kBlock), 0, ctx->stream, L[0], L[1], ctx->d_partials);
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_muse_final, dim3(2 * kMuseMaxCand, nd), dim3(64), 0, ctx->stream, L[0], L[1], (const double *)ctx->d_partials, kMuseBlocks);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, d_out, sizeof(double) * 4 * nj, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int q = 0; q < nd; ++q) *sigma[q] = muse_argmin(cands[q], ctx->h_pinned + 4 * first[q]);
+  return LRR_ICP_OK;
+}
+
 int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
   if (!d || !sigma) return LRR_ICP_ERR_ARG;
   lrr_icp_ctx *ctx = d->ctx;
   *sigma = 0.0;
   int64_t n = d->n;
   if (n <= 0) return LRR_ICP_OK;
+  if (n >= kMuseLong) { lrr_icp_dir *one[1] = {d}; double *out[1] = {sigma}; return muse_scale_long(ctx, one, 1, out); }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   // rrel_muset_obj(0,false): trimmed MUSE over inlier fractions 0.25..0.95 step 0.05
   struct Cand { int64_t k; double ek, sd, div; };
@@ -2241,6 +2310,13 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   WeightOpts wo;
   wo.rrl = o->rrl; wo.normalize = o->normalize; wo.strength_f = o->strength_f; wo.strength_b = o->strength_b;
   wo.mode_f = o->scale_mode_f; wo.mode_b = o->scale_mode_b; wo.inj_f = o->injected_f; wo.inj_b = o->injected_b;
+  if (wo.mode_f == LRR_ICP_SCALE_MUSE && wo.mode_b == LRR_ICP_SCALE_MUSE && F->n >= kMuseLong && B->n >= kMuseLong) {
+    lrr_icp_dir *both[2] = {F, B};  // two long lists: their order statistics and sums in the same launches
+    double *out2[2] = {&wo.inj_f, &wo.inj_b};
+    int rc = muse_scale_long(ctx, both, 2, out2);
+    if (rc) return rc;
+    wo.mode_f = wo.mode_b = LRR_ICP_SCALE_INJECTED;
+  }
   if (wo.mode_f == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &wo.inj_f); if (rc) return rc; wo.mode_f = LRR_ICP_SCALE_INJECTED; }
   if (wo.mode_b == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(B, &wo.inj_b); if (rc) return rc; wo.mode_b = LRR_ICP_SCALE_INJECTED; }
   if (o->normalize) {
