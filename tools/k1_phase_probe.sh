@@ -7,5 +7,5 @@ mkdir -p $out /tmp/prof
 cp -r lrr_amd include tools oracle /tmp/prof/ 2>/dev/null
 cd /tmp/prof
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -DLRR_PROFILE_K1 -Iinclude -o lrr_amd/liblrr_icp_hip.so lrr_amd/csrc/lrr_icp.hip 2> $GRAFT_REPO_ROOT/$out/build.err || { tail -5 $GRAFT_REPO_ROOT/$out/build.err; exit 1; }
-timeout -k 10 300 python tools/k1_phase_probe.py > $GRAFT_REPO_ROOT/$out/phases.txt 2> $GRAFT_REPO_ROOT/$out/phases.err || { grep -v "^[WIE]2026" $GRAFT_REPO_ROOT/$out/phases.err | tail -5; exit 1; }
+timeout -k 10 300 python ${PROBE:-tools/k1_phase_probe.py} > $GRAFT_REPO_ROOT/$out/phases.txt 2> $GRAFT_REPO_ROOT/$out/phases.err || { grep -v "^[WIE]2026" $GRAFT_REPO_ROOT/$out/phases.err | tail -5; exit 1; }
 cat $GRAFT_REPO_ROOT/$out/phases.txt
