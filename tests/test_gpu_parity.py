@@ -239,7 +239,7 @@ def _compare_iteration(g, c, it, dirs, tol=1e-8):
         assert abs(g.last_scale(d) - c.last_scale(d)) <= tol * c.last_scale(d), f"it {it} dir {d}: scale"
         Ag, t_g, c_g, _ = g.get_transform(d)
         Ac, t_c, c_c, _ = c.get_transform(d)
-        assert rel(Ag, Ac) < 1e-7 and rel(t_g, t_c) < 1e-7, f"it {it} dir {d}: transform"
+        assert rel(Ag, Ac) < max(1e-7, 10 * tol) and rel(t_g, t_c) < max(1e-7, 10 * tol), f"it {it} dir {d}: transform"
     return cg
 
 
@@ -337,6 +337,63 @@ def test_symmetric_without_strength_weighting(E, ob, kind_name, dof):
     for it in range(8):
         _compare_iteration(g, c, it, (0, 1))
     g.close()
+
+
+def test_random_option_combinations_against_oracle(E, ob):
+    """a seeded sweep over what the other tests fix by hand: class, degrees of freedom, normalisation and strength weighting
+    (forward classes), matcher semantics (rrl classes), cloud sizes, subset size, MUSE or an injected first scale — five
+    iterations each, device against oracle.  (Rigid transforms with normalisation get clouds centred on the origin: the
+    reference's defect otherwise, see test_forward_normalised_strength_weighted.)"""
+    import dataclasses
+    rng = np.random.default_rng(20260)
+    kinds = ["CDCL_FORWARD", "RRL_FORWARD", "CDCL_SYMMETRIC", "RRL_SYMMETRIC"]
+    done = 0
+    for trial in range(96):
+        kind = kinds[trial % 4]
+        sym = kind.endswith("SYMMETRIC")
+        dof = int(rng.choice([6, 12]))
+        rrl = kind.startswith("RRL")
+        nm, nf = int(rng.integers(400, 4000)), int(rng.integers(400, 4000))
+        normalize, strength = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        voronoi = rrl and bool(rng.integers(0, 2))
+        inject = bool(rng.integers(0, 2))
+        pair = synth.make_pair(nf, nm, 3000 + trial, kind="rigid" if dof == 6 else "affine", extent=80.0)
+        if dof == 6:
+            shift = 40.0
+            pair = dataclasses.replace(pair, moving=dataclasses.replace(pair.moving, loc=pair.moving.loc - shift),
+                                       fixed=dataclasses.replace(pair.fixed, loc=pair.fixed.loc - shift),
+                                       planted=synth.Transform(pair.planted.A, pair.planted.t - shift, pair.planted.c - shift))
+        T0 = synth.perturbed(pair.planted, 40 + trial, rot_deg=0.3, trans_mm=0.4)
+        args = dict(moving_inside=pair.moving if sym else None, fixed_inside=pair.fixed if sym else None, seed=100 + trial)
+        g = E.Estimator(getattr(E, kind), dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c, nn_method=E.NN_VORONOI if voronoi else E.NN_AUTO, **args)
+        c = ob.OracleEstimator(getattr(ob, kind), dof, pair.moving, pair.fixed, T0.A, T0.t, T0.c,
+                               nn_backend=ob.NN_VORONOI if voronoi else ob.NN_KDTREE, **args)
+        npts = int(rng.choice([min(nm, 1000), nm])) if not sym else None
+        for e in (g, c):
+            if not sym and normalize:
+                e.normalize_matches()
+            e.weight_by_strength(strength)
+            if inject:
+                e.inject_initial_scale(0.8, 0.9) if sym else e.inject_initial_scale(0.8)
+            e.set_transform(T0.A, T0.t, T0.c)
+            if npts:
+                e.set_number_points(npts)
+        what = (trial, kind, dof, nm, nf, normalize, strength, voronoi, inject, npts)
+        try:
+            for it in range(5):
+                # (match sets exact; weights and scales to 1e-6: the rigid rrl classes' small-angle updates amplify rounding
+                # differences to ~1e-7 by the fourth iteration)
+                _compare_iteration(g, c, it, (0, 1) if sym else (0,), tol=1e-6)
+        except AssertionError as err:
+            # (the rigid rrl classes can diverge — small-angle parameters estimated as absolute ones: both sides then
+            # carry NaN weights, which is agreement, not a difference)
+            both_diverged = rrl and dof == 6 and np.isnan(g.matches(0)[2]).any() and np.isnan(c.matches(0)[2]).any()
+            if not both_diverged:
+                raise AssertionError(f"{what}: {err}") from err
+        finally:
+            g.close()
+        done += 1
+    assert done == 96
 
 
 def test_roi_queries_set_features(E, ob):
