@@ -1938,66 +1938,54 @@ static int muse_scale_long(lrr_icp_ctx *ctx, lrr_icp_dir *const *dirs, int nd, d
   return LRR_ICP_OK;
 }
 
-int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
-  if (!d || !sigma) return LRR_ICP_ERR_ARG;
-  lrr_icp_ctx *ctx = d->ctx;
-  *sigma = 0.0;
-  int64_t n = d->n;
-  if (n <= 0) return LRR_ICP_OK;
-  if (n >= kMuseLong) { lrr_icp_dir *one[1] = {d}; double *out[1] = {sigma}; return muse_scale_long(ctx, one, 1, out); }
+// MUSE of one or two SHORT lists in one submission: a coarse level's few keys are gathered first (the selections then sweep n
+// keys instead of the whole cloud's array, mostly +inf for the inactive sources), every candidate's order statistic and the
+// sum below it come from a single-workgroup select (k_select: microseconds for a few thousand keys), one copy, one wait
+static int muse_scale_short(lrr_icp_ctx *ctx, lrr_icp_dir *const *dirs, int nd, double *const *sigma) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  // rrel_muset_obj(0,false): trimmed MUSE over inlier fractions 0.25..0.95 step 0.05
-  struct Cand { int64_t k; double ek, sd, div; };
-  std::vector<Cand> cands;
+  std::vector<MuseCandidate> cands[2];
   std::vector<SelJob> jobs;
-  // a coarse level's list: its few keys are gathered first, so the selections sweep n keys instead of the whole cloud's
-  // array (mostly +inf for the inactive sources) — the first estimate of a run dropped from 0.4 ms to microseconds per list
-  const double *keys = d->key_s;
-  int nkeys = (int)d->from->n;
-  if (n * 4 < d->from->n && !d->slot_lazy) {
-    if ((size_t)n > ctx->muse_cap) {
-      if (ctx->d_muse) (void)hipFree(ctx->d_muse);
-      ctx->d_muse = nullptr; ctx->muse_cap = 0;
-      HIPCHK(ctx, hipMalloc(&ctx->d_muse, sizeof(double) * (size_t)n));
-      ctx->muse_cap = (size_t)n;
-    }
-    hipLaunchKernelGGL(k_compact_by_slot, dim3(blocks_for(d->from->n)), dim3(kBlock), 0, ctx->stream, d->slot, d->key_s, (int)d->from->n, ctx->d_muse);
-    HIPCHK(ctx, hipGetLastError());
-    keys = ctx->d_muse;
-    nkeys = (int)n;
+  size_t need = 0;
+  for (int q = 0; q < nd; ++q) need += (size_t)dirs[q]->n;
+  if (need > ctx->muse_cap) {
+    if (ctx->d_muse) (void)hipFree(ctx->d_muse);
+    ctx->d_muse = nullptr; ctx->muse_cap = 0;
+    HIPCHK(ctx, hipMalloc(&ctx->d_muse, sizeof(double) * need));
+    ctx->muse_cap = need;
   }
-  for (double frac = 0.25; frac <= 0.95 + 0.00001; frac += 0.05) {
-    int64_t k = (int64_t)std::floor(frac * (double)n + 0.5);
-    if (k > n) k = n;
-    if (k <= 0) k = 1;
-    double pk = (double)k / (double)(n + 1), qk = 1.0 - pk;
-    double Qk = norm_inv_cdf((1.0 + pk) / 2.0);
-    double pQk = std::sqrt(2.0 / M_PI) * std::exp(-Qk * Qk / 2.0);
-    double Qp = 1.0 / pQk, Qpp = Qk / (pQk * pQk), Qppp = (1.0 + 2.0 * Qk * Qk) / (pQk * pQk * pQk);
-    double np2 = (double)n + 2.0;
-    double vrk = (pk * qk / np2) * Qp * Qp + (pk * qk / (np2 * np2)) * (2.0 * (qk - pk) * Qp * Qpp + pk * qk * (Qp * Qppp + Qpp * Qpp / 2.0));
-    double sd = std::sqrt(vrk);
-    if (Qk / sd < 3.0) continue;  // min_exp_kth_to_stddev_ratio
-    double div = (double)(n + 1) * std::sqrt(2.0 / M_PI) * (1.0 - std::exp(-Qk * Qk / 2.0));
-    cands.push_back({k, Qk, sd, div});
-    // keys of inactive sources are +inf and sort last
-    jobs.push_back(make_job(keys, nkeys, nullptr, 0, k - 1, n));
+  size_t off = 0;
+  int first[2] = {0, 0};
+  for (int q = 0; q < nd; ++q) {
+    lrr_icp_dir *d = dirs[q];
+    const int64_t n = d->n;
+    const double *keys = d->key_s;
+    int nkeys = (int)d->from->n;
+    if (n * 4 < d->from->n && !d->slot_lazy) {
+      hipLaunchKernelGGL(k_compact_by_slot, dim3(blocks_for(d->from->n)), dim3(kBlock), 0, ctx->stream, d->slot, d->key_s, (int)d->from->n, ctx->d_muse + off);
+      HIPCHK(ctx, hipGetLastError());
+      keys = ctx->d_muse + off;
+      nkeys = (int)n;
+      off += (size_t)n;
+    }
+    cands[q] = muse_candidate_table(n);
+    first[q] = (int)jobs.size();
+    for (const MuseCandidate &c : cands[q]) jobs.push_back(make_job(keys, nkeys, nullptr, 0, c.k - 1, n));  // keys of inactive sources are +inf and sort last
   }
   std::vector<double> res(4 * jobs.size() + 4);
   int rc = run_select(ctx, jobs, res.data(), true);
   if (rc) return rc;
-  bool at_start = true;
-  double best_sk = 0.0, best_obj = 0.0;
-  for (size_t c = 0; c < cands.size(); ++c) {
-    double vk = res[4 * c], sum_less = res[4 * c + 1], cnt_less = res[4 * c + 2];
-    // sum of the k smallest = sum of keys below the k-th value + copies of the k-th value
-    double sum_k = sum_less + ((double)cands[c].k - cnt_less) * vk;
-    double sk = sum_k / cands[c].div;
-    double obj = sk * cands[c].sd / cands[c].ek;
-    if (at_start || obj < best_obj) { at_start = false; best_sk = sk; best_obj = obj; }
-  }
-  *sigma = best_sk;
+  for (int q = 0; q < nd; ++q) *sigma[q] = muse_argmin(cands[q], res.data() + 4 * first[q]);
   return LRR_ICP_OK;
+}
+
+int lrr_icp_muse_scale(lrr_icp_dir *d, double *sigma) {
+  if (!d || !sigma) return LRR_ICP_ERR_ARG;
+  lrr_icp_ctx *ctx = d->ctx;
+  *sigma = 0.0;
+  if (d->n <= 0) return LRR_ICP_OK;
+  lrr_icp_dir *one[1] = {d};
+  double *out[1] = {sigma};
+  return d->n >= kMuseLong ? muse_scale_long(ctx, one, 1, out) : muse_scale_short(ctx, one, 1, out);
 }
 
 int lrr_icp_assign_weights(lrr_icp_dir *d, double sigma) {
@@ -2310,10 +2298,10 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   WeightOpts wo;
   wo.rrl = o->rrl; wo.normalize = o->normalize; wo.strength_f = o->strength_f; wo.strength_b = o->strength_b;
   wo.mode_f = o->scale_mode_f; wo.mode_b = o->scale_mode_b; wo.inj_f = o->injected_f; wo.inj_b = o->injected_b;
-  if (wo.mode_f == LRR_ICP_SCALE_MUSE && wo.mode_b == LRR_ICP_SCALE_MUSE && F->n >= kMuseLong && B->n >= kMuseLong) {
-    lrr_icp_dir *both[2] = {F, B};  // two long lists: their order statistics and sums in the same launches
+  if (wo.mode_f == LRR_ICP_SCALE_MUSE && wo.mode_b == LRR_ICP_SCALE_MUSE && (F->n >= kMuseLong) == (B->n >= kMuseLong)) {
+    lrr_icp_dir *both[2] = {F, B};  // both lists: their order statistics and sums in the same launches, one wait
     double *out2[2] = {&wo.inj_f, &wo.inj_b};
-    int rc = muse_scale_long(ctx, both, 2, out2);
+    int rc = F->n >= kMuseLong ? muse_scale_long(ctx, both, 2, out2) : muse_scale_short(ctx, both, 2, out2);
     if (rc) return rc;
     wo.mode_f = wo.mode_b = LRR_ICP_SCALE_INJECTED;
   }
