@@ -365,8 +365,10 @@ def test_two_rank_register_locations_equals_one_rank(E, tmp_path):
     assert np.array_equal(want[:, 19], np.arange(7))
 
 
-def test_config4_path_on_feature_files(E, ob, tmp_path):
-    """config 4 rehearsal: the example CT pair is a download link (not in the image), so the same path runs on a
+@pytest.mark.parametrize("matcher", ["voronoi", "exact"])
+def test_config4_path_on_feature_files(E, ob, tmp_path, matcher):
+    """(matcher: the tool's default is the production binary's — the lookup semantics of the Voronoi maps.)
+    config 4 rehearsal: the example CT pair is a download link (not in the image), so the same path runs on a
     synthetic pair written as feature FILES in the reference's layout: tools/run_config4.py reads the two .vtk
     (VTK XML PolyData) files, selects the ROIs on the device, registers every location and the rows are checked
     against the CPU oracle fed with the same files.  With LRR_CONFIG4_DIR set the real pair is run the same way."""
@@ -393,7 +395,7 @@ def test_config4_path_on_feature_files(E, ob, tmp_path):
         extra = ["--init", str(tmp_path / "init.txt"), "--roi", "80"]
     out = tmp_path / "rows.npy"
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_config4.py"), datadir, "--fixed", fixed, "--moving", moving,
-                        "--out", str(out)] + extra, capture_output=True, text=True, timeout=600)
+                        "--out", str(out), "--matcher", matcher] + extra, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     if "not run: data absent" in r.stdout:
         pytest.skip("config 4 not run: data absent")
@@ -418,7 +420,7 @@ def test_config4_path_on_feature_files(E, ob, tmp_path):
         fi, mi = fx.in_box(cf - half, cf + half), mv.in_box(cm - half, cm + half)
         assert fi.size == rec["n_fixed_inside"] and mi.size == rec["n_moving_inside"]
         o = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, mv, fx, A0, t0, np.zeros(3), moving_inside=mv.subset(mi), fixed_inside=fx.subset(fi),
-                               seed=locations.location_seed(7, b))
+                               seed=locations.location_seed(7, b), nn_backend=ob.NN_VORONOI if matcher == "voronoi" else ob.NN_KDTREE)
         # the caller's loop (rrl/itkLocationRegistration.cxx:2418-2482): stop at convergence, after 70 iterations or
         # when the affine part leaves the valid range (a ROI whose estimate collapses)
         conv, its, valid = False, 0, True

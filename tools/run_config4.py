@@ -8,7 +8,8 @@ lung-CT pair (README.md:22; not in this image and not fetchable: supply it).
 Reads `<DATADIR>/<fixed>_00.vtk` and `<DATADIR>/<moving>_00.vtk` (VTK XML PolyData written by ExtractFeatures;
 rrl/itkLocationRegistration.cxx:803-841) with the VTK-free reader, selects the ROI features of every query
 location on the device (:1324-1360, >= 1000 each :1632) and runs rrl_estimation_symmetric_ICP_matching_all<3,12>
-to convergence for all locations in one batch, then the caller's decision measurements (:1816-1871).
+to convergence for all locations in one batch — matched with the lookup semantics of the Voronoi maps the production
+binary uses (`--matcher exact`: the exact search) —, then the caller's decision measurements (:1816-1871).
 
 Query locations: FILE with one `x y z` (physical coordinates of the fixed volume) per line, default
 `<DATADIR>/<fixed>nodules.txt` (README.md:64) when it exists, else features sampled from the fixed volume.
@@ -39,6 +40,9 @@ def main():
     ap.add_argument("--max-locations", type=int, default=100)  # :2134
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--out")
+    ap.add_argument("--matcher", choices=["voronoi", "exact"], default="voronoi",
+                    help="voronoi: the lookup semantics of the 1 mm Voronoi maps the production binary hands to every estimator "
+                         "(set_voronoi_maps, rrl/itkLocationRegistration.cxx:1641-1643); exact: the exact nearest neighbour")
     a = ap.parse_args()
     ff, mf = os.path.join(a.datadir, a.fixed + "_00.vtk"), os.path.join(a.datadir, a.moving + "_00.vtk")
     if not (os.path.exists(ff) and os.path.exists(mf)):
@@ -71,6 +75,8 @@ def main():
     seeds = np.array([locations.location_seed(a.seed, i) for i in range(B)], dtype=np.uint64)
     E.set_device(int(os.environ.get("LRR_ICP_DEVICE", "0")))
     bt = E.LocationBatch(moving, fixed)
+    if a.matcher == "voronoi":
+        bt.set_voronoi_maps(True)
     rows = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=locations.MAX_ITERATIONS, diagnostics=True, check_valid=True)
     C = bt.COL
     for b in range(B):
