@@ -18,9 +18,11 @@
 #ifndef LRR_AMD_CDCL_ESTIMATION_H_
 #define LRR_AMD_CDCL_ESTIMATION_H_
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <stdexcept>
 #include <vector>
 
 #include "lrr_amd/icp_engine.h"
@@ -29,9 +31,32 @@
 namespace lrr_amd {
 
 // match rows of a moving / fixed pair, resident on the device
+// The device cloud of a vector of cdcl_feature objects (location_, covariance_, strength_: cdcl/cdcl_feature.h:21-64), n x 3 / n x 9 / n
+// row-major.  Such a feature has no error projector of its own: the cloud's projector slot takes the one the EM class's base derives from
+// the covariance wherever it needs one, the outer product of the eigenvector of the smallest eigenvalue — the point normal
+// (NORMAL_DISTANCES_FOR_ICP, cdcl/cdcl_estimation_ICP.txx:523-537 and :696-709).  cdcl_estimation_em_t::initialize() relies on it.
+inline lrr_icp_cloud *cdcl_feature_cloud(int64_t n, const double *loc, const double *cov9, const double *strength) {
+  if (n < 0 || (n > 0 && (!loc || !cov9 || !strength))) throw std::runtime_error("cdcl_feature_cloud: missing locations, covariances or strengths");
+  std::vector<double> proj(9 * (size_t)std::max<int64_t>(n, 1));
+  for (int64_t i = 0; i < n; ++i) {
+    double U[9], sv[3], V[9];
+    linalg::svd3(cov9 + 9 * i, U, sv, V);  // symmetric positive semi-definite: singular vectors = eigenvectors
+    int lo = 0;
+    for (int j = 1; j < 3; ++j) if (sv[j] < sv[lo]) lo = j;
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) proj[9 * (size_t)i + 3 * a + b] = V[3 * a + lo] * V[3 * b + lo];
+  }
+  lrr_icp_cloud *c = nullptr;
+  check(lrr_icp_cloud_create(device::ctx(), n, loc, proj.data(), strength, 0, &c), "cloud upload");
+  if (lrr_icp_cloud_set_covariances(c, cov9) != LRR_ICP_OK) {
+    lrr_icp_cloud_destroy(c);
+    throw std::runtime_error("cdcl_feature_cloud: covariance upload failed");
+  }
+  return c;
+}
+
 class cdc_match_rows {
  public:
-  cdc_match_rows(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, int max_matches = 100) : set_(nullptr), moving_(moving) {
+  cdc_match_rows(lrr_icp_cloud *moving, lrr_icp_cloud *fixed, int max_matches = 100) : set_(nullptr), moving_(moving), fixed_(fixed) {
     check(lrr_icp_cdc_set_create(moving, fixed, max_matches, &set_), "cdc_set_create");
   }
   ~cdc_match_rows() { if (set_) lrr_icp_cdc_set_destroy(set_); }
@@ -39,10 +64,11 @@ class cdc_match_rows {
   cdc_match_rows &operator=(const cdc_match_rows &) = delete;
   lrr_icp_cdc_set *handle() const { return set_; }
   lrr_icp_cloud *moving() const { return moving_; }
+  lrr_icp_cloud *fixed() const { return fixed_; }
 
  private:
   lrr_icp_cdc_set *set_;
-  lrr_icp_cloud *moving_;
+  lrr_icp_cloud *moving_, *fixed_;
 };
 
 // (cdcl/cdcl_obj_fun_par.h:24-52) constructor: matches + transform (its centre and covariance enter J_th C_theta J_th^T);
@@ -338,9 +364,68 @@ class cdcl_estimation_em_t {
     return parameters_converged && covariance_converged && std::sqrt(fro) < 1e-3;
   }
 
+  // (cdcl/cdcl_estimation.txx:70-84) initial weights and covariance from the base class cdcl_estimation_ICP at the current resolution:
+  // find_closest_euclidean() over ALL moving features (cdcl_estimation_ICP.txx:451-489) and estimate_LS() without the parameters
+  // (:646-750): residuals along the normal of the fixed feature's covariance (the projector cdcl_feature_cloud() stored), scale =
+  // 2 x MUSE (:557-582), Beaton-Tukey weights, trans_'s covariance = inverse of AtA.  weight_by_strength_ of the base is false and
+  // nothing in the reference sets it on this class: not offered.  The clouds must come from cdcl_feature_cloud().
+  void initialize() {
+    lrr_icp_dir *dir = closest_point_list(res_);
+    const int64_t nm = lrr_icp_cloud_size(moving_of(res_));
+    if (nm < 1) throw std::runtime_error("cdcl_estimation_em: initialize() without moving features");
+    std::vector<int64_t> order((size_t)nm);
+    for (int64_t i = 0; i < nm; ++i) order[(size_t)i] = i;  // moving_[res_] in its own order: no draw from the random stream
+    const uint32_t no_keys[4] = {0, 0, 0, 0};
+    lrr_icp_xform xf = xform(trans_);
+    check(lrr_icp_match(dir, &xf, no_keys, order.data(), nm, LRR_ICP_NN_GRID), "closest points");
+    lrr_icp_norm nm_stats;
+    for (int d = 0; d < 3; ++d) nm_stats.cm[d] = nm_stats.cf[d] = 0.0;
+    nm_stats.rm = nm_stats.rf = 1.0;
+    vnl_vector_fixed<double, 3> cm(0.0), cf(0.0);
+    if (normalize_matches_) {  // (:654-657)
+      check(lrr_icp_normalize_stats(dir, &nm_stats), "normalize statistics");
+      for (int d = 0; d < 3; ++d) { cm[d] = nm_stats.cm[d]; cf[d] = nm_stats.cf[d]; }
+      trans_->normalize(nm_stats.rm, nm_stats.rf, cm, cf);
+    }
+    xf = xform(trans_);
+    double S = 0.0, W = 0.0, sigma = 0.0;
+    check(lrr_icp_residual_pass(dir, &xf, &nm_stats, &S, &W), "residual pass");
+    check(lrr_icp_muse_scale(dir, &sigma), "MUSE scale");  // (the MAD scale computed first is overwritten, :562-572)
+    initial_scale_ = 2.0 * sigma;                           // (:580-582)
+    check(lrr_icp_assign_weights(dir, initial_scale_), "assign weights");
+    double AtA[dof * dof], Atb[dof];
+    const double centre[3] = {trans_->center_moving_[0], trans_->center_moving_[1], trans_->center_moving_[2]};
+    check(lrr_icp_accumulate(dir, (int)dof, centre, &nm_stats, is_rigid() ? LRR_ICP_ACC_RIGID_INCREMENT : 0, AtA, Atb), "normal equations");
+    solve_normal_equations<dof>(trans_, AtA, Atb, false);
+    if (normalize_matches_) trans_->unnormalize(nm_stats.rm, nm_stats.rf, cm, cf);  // (:738-742)
+  }
+  double initial_scale() const { return initial_scale_; }
+  // (cdcl/cdcl_estimation.txx:190-204)
+  bool run(unsigned *iterations_done = nullptr) {
+    this->initialize();
+    bool converged = false;
+    const unsigned max_iterations = 85;
+    unsigned iteration = 0;
+    while (!converged && iteration < max_iterations) {
+      converged = this->one_iteration(iteration);
+      ++iteration;
+    }
+    if (iterations_done) *iterations_done = iteration;
+    return converged;
+  }
+  ~cdcl_estimation_em_t() { for (lrr_icp_dir *d : closest_) if (d) lrr_icp_dir_destroy(d); }
+  cdcl_estimation_em_t(const cdcl_estimation_em_t &) = delete;
+  cdcl_estimation_em_t &operator=(const cdcl_estimation_em_t &) = delete;
+
  private:
   bool is_rigid() const { return dof == 6 && trans_->is_type(cdcl_trans_rigid3d::type_id()); }
   lrr_icp_cloud *moving_of(unsigned r) const { return rows_[r]->moving(); }
+  // the one-to-one match list of the base class at resolution r (created on first use)
+  lrr_icp_dir *closest_point_list(unsigned r) {
+    if (closest_.size() < rows_.size()) closest_.resize(rows_.size(), nullptr);
+    if (!closest_[r]) check(lrr_icp_dir_create(device::ctx(), rows_[r]->moving(), rows_[r]->fixed(), &closest_[r]), "dir create");
+    return closest_[r];
+  }
   void premap(trans_sptr_type const &G) {
     lrr_icp_xform g = xform(G);
     check(lrr_icp_cdc_set_premap(rows_[res_]->handle(), &g), "cdc premap");
@@ -395,6 +480,8 @@ class cdcl_estimation_em_t {
   double avg_largest_eval_ = 0.0;
   unsigned switches_down_ = 0, switches_up_ = 0;
   step_info last_;
+  std::vector<lrr_icp_dir *> closest_;
+  double initial_scale_ = 0.0;
 };
 typedef cdcl_estimation_em_t<12> cdcl_estimation_em;
 typedef cdcl_estimation_em_t<6> cdcl_estimation_em_rigid;

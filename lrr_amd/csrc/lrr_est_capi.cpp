@@ -571,10 +571,8 @@ struct lrr_cdc_em {
 };
 static lrr_icp_cloud *cdc_cloud(const lrr_est_features *f) {
   if (!f || !f->cov) throw std::runtime_error("cdc_em: the features need covariances");
-  lrr_icp_cloud *c = nullptr;
-  lrr_amd::check(lrr_icp_cloud_create(lrr_amd::device::ctx(), f->n, f->loc, f->proj, f->strength, 0, &c), "cloud upload");
-  if (lrr_icp_cloud_set_covariances(c, f->cov) != 0) { lrr_icp_cloud_destroy(c); throw std::runtime_error("cdc_em: covariance upload failed"); }
-  return c;
+  // (cdcl_feature: location, covariance, strength — f->proj is not read; the projector slot takes the covariance's normal projector)
+  return lrr_amd::cdcl_feature_cloud(f->n, f->loc, f->cov, f->strength);
 }
 // dof 12: affine; dof 6: rigid3d (small-angle increment).  levels pairs of feature sets, [0] the finest, with the point spacing
 // of every fixed set (levels == 1: spacing may be NULL); covar: dof x dof
@@ -614,6 +612,28 @@ int lrr_cdc_em_one_iteration(lrr_cdc_em *h, unsigned iteration, int *converged, 
 }
 int lrr_cdc_em_one_iteration_state(lrr_cdc_em *h, unsigned iteration, int *converged, double *info, double *state) {
   return guard([&] { if (h->em12) cdc_em_iterate(h->em12, iteration, converged, info, state); else cdc_em_iterate(h->em6, iteration, converged, info, state); });
+}
+// normalize_matches() of the base class (cdcl/cdcl_estimation_ICP.h:76); on by default here, `on` = 0 switches it off
+int lrr_cdc_em_normalize_matches(lrr_cdc_em *h, int on) {
+  return guard([&] { if (h->em12) h->em12->normalize_matches(on != 0); else h->em6->normalize_matches(on != 0); });
+}
+// initialize() (cdcl/cdcl_estimation.txx:70-84); scale: the scale of its robust weights (may be NULL)
+int lrr_cdc_em_initialize(lrr_cdc_em *h, double *scale) {
+  return guard([&] {
+    if (h->em12) { h->em12->initialize(); if (scale) *scale = h->em12->initial_scale(); }
+    else { h->em6->initialize(); if (scale) *scale = h->em6->initial_scale(); }
+  });
+}
+// run() (cdcl/cdcl_estimation.txx:190-204): initialize + one_iteration until converged, 85 at most
+int lrr_cdc_em_run(lrr_cdc_em *h, int *converged, unsigned *iterations) {
+  return guard([&] {
+    bool c = h->em12 ? h->em12->run(iterations) : h->em6->run(iterations);
+    if (converged) *converged = c ? 1 : 0;
+  });
+}
+// the resolution the estimator is at (0 = the finest)
+int lrr_cdc_em_resolution(lrr_cdc_em *h, int *res) {
+  return guard([&] { *res = (int)(h->em12 ? h->em12->resolution() : h->em6->resolution()); });
 }
 int lrr_cdc_em_get_transform(lrr_cdc_em *h, double *A, double *t, double *c, double *covar) {
   return guard([&] { if (h->em12) read_trans<12>(h->em12->get_transform(), A, t, c, covar); else read_trans<6>(h->em6->get_transform(), A, t, c, covar); });

@@ -427,6 +427,10 @@ class CdcEm:
         L.lrr_cdc_em_one_iteration_state.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_int), _dp, _dp]
         L.lrr_cdc_em_get_transform.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
         L.lrr_cdc_em_rows.argtypes = [C.c_void_p, _ip, _ip, _dp]
+        L.lrr_cdc_em_normalize_matches.argtypes = [C.c_void_p, C.c_int]
+        L.lrr_cdc_em_initialize.argtypes = [C.c_void_p, _dp]
+        L.lrr_cdc_em_run.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]
+        L.lrr_cdc_em_resolution.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         self._ck(L.lrr_cdc_em_create_pyramid(self.dof, levels, pm, pf, _d(sp), _d(A), _d(t), _d(c), _d(cv), seed, self.max_matches, C.byref(self.h)))
 
     def _ck(self, rc):
@@ -442,6 +446,25 @@ class CdcEm:
         self.resolution, self.matches_size, self.fell_back, self.avg_largest_eval = int(state[0]), int(state[1]), bool(state[2]), float(state[3])
         self.switches = (int(state[4]), int(state[5]))  # to a finer, to a coarser resolution, this iteration
         return bool(conv.value), info
+
+    def normalize_matches(self, on=True):
+        """normalize_matches() of the base class (cdcl/cdcl_estimation_ICP.h:76); on unless switched off here"""
+        self._ck(self.L.lrr_cdc_em_normalize_matches(self.h, int(bool(on))))
+
+    def initialize(self):
+        """cdcl_estimation::initialize (cdcl/cdcl_estimation.txx:70-84): closest points of all moving features, the robust
+        point-to-plane fit of the base class, its inverse normal matrix as the parameter covariance; returns the scale (2 x MUSE)"""
+        scale = np.zeros(1)
+        self._ck(self.L.lrr_cdc_em_initialize(self.h, _d(scale)))
+        return float(scale[0])
+
+    def run(self):
+        """cdcl_estimation::run (cdcl/cdcl_estimation.txx:190-204): (converged, iterations done)"""
+        conv, its, res = C.c_int(0), C.c_uint(0), C.c_int(0)
+        self._ck(self.L.lrr_cdc_em_run(self.h, C.byref(conv), C.byref(its)))
+        self._ck(self.L.lrr_cdc_em_resolution(self.h, C.byref(res)))
+        self.resolution = int(res.value)
+        return bool(conv.value), int(its.value)
 
     def get_transform(self):
         A, t, c, cov = np.zeros((3, 3)), np.zeros(3), np.zeros(3), np.zeros((self.dof, self.dof))

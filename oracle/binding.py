@@ -221,6 +221,31 @@ class CdcEmOracle:
         n = self.mv[self.resolution].n
         return self._w[:n * self.mm].reshape(n, self.mm)
 
+    def initialize(self, normalize=True):
+        """cdcl_estimation::initialize (cdcl/cdcl_estimation.txx:70-84) at the current resolution: the parameter covariance from the base
+        class's robust point-to-plane fit over the closest points; returns the scale its weights were computed with"""
+        L = lib()
+        keep = []
+        fm, ff = _features(self.mv[self.resolution], keep), _features(self.fx[self.resolution], keep)
+        FP = C.POINTER(_Features)
+        L.lrr_oracle_cdc_em_initialize.restype = C.c_int
+        L.lrr_oracle_cdc_em_initialize.argtypes = [C.c_int, FP, FP, _dp, _dp, _dp, C.c_int, _dp, _dp]
+        cov, scale = np.zeros((self.dof, self.dof)), np.zeros(1)
+        if L.lrr_oracle_cdc_em_initialize(self.dof, C.byref(fm), C.byref(ff), _d(self.A), _d(self.t), _d(self.c), int(bool(normalize)), _d(cov), _d(scale)) != 0:
+            raise RuntimeError("oracle EM initialize: bad argument")
+        self.cov = cov
+        return float(scale[0])
+
+    def run(self, max_iterations=85, normalize=True):
+        """cdcl_estimation::run (cdcl/cdcl_estimation.txx:190-204): initialize, then one_iteration until converged (85 at most);
+        returns (converged, iterations done)"""
+        self.initialize(normalize)
+        converged, iteration = False, 0
+        while not converged and iteration < max_iterations:
+            converged, _ = self.one_iteration(iteration)
+            iteration += 1
+        return converged, iteration
+
     def one_iteration(self, iteration):
         L = lib()
         keep = []

@@ -1552,6 +1552,7 @@ typedef struct {
   double *m_from_loc;   /* their locations (3 per match) */
   uint8_t *flag;        /* scratch: distinct-to marker, size fixed.n */
   double last_scale, injected_scale;
+  double scale_constant; /* 1 in the matching_all classes (cdcl .txx:730-732), 2 in their base class (cdcl_estimation_ICP.txx:580-582) */
   uint64_t rng;
   int64_t *explicit_order;
   int64_t explicit_n;
@@ -1575,6 +1576,7 @@ static fwd_est *fwd_create(int rrl, int dof, const lrr_oracle_features *moving,
   f->flag = (uint8_t *)calloc((size_t)(f->fixed.n > 0 ? f->fixed.n : 1), 1);
   f->rng = seed;
   f->injected_scale = -1.0;
+  f->scale_constant = 1.0;
   return f;
 }
 
@@ -1734,8 +1736,7 @@ static double fwd_estimate_scale_and_assign_weight(fwd_est *f) {
   } else {
     scale = sqrt(sum_weighted_error / sum_weights);
   }
-  const double constant = 1.0;
-  scale = constant * scale;
+  scale = f->scale_constant * scale;
   for (int64_t i = 0; i < n; ++i) {
     double scale2 = scale * scale;
     f->m_w[i] = lrr_oracle_weight_BT(f->m_w[i] / scale2) / scale2;
@@ -2027,6 +2028,48 @@ static void fwd_estimate_LS(fwd_est *f, int estimate_parameters, normal_eq *ne) 
     trans_unnormalize(&f->tr, rm, rf, cm, cf);
     fwd_unnormalize_matches(f, cm, rm, cf, rf);
   }
+}
+
+/* cdcl_estimation::initialize (cdcl/cdcl_estimation.txx:70-84) at one resolution: the base class's find_closest_euclidean over ALL moving
+ * features (cdcl_estimation_ICP.txx:451-489: one nearest fixed feature each, w = 1) and its estimate_LS() (:646-750, parameters not
+ * estimated): residuals along the normal of the fixed feature, the eigenvector of the smallest eigenvalue of its covariance
+ * (NORMAL_DISTANCES_FOR_ICP, :523-537 and :696-709), scale = 2 x MUSE (:557-582), Beaton-Tukey weights (:603-604), parameter
+ * covariance = svd inverse of AtA (:727-731).  weight_by_strength_ stays false: nothing in the reference sets it on this class.
+ * With normalize the reference takes the eigenvectors of covariance / r_f^2: the same vectors.
+ * A, t, c: trans_, in and out — normalize() / unnormalize() around the fit hand the same map back about another centre (the moving
+ * centroid, cdcl_trans_affine.txx:259-286, cdcl_trans_rigid3d.cxx:284-305); covar_out: dof x dof, belonging to that centre;
+ * scale_out: the scale the weights were computed with. */
+int lrr_oracle_cdc_em_initialize(int dof, const lrr_oracle_features *moving, const lrr_oracle_features *fixed, double *A,
+                                 double *t, double *c, int normalize, double *covar_out, double *scale_out) {
+  if ((dof != 6 && dof != 12) || !moving || !fixed || !fixed->cov || moving->n < 1 || fixed->n < 1) return -1;
+  double *proj = (double *)malloc(sizeof(double) * 9 * (size_t)fixed->n);
+  for (int64_t j = 0; j < fixed->n; ++j) {
+    double nrm[3], big[3];
+    sym_eig_ends(fixed->cov + 9 * j, nrm, big);
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) proj[9 * j + 3 * a + b] = nrm[a] * nrm[b];
+  }
+  lrr_oracle_features fx = *fixed;
+  fx.proj = proj;
+  trans T;
+  trans_from_Atc(&T, dof, A, t, c);
+  fwd_est *f = fwd_create(0, dof, moving, &fx, &T, 1, LRR_ORACLE_NN_KDTREE);
+  f->number_points = moving->n;
+  f->normalize_matches = normalize;
+  f->scale_constant = 2.0;
+  f->explicit_order = (int64_t *)malloc(sizeof(int64_t) * (size_t)moving->n);  /* moving_[res_] in its own order */
+  for (int64_t i = 0; i < moving->n; ++i) f->explicit_order[i] = i;
+  f->explicit_n = moving->n;
+  fwd_find_closest_euclidean(f);
+  normal_eq ne;
+  fwd_estimate_LS(f, 0, &ne);
+  memcpy(covar_out, f->tr.covar, sizeof(double) * (size_t)(dof * dof));
+  memcpy(A, f->tr.A, sizeof f->tr.A);
+  memcpy(t, f->tr.t, sizeof f->tr.t);
+  memcpy(c, f->tr.c, sizeof f->tr.c);
+  if (scale_out) *scale_out = f->last_scale;
+  fwd_free(f);
+  free(proj);
+  return 0;
 }
 
 /* one_iteration of the forward classes (cdcl .txx:434-509; rrl .txx:427-462) */

@@ -125,6 +125,13 @@ int lrr_oracle_cdc_em_iteration(const lrr_oracle_features *moving, const lrr_ora
                                 double *covar, unsigned iteration, uint64_t *seed_state, int max_matches,
                                 int64_t *row_count, int64_t *to_idx, double *w, double *info);
 
+/* cdcl_estimation::initialize at one resolution (cdcl/cdcl_estimation.txx:70-84 -> cdcl_estimation_ICP.txx:451-489, 497-750): closest
+ * fixed feature of every moving feature, residuals along the normal of the fixed feature's covariance, 2 x MUSE scale, the parameter
+ * covariance (dof x dof) = inverse of AtA; A, t, c come back as normalize() / unnormalize() around the fit leave them (the same map
+ * about the moving centroid) */
+int lrr_oracle_cdc_em_initialize(int dof, const lrr_oracle_features *moving, const lrr_oracle_features *fixed, double *A,
+                                 double *t, double *c, int normalize, double *covar_out, double *scale_out);
+
 /* stand-alone pieces (each is also used inside the estimators) */
 void   lrr_oracle_nn(const double *fixed_loc, int64_t nf, const double *query, int64_t nq,
                      int backend, int64_t *idx_out);

@@ -319,3 +319,61 @@ def test_em_rows_beyond_the_device_capacity_are_an_error(E):
     with pytest.raises(RuntimeError, match="compute_weights"):
         g.one_iteration(0)
     g.close()
+
+
+@pytest.mark.parametrize("normalize", [True, False], ids=["normalised", "plain"])
+@pytest.mark.parametrize("dof,centred", [(12, False), (6, False), (6, True)], ids=["affine", "rigid", "rigid-centre-0"])
+def test_em_initialize_equals_the_oracle(E, ob, dof, centred, normalize):
+    """cdcl_estimation::initialize (cdcl/cdcl_estimation.txx:70-84): the base class's closest points over all moving features and
+    its robust point-to-plane fit — normals from the fixed features' covariances, scale 2 x MUSE, the parameter covariance =
+    inverse of AtA (cdcl_estimation_ICP.txx:451-489, 497-750) — on the device against the oracle's restatement
+    (lrr_oracle_cdc_em_initialize, itself held against numpy in tests/test_oracle_cdc_em.py).  The rigid transform's normalize()
+    leaves its centre in mm beside normalised features (cdcl_trans_rigid3d.cxx:260-280): with a centre away from the origin the
+    normalised fit is meaningless in the reference too, and has to come out the same."""
+    from lrr_amd import synth
+    mv, fx, T0, Ct = scenario(dof, n=3000)
+    if centred:
+        T0 = synth.Transform(T0.A, T0.t - T0.A @ T0.c, np.zeros(3))
+    g = E.CdcEm(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, dof=dof)
+    c = ob.CdcEmOracle(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, dof=dof)
+    g.normalize_matches(normalize)
+    sg, sc = g.initialize(), c.initialize(normalize=normalize)
+    assert sg == pytest.approx(sc, rel=1e-9)
+    A, t, cen, cov = g.get_transform()
+    # the transform comes back as normalize() / unnormalize() leave it: the same map about the moving centroid
+    assert np.allclose(A, c.A, rtol=0, atol=1e-12) and np.allclose(t, c.t, rtol=0, atol=1e-9 * max(1.0, np.abs(c.t).max()))
+    assert np.allclose(cen, c.c, rtol=0, atol=1e-9 * max(1.0, np.abs(c.c).max()))
+    if not normalize:
+        assert np.array_equal(A, T0.A) and np.array_equal(t, T0.t) and np.array_equal(cen, T0.c)
+    assert np.allclose(cov, c.cov, rtol=1e-6, atol=1e-9 * np.abs(c.cov).max())
+    assert np.all(np.isfinite(cov)) and np.abs(cov - Ct).max() > 0     # the covariance handed in was replaced
+    g.close()
+
+
+@pytest.mark.parametrize("dof", [12, 6])
+def test_em_run_equals_the_oracle(E, ob, dof):
+    """cdcl_estimation::run (cdcl/cdcl_estimation.txx:190-204) = initialize + one_iteration until converged, 85 at most: the same
+    number of iterations, the same end state as the oracle driven the same way"""
+    import dataclasses
+    from lrr_amd import synth
+    mv, fx, T0, Ct = scenario(dof, n=2000)
+    if dof == 6:
+        # cdcl_trans_rigid3d::unnormalize leaves the translation of a map about the origin and moves the centre to the moving
+        # centroid (cdcl_trans_rigid3d.cxx:294-304): a normalised initialize() keeps the rigid map only when that centroid IS the
+        # origin.  The moving set is shifted there, and the same map written about the origin.
+        cm0 = mv.loc.mean(axis=0)
+        mv = dataclasses.replace(mv, loc=mv.loc - cm0)
+        T0 = synth.Transform(T0.A, T0.t + T0.A @ (cm0 - T0.c), np.zeros(3))
+    g = E.CdcEm(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, dof=dof)
+    c = ob.CdcEmOracle(mv, fx, T0.A, T0.t, T0.c, Ct, seed=77, dof=dof)
+    conv_g, its_g = g.run()
+    conv_c, its_c = c.run()
+    assert (conv_g, its_g) == (conv_c, its_c)
+    assert its_g > 6                       # the parameter estimate took part (startEM = 5)
+    A, t, cen, cov = g.get_transform()
+    assert np.allclose(A, c.A, rtol=0, atol=1e-6 * np.abs(c.A).max())
+    assert np.allclose(t, c.t, rtol=0, atol=1e-5 * max(1.0, np.abs(c.t).max()))
+    assert np.allclose(cov, c.cov, rtol=1e-3, atol=1e-5 * np.abs(c.cov).max())
+    rc, ti, w = g.rows()
+    assert np.array_equal(rc, c.rc)
+    g.close()
