@@ -222,6 +222,8 @@ struct lrr_icp_dir {
   bool last_voronoi = false;  // the last search ran with the lookup semantics (its bounds refer to the site cloud)
   double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
   double *q_loc = nullptr;     // 3 per source: location of the matched target, cached by the fused residual pass
+  bool qloc_in_step = false;   // ... and in step with m_to for EVERY source: written by a fused estimate over all sources, no search
+                               // since other than the inline certificate kernel (which keeps it in step): that kernel may stream it
   double *from_loc = nullptr;  // 3 per source: pre-mapped copies
   int from_is_copy = 0;
   unsigned *flag = nullptr; int64_t flag_cap = 0;  // per target: stamp of the last call that matched it
@@ -803,6 +805,7 @@ int ensure_dir_capacity(lrr_icp_dir *d) {
   HIPCHK(ctx, hipMalloc(&d->key_s, sizeof(double) * need));
   HIPCHK(ctx, hipMalloc(&d->from_loc, sizeof(double) * 3 * need));
   HIPCHK(ctx, hipMalloc(&d->q_loc, sizeof(double) * 3 * need));
+  d->qloc_in_step = false;
   d->cap = need;
   return LRR_ICP_OK;
 }
@@ -1412,6 +1415,7 @@ int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   d->from = from;
   d->n = 0;
+  d->qloc_in_step = false;
   d->prev_n = -1;
   d->searches = 0;
   d->have_bounds = false;
@@ -1477,6 +1481,7 @@ struct MatchPrep {
   bool short_list = false;  // ... whose list was short last time: the listed sources go straight to the wave-per-query kernel
   bool inline_list = false; // ... or very short: the certificate kernel searches them itself
   bool growth = false;      // ball search right after a dense level grew: sources without a previous match exist
+  bool qloc = false;        // the direction's cached match locations were in step with m_to when this search was prepared
   lrr_icp_xform prev_xf;  // transform of that search
   int method = LRR_ICP_NN_GRID;
 };
@@ -1530,6 +1535,8 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   d->n = n_points;
   P.N = N;
   P.empty = n_points == 0;
+  P.qloc = d->qloc_in_step && method != LRR_ICP_NN_VORONOI && n_points == N;  // (the cache holds FEATURE locations: not what the site search compares)
+  d->qloc_in_step = false;  // whatever search follows may change matches; the inline certificate kernel's launch sites restore it
   if (P.empty) {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
     return LRR_ICP_OK;
@@ -1617,6 +1624,7 @@ static BallArgs ball_args(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L) {
   a.d2lb = d->d2lb;
   a.xf_prev = to_dev(&P.prev_xf);
   a.list = L.d_active; a.list_count = P.counts + 2;
+  a.q_loc = P.qloc ? d->q_loc : nullptr;
   return a;
 }
 // the wave-per-query arguments of one direction's search: with the lookup semantics the search runs in the to-cloud's site
@@ -1627,6 +1635,7 @@ static HardArgs hard_args_of(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, bool
   return h;
 }
 inline unsigned cert_blocks_for(int64_t n) { return (unsigned)((((n + kCertBlock - 1) / kCertBlock) + 7) / 8 * 8); }
+inline unsigned cert_inline_blocks_for(int64_t n) { return (unsigned)((((n + kCertBlock * kCertPer - 1) / (kCertBlock * kCertPer)) + 7) / 8 * 8); }
 
 // the launches of one prepared submission on stream st
 static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream_t st) {
@@ -1646,8 +1655,9 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
   static const bool no_inline = std::getenv("LRR_ICP_NO_INLINE_CERT") != nullptr;
   if (P.cert && P.inline_list && !no_inline) {  // a short list last time: the certificate kernel serves its failures itself
     ctx->k1_paths[LRR_ICP_K1_CERT_INLINE] += 1;
-    hipLaunchKernelGGL(k_match_cert_inline, dim3(cert_blocks_for(N)), dim3(kCertBlock), 0, st, ball_args(d, P, L));
+    hipLaunchKernelGGL(k_match_cert_inline, dim3(cert_inline_blocks_for(N)), dim3(kCertBlock), 0, st, ball_args(d, P, L));
     HIPCHK(ctx, hipGetLastError());
+    d->qloc_in_step = P.qloc;  // (the kernel stores the location of every match it changes)
     d->cert_inline = true;
     return LRR_ICP_OK;
   }
@@ -1732,11 +1742,12 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
       if (Pf.cert && Pb.cert && Pf.inline_list && Pb.inline_list && !no_inline) {
         hipEvent_t ev0, ev1;
         prof.attach(&ev0, &ev1);
-        if (ev0) hipExtLaunchKernelGGL(k_match_cert_inline2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, ev0, ev1, 0, af, ab);
-        else hipLaunchKernelGGL(k_match_cert_inline2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
+        if (ev0) hipExtLaunchKernelGGL(k_match_cert_inline2, dim3(cert_inline_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, ev0, ev1, 0, af, ab);
+        else hipLaunchKernelGGL(k_match_cert_inline2, dim3(cert_inline_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
         HIPCHK(ctx, hipGetLastError());
         ctx->k1_paths[LRR_ICP_K1_CERT_INLINE] += 2;
         f->cert_inline = b->cert_inline = true;  // the host adds this search to the certificate statistics when it learns the counts
+        f->qloc_in_step = Pf.qloc; b->qloc_in_step = Pb.qloc;
         return LRR_ICP_OK;
       }
       prof.begin();
@@ -2293,6 +2304,9 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   hipLaunchKernelGGL(k_f_residual, dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, to_dev(xfF), to_dev(xfB), ident, o->normalize,
                      o->scale_mode_f == LRR_ICP_SCALE_MUSE ? 1 : 0, o->scale_mode_b == LRR_ICP_SCALE_MUSE ? 1 : 0, P1);
   HIPCHK(ctx, hipGetLastError());
+  // (F1 stored the location of every active source's match)
+  F->qloc_in_step = F->n == F->from->n && !F->from_is_copy;
+  B->qloc_in_step = B->n == B->from->n && !B->from_is_copy;
   // scale modes; MUSE needs the sorted residuals: its tables and argmin stay on the host (first
   // estimate after set_transform only)
   WeightOpts wo;
@@ -2410,6 +2424,7 @@ int lrr_icp_debug_set_match(lrr_icp_dir *d, int64_t from_idx, int64_t value) {
   HIPCHK(ctx, hipMemcpy(&s, d->from->canon_of + from_idx, sizeof(int), hipMemcpyDeviceToHost));
   const int v = (int)value;
   HIPCHK(ctx, hipMemcpy(d->m_to + s, &v, sizeof(int), hipMemcpyHostToDevice));
+  d->qloc_in_step = false;
   return LRR_ICP_OK;
 }
 
@@ -2552,6 +2567,7 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   fo.mode = o->scale_mode; fo.injected = o->injected;
   hipLaunchKernelGGL(k_fw_residual, dim3(nbF), dim3(kWide), 0, st, aF, fo, to_dev(xf), P3, nb3, SC, P1);
   HIPCHK(ctx, hipGetLastError());
+  F->qloc_in_step = F->n == F->from->n && !F->from_is_copy;
   // MUSE needs the sorted residuals: its tables and argmin stay on the host (first estimate only)
   if (fo.mode == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &fo.injected); if (rc) return rc; fo.mode = LRR_ICP_SCALE_INJECTED; }
   // the order statistic rides along with the weight pass once the scale has settled (as in lrr_icp_estimate_symmetric)

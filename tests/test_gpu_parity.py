@@ -566,6 +566,73 @@ def test_certificate_skips_only_provable_matches(E, ob):
     assert seen > 0 and searched == 0
 
 
+def test_certificate_with_cached_match_locations(E, ob):
+    """Once a fused estimate has run over every source, the inline certificate kernel reads the location of a source's match from the
+    estimate's cache (streamed with the source) instead of gathering it, and stores the location of every match it changes itself.
+    Estimates and searches interleaved in every order — iterations, two searches in a row under transforms that move far enough for some
+    certificates to fail (the kernel's own cache updates are then what the next search compares with), a search through another path
+    in between (the cache is dropped), a backward estimate — equal the oracle's match sets throughout."""
+    timer = E.DeviceTimer()
+    pair = synth.make_pair(20000, 20000, 515, kind="affine")
+    T0 = synth.perturbed(pair.planted, 3, rot_deg=0.2, trans_mm=0.2)
+    g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=pair.moving, fixed_inside=pair.fixed, seed=21)
+    c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=pair.moving, fixed_inside=pair.fixed,
+                           seed=21, nn_backend=ob.NN_KDTREE)
+    rng = np.random.default_rng(77)
+
+    def same(tag):
+        for dr in (0, 1):
+            fg, tg, _ = g.matches(dr)
+            fc, tc, _ = c.matches(dr)
+            assert np.array_equal(fg, fc) and np.array_equal(tg, tc), (tag, dr)
+
+    def nudge(step):
+        A, t, cen, _ = g.get_transform(0)
+        d = rng.normal(size=3)
+        d *= step / np.linalg.norm(d)
+        for e in (g, c):
+            e.set_transform(synth.rotation_xyz(step * 1e-3, -step * 5e-4, step * 2e-3) @ A, t + d, cen)
+            e.set_number_points(10**9)
+
+    for e in (g, c):
+        e.weight_by_strength(True)
+        e.normalize_matches()
+        e.set_number_points(10**9)
+    timer.k1_path_counts(reset=True)
+    it, extra = 0, 0
+    while it < 40 and extra < 4:   # iterations at the finest level — search, estimate, search ... — until the inline kernel has run a few times
+        assert g.one_iteration(it) == c.one_iteration(it)
+        same(("iteration", it))
+        it += 1
+        extra += int(timer.k1_path_counts()["cert_inline"] > 0)
+    assert timer.k1_path_counts()["cert_inline"] > 0, timer.k1_path_counts()
+    for k, step in enumerate([1e-6, 1e-3, 3e-2, 3e-2, 1e-6]):   # searches in a row: the kernel keeps its cache in step by itself
+        nudge(step)
+        for e in (g, c):
+            e.find_closest_euclidean()
+        same(("search", k, step))
+    for it in range(it, it + 3):
+        assert g.one_iteration(it) == c.one_iteration(it)
+        same(("iteration", it))
+    nudge(2.0)                   # far: the search leaves the certificate path (the cache is dropped), then comes back to it
+    for e in (g, c):
+        e.find_closest_euclidean()
+    same("far")
+    for it in range(it + 1, it + 13):
+        assert g.one_iteration(it) == c.one_iteration(it)
+        same(("iteration", it))
+    for e in (g, c):
+        e.estimate_LS_backward(False)
+    nudge(1e-4)
+    for e in (g, c):
+        e.find_closest_euclidean()
+    same("after the backward estimate")
+    Ag, tg_, _, _ = g.get_transform(0)
+    Ac, tc_, _, _ = c.get_transform(0)
+    assert np.allclose(Ag, Ac, atol=1e-9) and np.allclose(tg_, tc_, atol=1e-7)
+    g.close()
+
+
 def test_match_ties_through_every_search_path(E, ob):
     """lattice clouds with duplicate points under exact half-cell translations: every query has
     several exactly equidistant targets.  The first search of a level (tile kernel), the later ones
