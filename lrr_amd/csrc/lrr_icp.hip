@@ -223,7 +223,11 @@ struct lrr_icp_dir {
   double *w = nullptr, *wc = nullptr, *r2 = nullptr, *key_g = nullptr, *key_s = nullptr;
   double *q_loc = nullptr;     // 3 per source: location of the matched target, cached by the fused residual pass
   bool qloc_in_step = false;   // ... and in step with m_to for EVERY source: written by a fused estimate over all sources, no search
-                               // since other than the inline certificate kernel (which keeps it in step): that kernel may stream it
+                               // since other than the inline certificate kernel (which marks the entries it changes): that kernel may stream it
+  bool qps_in_step = false;    // the same for the rest of the matched target's record (projector, strength: 7 doubles per source behind the
+                               // locations, at q_loc + 3 n): the symmetric estimate's residual and normal-equation passes stream it then
+  bool last_search_cert = false;  // the last search went through a certificate kernel: the run is near its fixed point, the next
+                               // estimate caches the whole record
   double *from_loc = nullptr;  // 3 per source: pre-mapped copies
   int from_is_copy = 0;
   unsigned *flag = nullptr; int64_t flag_cap = 0;  // per target: stamp of the last call that matched it
@@ -804,8 +808,8 @@ int ensure_dir_capacity(lrr_icp_dir *d) {
   HIPCHK(ctx, hipMalloc(&d->key_g, sizeof(double) * need));
   HIPCHK(ctx, hipMalloc(&d->key_s, sizeof(double) * need));
   HIPCHK(ctx, hipMalloc(&d->from_loc, sizeof(double) * 3 * need));
-  HIPCHK(ctx, hipMalloc(&d->q_loc, sizeof(double) * 3 * need));
-  d->qloc_in_step = false;
+  HIPCHK(ctx, hipMalloc(&d->q_loc, sizeof(double) * 10 * need));  // locations (3 per source), then projector + strength (7 per source)
+  d->qloc_in_step = d->qps_in_step = false;
   d->cap = need;
   return LRR_ICP_OK;
 }
@@ -1415,7 +1419,7 @@ int lrr_icp_dir_set_from(lrr_icp_dir *d, lrr_icp_cloud *from) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   d->from = from;
   d->n = 0;
-  d->qloc_in_step = false;
+  d->qloc_in_step = d->qps_in_step = false;
   d->prev_n = -1;
   d->searches = 0;
   d->have_bounds = false;
@@ -1482,6 +1486,7 @@ struct MatchPrep {
   bool inline_list = false; // ... or very short: the certificate kernel searches them itself
   bool growth = false;      // ball search right after a dense level grew: sources without a previous match exist
   bool qloc = false;        // the direction's cached match locations were in step with m_to when this search was prepared
+  bool qps = false;         // ... and the cached projectors / strengths too
   lrr_icp_xform prev_xf;  // transform of that search
   int method = LRR_ICP_NN_GRID;
 };
@@ -1535,8 +1540,10 @@ static int match_prepare(lrr_icp_dir *d, const lrr_icp_xform *xf, const uint32_t
   d->n = n_points;
   P.N = N;
   P.empty = n_points == 0;
-  P.qloc = d->qloc_in_step && method != LRR_ICP_NN_VORONOI && n_points == N;  // (the cache holds FEATURE locations: not what the site search compares)
-  d->qloc_in_step = false;  // whatever search follows may change matches; the inline certificate kernel's launch sites restore it
+  P.qloc = d->qloc_in_step && n_points == N;  // (lookup semantics: the kernel marks the cache but does not read it — it holds FEATURE locations)
+  P.qps = P.qloc && d->qps_in_step;
+  d->qloc_in_step = d->qps_in_step = false;  // whatever search follows may change matches; the inline certificate kernel's launch sites restore them
+  d->last_search_cert = false;
   if (P.empty) {
     HIPCHK(ctx, hipMemsetAsync(d->slot, 0xff, sizeof(int) * d->cap, st));
     return LRR_ICP_OK;
@@ -1657,13 +1664,15 @@ static int match_launch(lrr_icp_dir *d, const MatchPrep &P, K1Lane &L, hipStream
     ctx->k1_paths[LRR_ICP_K1_CERT_INLINE] += 1;
     hipLaunchKernelGGL(k_match_cert_inline, dim3(cert_inline_blocks_for(N)), dim3(kCertBlock), 0, st, ball_args(d, P, L));
     HIPCHK(ctx, hipGetLastError());
-    d->qloc_in_step = P.qloc;  // (the kernel stores the location of every match it changes)
+    d->qloc_in_step = P.qloc; d->qps_in_step = P.qps;  // (the kernel marks the cache entry of every match it changes)
+    d->last_search_cert = true;
     d->cert_inline = true;
     return LRR_ICP_OK;
   }
   if (P.cert) {
     BallArgs a = ball_args(d, P, L);
     ctx->k1_paths[LRR_ICP_K1_CERT] += 1;
+    d->last_search_cert = true;
     hipLaunchKernelGGL(k_match_cert, dim3(cert_blocks_for(N)), dim3(kCertBlock), 0, st, a);
     HIPCHK(ctx, hipGetLastError());
     if (!P.short_list) hipLaunchKernelGGL(k_match_list, dim3(ball_blocks_for(N)), dim3(kBallBlock), 0, st, a);
@@ -1748,11 +1757,14 @@ int lrr_icp_match_pair(lrr_icp_dir *f, const lrr_icp_xform *xf_f, const uint32_t
         ctx->k1_paths[LRR_ICP_K1_CERT_INLINE] += 2;
         f->cert_inline = b->cert_inline = true;  // the host adds this search to the certificate statistics when it learns the counts
         f->qloc_in_step = Pf.qloc; b->qloc_in_step = Pb.qloc;
+        f->qps_in_step = Pf.qps; b->qps_in_step = Pb.qps;
+        f->last_search_cert = b->last_search_cert = true;
         return LRR_ICP_OK;
       }
       prof.begin();
       if (Pf.cert && Pb.cert) {
         ctx->k1_paths[LRR_ICP_K1_CERT] += 2;
+        f->last_search_cert = b->last_search_cert = true;
         hipLaunchKernelGGL(k_match_cert2, dim3(cert_blocks_for(std::max(Pf.N, Pb.N)), 2), dim3(kCertBlock), 0, st, af, ab);
         HIPCHK(ctx, hipGetLastError());
         if (!(Pf.short_list && Pb.short_list)) {
@@ -2299,14 +2311,24 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   int nbF = grid_wide_pair(nsF), nbB = grid_wide_pair(nsB), nt = (int)F->to->n, nbT = grid_wide(nt);
   int nb3 = std::max(nbF, nbT);
   NormD ident = to_dev((const lrr_icp_norm *)nullptr);
-  // F1
+  // F1.  The matched targets' records per source: streamed from the cache while it is in step with the matches (steady state: the
+  // certificate kernel keeps it so), stored in full when the last search was a certificate pass (the next estimate will stream
+  // them), locations only otherwise (a run that still moves pays no extra 56 B per match)
+  auto cache_bits = [](const lrr_icp_dir *d) {
+    const bool full = d->n == d->from->n && !d->from_is_copy;
+    return !full ? 0 : d->qps_in_step ? (int)kMatchCached : d->last_search_cert ? (int)kMatchCacheFill : 0;
+  };
+  const int bitsF = cache_bits(F), bitsB = cache_bits(B);
+  aF.float_product |= bitsF; aB.float_product |= bitsB;
   if (o->normalize) { int rc = next_flag_gen(F, &aF.gen); if (rc) return rc; }
   hipLaunchKernelGGL(k_f_residual, dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, to_dev(xfF), to_dev(xfB), ident, o->normalize,
                      o->scale_mode_f == LRR_ICP_SCALE_MUSE ? 1 : 0, o->scale_mode_b == LRR_ICP_SCALE_MUSE ? 1 : 0, P1);
   HIPCHK(ctx, hipGetLastError());
-  // (F1 stored the location of every active source's match)
+  // (F1 stored — or found — the location of every active source's match, and with the bits above the rest of its record)
   F->qloc_in_step = F->n == F->from->n && !F->from_is_copy;
   B->qloc_in_step = B->n == B->from->n && !B->from_is_copy;
+  F->qps_in_step = bitsF != 0;
+  B->qps_in_step = bitsB != 0;
   // scale modes; MUSE needs the sorted residuals: its tables and argmin stay on the host (first
   // estimate after set_transform only)
   WeightOpts wo;
@@ -2424,7 +2446,7 @@ int lrr_icp_debug_set_match(lrr_icp_dir *d, int64_t from_idx, int64_t value) {
   HIPCHK(ctx, hipMemcpy(&s, d->from->canon_of + from_idx, sizeof(int), hipMemcpyDeviceToHost));
   const int v = (int)value;
   HIPCHK(ctx, hipMemcpy(d->m_to + s, &v, sizeof(int), hipMemcpyHostToDevice));
-  d->qloc_in_step = false;
+  d->qloc_in_step = d->qps_in_step = false;
   return LRR_ICP_OK;
 }
 
@@ -2568,6 +2590,7 @@ int lrr_icp_estimate_forward(lrr_icp_dir *F, const lrr_icp_xform *xf, const lrr_
   hipLaunchKernelGGL(k_fw_residual, dim3(nbF), dim3(kWide), 0, st, aF, fo, to_dev(xf), P3, nb3, SC, P1);
   HIPCHK(ctx, hipGetLastError());
   F->qloc_in_step = F->n == F->from->n && !F->from_is_copy;
+  F->qps_in_step = false;  // (this pass stores locations only, over the marks of the certificate kernel too)
   // MUSE needs the sorted residuals: its tables and argmin stay on the host (first estimate only)
   if (fo.mode == LRR_ICP_SCALE_MUSE) { int rc = lrr_icp_muse_scale(F, &fo.injected); if (rc) return rc; fo.mode = LRR_ICP_SCALE_INJECTED; }
   // the order statistic rides along with the weight pass once the scale has settled (as in lrr_icp_estimate_symmetric)

@@ -566,18 +566,22 @@ def test_certificate_skips_only_provable_matches(E, ob):
     assert seen > 0 and searched == 0
 
 
-def test_certificate_with_cached_match_locations(E, ob):
-    """Once a fused estimate has run over every source, the inline certificate kernel reads the location of a source's match from the
-    estimate's cache (streamed with the source) instead of gathering it, and stores the location of every match it changes itself.
-    Estimates and searches interleaved in every order — iterations, two searches in a row under transforms that move far enough for some
-    certificates to fail (the kernel's own cache updates are then what the next search compares with), a search through another path
-    in between (the cache is dropped), a backward estimate — equal the oracle's match sets throughout."""
+@pytest.mark.parametrize("voronoi", [False, True], ids=["exact", "lookup"])
+def test_certificate_with_cached_match_locations(E, ob, voronoi):
+    """Once a fused estimate has run over every source, the matched target's record of every source sits in a cache beside the matches:
+    the inline certificate kernel reads the match's location from it (streamed with the source; exact search only — the lookup
+    semantics compare site locations) and marks the entry of every match it changes; the next estimate's residual and
+    normal-equation passes stream the records instead of gathering them and refresh the marked entries.  Estimates and searches
+    interleaved in every order — iterations, searches in a row under transforms that move far enough for some certificates to fail
+    (marked entries are then what the next search meets), a search through another path in between (the cache is dropped), a
+    backward estimate — equal the oracle's match sets throughout, and the transforms agree at the end."""
     timer = E.DeviceTimer()
     pair = synth.make_pair(20000, 20000, 515, kind="affine")
     T0 = synth.perturbed(pair.planted, 3, rot_deg=0.2, trans_mm=0.2)
-    g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=pair.moving, fixed_inside=pair.fixed, seed=21)
+    g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=pair.moving, fixed_inside=pair.fixed, seed=21,
+                    nn_method=E.NN_VORONOI if voronoi else E.NN_AUTO)
     c = ob.OracleEstimator(ob.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=pair.moving, fixed_inside=pair.fixed,
-                           seed=21, nn_backend=ob.NN_KDTREE)
+                           seed=21, nn_backend=ob.NN_VORONOI if voronoi else ob.NN_KDTREE)
     rng = np.random.default_rng(77)
 
     def same(tag):
