@@ -105,6 +105,7 @@ struct SelJob {
   int row_a0, row_a1, row_b0, row_b1, col;
 };
 constexpr int kFoldStage = 192;     // in-window keys a block of the weight pass can stage per selection
+constexpr int kFoldAllMax = 4096;   // matches per list up to which the folded selection gathers every key (lrr_icp_estimate_symmetric)
 constexpr int kSelPack = 16;     // (the 30 order statistics of a pair of MUSE lists: two packs)
 struct SelPack { SelJob j[kSelPack]; };  // the jobs of one windowed selection, passed as a kernel argument
 
@@ -2357,8 +2358,14 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   bool fold = same && ctx->sel_runs >= 2 && o->dof == 12 && std::getenv("LRR_ICP_NO_FOLD") == nullptr;
   for (int k = 0; k < 4 && fold; ++k)
     if (!(std::fabs(ctx->sel_last[k] - ctx->sel_prev[k]) <= 1e-3 * std::fabs(ctx->sel_last[k]))) fold = false;
+  // Short lists (the coarse levels of the schedule: a few thousand matches among 200k sources) ride along as well, with the window
+  // wide open: the weight pass gathers EVERY finite key (a block meets a few dozen: kFoldStage holds them, kSelCap all of them) and
+  // the final block ranks them — two launches instead of four, and nothing to miss.
+  static const bool no_fold_all = std::getenv("LRR_ICP_NO_FOLD_ALL") != nullptr;
+  const bool fold_all = !fold && o->dof == 12 && !no_fold_all && F->n <= kFoldAllMax && B->n <= kFoldAllMax;
+  if (fold_all) fold = true;
   FoldArgs fa;
-  fa.prev = ctx->d_selprev; fa.win = ctx->d_selwin; fa.coll = ctx->d_selcoll; fa.cursor = ctx->d_selcursor; fa.P5 = ctx->d_fused + kFusedP5;
+  fa.prev = ctx->d_selprev; fa.win = fold_all ? nullptr : ctx->d_selwin; fa.coll = ctx->d_selcoll; fa.cursor = ctx->d_selcursor; fa.P5 = ctx->d_fused + kFusedP5;
   if (fold) hipLaunchKernelGGL((k_f_weights<true>), dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, wo, P1, P3, nb3, SC, P4, fa);
   else hipLaunchKernelGGL((k_f_weights<false>), dim3(nbF + nbB), dim3(kWide), 0, st, aF, aB, nbF, nbB, wo, P1, P3, nb3, SC, P4, fa);
   HIPCHK(ctx, hipGetLastError());
@@ -2386,7 +2393,7 @@ int lrr_icp_estimate_symmetric(lrr_icp_dir *F, lrr_icp_dir *B, const lrr_icp_xfo
   if (fold) {
     SelPack pk;
     for (int j = 0; j < kSelPack; ++j) pk.j[j] = hj[std::min(j, nj - 1)];
-    hipLaunchKernelGGL(k_selw_fold_final, dim3(nj), dim3(kSelThreads), 0, st, pk, ctx->d_selprev, ctx->d_selwin, (const double *)(ctx->d_fused + kFusedP5),
+    hipLaunchKernelGGL(k_selw_fold_final, dim3(nj), dim3(kSelThreads), 0, st, pk, ctx->d_selprev, fold_all ? (double *)nullptr : ctx->d_selwin, (const double *)(ctx->d_fused + kFusedP5),
                        (const unsigned long long *)ctx->d_selcoll, ctx->d_selcursor);
     HIPCHK(ctx, hipGetLastError());
   } else {
