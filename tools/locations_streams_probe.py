@@ -28,10 +28,15 @@ def main():
             E.set_device(0)
             if batches[k] is None:
                 batches[k] = E.LocationBatch(pair.moving, pair.fixed)
-            idx = list(range(k, len(rois), S))
-            rows, pairs = locations.register_locations(pair, [rois[i] for i in idx], [inits[i] for i in idx], 0, 1, batch=batches[k])
+            # part k of S (contiguous blocks, as the ranks of a multi-GPU run take them): a location keeps its index and with it
+            # the seed of its subset permutations, so the rows can be compared with the one-batch rows
+            idx = list(locations.multi_gpu.shard(len(rois), k, S))
+            mb, fb = locations.roi_boxes(rois)
+            A0 = np.stack([inits[i].A for i in idx]); t0 = np.stack([inits[i].t for i in idx]); c0 = np.stack([inits[i].c for i in idx])
+            seeds = np.array([locations.location_seed(7, i) for i in idx], dtype=np.uint64)
+            rows = batches[k].run(A0, t0, c0, mb[idx], fb[idx], seeds, max_iterations=locations.MAX_ITERATIONS)
             rows[:, 19] = idx
-            return rows, pairs
+            return rows, int(rows[:, E.LocationBatch.COL["matched_pairs"]].sum())
 
         def call():
             futs = [locations._worker_thread(k).submit(work, k) for k in range(S)]
