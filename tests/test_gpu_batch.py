@@ -132,6 +132,44 @@ def test_batch_equals_one_at_a_time_and_oracle(E, ob, matcher):
     bt.close()
 
 
+def test_batch_long_lists_equal_one_at_a_time(E):
+    """ROIs of 120 mm in a 120k-feature pair: lists of 7000-18000 entries — up to eighteen parts per list in the estimate passes
+    (their sums folded by the next pass in part order), order statistics over more keys than the register form of the selection
+    holds (the radix select over memory), the wave-per-query phase with long hand-over lists.  Rows against the one-at-a-time
+    class: flags, iteration counts and final match sets exactly, transforms to rounding."""
+    from lrr_amd import locations
+    pair, rois, inits, mbox, fbox, seeds = _setup(120000, 3, 20261, 60.0)
+    sizes = [(len(r[2]), len(r[3])) for r in rois]
+    assert max(max(a, b) for a, b in sizes) > 16000 and min(min(a, b) for a, b in sizes) > 6144, sizes
+    bt = E.LocationBatch(pair.moving, pair.fixed)
+    A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
+    rows = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=locations.MAX_ITERATIONS, diagnostics=False)
+    C = bt.COL
+    for b, (_, _, mi, fi) in enumerate(rois):
+        m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[b]
+        g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in,
+                        seed=int(seeds[b]))
+        conv, its, npairs = g.run_counted(locations.MAX_ITERATIONS, check_valid=True)
+        assert bool(rows[b, C["converged"]]) == conv and int(rows[b, C["iterations"]]) == its, b
+        assert int(rows[b, C["matched_pairs"]]) == npairs
+        A, t, c, cov = g.get_transform()
+        assert rel(rows[b, C["A"]].reshape(3, 3), A) < 1e-9 and rel(rows[b, C["t"]], t) < 1e-9, b
+        assert rel(rows[b, C["covariance"]].reshape(12, 12), cov) < 1e-6
+        for d in (0, 1):
+            fb, tb, wb = bt.matches(b, d)
+            fg, tg, wg = g.matches(d)
+            assert np.array_equal(fb, fg) and np.array_equal(tb, tg), (b, d)
+            assert np.allclose(wb, wg, rtol=1e-8, atol=1e-12 * np.abs(wg).max()), (b, d)
+        assert abs(rows[b, C["weighted_error"]] - g.weighted_error()) <= 1e-9 * max(1.0, g.weighted_error())
+        g.close()
+    # the decision measurements on the long lists too: finite, and the rows of a second run are the same bits
+    rd = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=locations.MAX_ITERATIONS, diagnostics=True)
+    rd2 = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=locations.MAX_ITERATIONS, diagnostics=True)
+    assert np.all(np.isfinite(rd)) and np.array_equal(rd, rd2)
+    assert np.array_equal(rd[:, C["iterations"]], rows[:, C["iterations"]])
+    bt.close()
+
+
 def test_batch_decision_measurements(E, ob):
     """the post-convergence calls of the caller's verifier (rrl/itkLocationRegistration.cxx:1816-1871):
     forward angles / error, estimate_LS_backward(false), backward angles / error / covariance — batch
