@@ -170,6 +170,34 @@ def test_batch_long_lists_equal_one_at_a_time(E):
     bt.close()
 
 
+def test_batch_equal_strengths_equal_one_at_a_time(E):
+    """every feature with the same strength: the strength keys of a list are all equal — one slice of the selection's histogram holds
+    them all, which is the case the order statistics hand to the generic radix select — and the MAD scale of the strength weights is
+    what it is for a constant (rows against the one-at-a-time class, as above)"""
+    import dataclasses
+    from lrr_amd import locations
+    pair, rois, inits, mbox, fbox, seeds = _setup(40000, 4, 20263, 50.0)
+    pair = dataclasses.replace(pair, moving=dataclasses.replace(pair.moving, strength=np.full(pair.moving.n, 3.0)),
+                               fixed=dataclasses.replace(pair.fixed, strength=np.full(pair.fixed.n, 3.0)))
+    bt = E.LocationBatch(pair.moving, pair.fixed)
+    A0 = np.stack([T.A for T in inits]); t0 = np.stack([T.t for T in inits]); c0 = np.stack([T.c for T in inits])
+    rows = bt.run(A0, t0, c0, mbox, fbox, seeds, max_iterations=locations.MAX_ITERATIONS, diagnostics=False)
+    C = bt.COL
+    for b, (_, _, mi, fi) in enumerate(rois):
+        m_in, f_in, T0 = pair.moving.subset(mi), pair.fixed.subset(fi), inits[b]
+        g = E.Estimator(E.RRL_SYMMETRIC, 12, pair.moving, pair.fixed, T0.A, T0.t, T0.c, moving_inside=m_in, fixed_inside=f_in,
+                        seed=int(seeds[b]))
+        conv, its, npairs = g.run_counted(locations.MAX_ITERATIONS, check_valid=True)
+        assert bool(rows[b, C["converged"]]) == conv and int(rows[b, C["iterations"]]) == its, b
+        A, t, c, cov = g.get_transform()
+        both_nan = not np.all(np.isfinite(A)) and not np.all(np.isfinite(rows[b, C["A"]]))
+        assert both_nan or (rel(rows[b, C["A"]].reshape(3, 3), A) < 1e-9 and rel(rows[b, C["t"]], t) < 1e-9), b
+        for d in (0, 1):
+            assert np.array_equal(bt.matches(b, d)[1], g.matches(d)[1]), (b, d)
+        g.close()
+    bt.close()
+
+
 def test_batch_decision_measurements(E, ob):
     """the post-convergence calls of the caller's verifier (rrl/itkLocationRegistration.cxx:1816-1871):
     forward angles / error, estimate_LS_backward(false), backward angles / error / covariance — batch
